@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the rasterizer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): Msplats/s forward+backward @ 1 M Gaussians, 1920x1080, SH degree 3
+(config C3, synthetic scene A of SURVEY.md §8d), colour + depth targets with upstream gradients.
+One "step" = one `GaussianRasterizer` forward + `torch.autograd.backward` through the C ABI, inputs
+resident in HBM.  N > 1: view-parallel -- rank 0 broadcasts the Gaussian buffers over RCCL once
+(outside the timed region), every rank then renders its own camera view; no data-path collective
+(weak scaling).  Rank 0 prints ONE JSON line with the bench contract keys plus
+
+  "roofline":     dominant kernel, ALGORITHMIC bytes per launch / mean launch time (hipEvents
+                  recorded by the library on the launch stream during the timed region) vs 8 TB/s
+  "cpu_baseline": the CPU oracle (a port of the reference algorithm, OpenMP) on the same workload,
+                  rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+CONFIGS = {
+    # name: (P, W, H, sh_degree, backward)
+    "c2": (100_000, 800, 800, 1, False),
+    "c3": (1_000_000, 1920, 1080, 3, True),
+    "c5": (5_000_000, 1920, 1080, 3, True),
+}
+
+
+def algorithmic_bytes(P, M, R, N):
+    """Per-stage ALGORITHMIC bytes of one launch (SURVEY.md §8d derivation)."""
+    return {
+        "preprocess": (44 + 12 * M + 75) * P,
+        "scan_tiles": 8 * (N // 256 + 1),
+        "scatter": 20 * P + 12 * R,
+        "sort_tiles": 24 * R,
+        "render_fwd": 4 * R + 40 * P + 24 * N,
+        "zero_grads": 0,
+        "render_bwd": 4 * R + 40 * P + 20 * N + 36 * P,
+        "preprocess_bwd": (56 + 36 + 107 + 12 * M + 40 + 12 * M) * P,
+    }
+
+
+def step_bytes(P, M, R, N, backward):
+    if backward:
+        return (502 + 36 * M) * P + 52 * R + 44 * N
+    return (187 + 12 * M) * P + 48 * R + 24 * N
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--gaussians", type=int, default=0, help="override P (experiments only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in bloomscene_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
+    from bloomscene_amd.synthetic import scene_a, upstream_grads
+    from bloomscene_amd.views import broadcast_gaussians, yawed_camera
+
+    P, W, H, deg, do_bwd = CONFIGS[args.config]
+    if args.gaussians:
+        P = args.gaussians
+    M = (deg + 1) ** 2
+    N = W * H
+
+    # ---- inputs: generated on rank 0's host, broadcast over RCCL/xGMI, resident in HBM ----
+    names = ("means3D", "scales", "rotations", "opacities", "shs")
+    if rank == 0:
+        sc = scene_a(P, W, H, deg, seed=0)
+        bufs = {k: getattr(sc, k).to(dev) for k in names}
+    else:
+        shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1), "shs": (P, M, 3)}
+        bufs = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in names}
+    bcast_ms = broadcast_gaussians(bufs, src=0) if world > 1 else 0.0
+    gC, gD = upstream_grads(W, H, seed=1)
+    gC, gD = gC.to(dev), gD.to(dev)
+    # independent views: rank r looks 0.25*r degrees to the side of the scene-A camera
+    cam = yawed_camera(W, H, math.radians(60.0), yaw_deg=0.25 * rank).to(dev)
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(settings)
+    leaves = {k: v.requires_grad_(do_bwd) for k, v in bufs.items()}
+    state = {}
+
+    def step():
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=do_bwd)
+        color, radii, depth = rasterizer(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                         shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        if do_bwd:
+            for v in leaves.values():
+                v.grad = None
+            torch.autograd.backward((color, depth), (gC, gD))
+        state["radii"] = radii
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _capi.profile_read()
+    _capi.profile_enable(False)
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # instances of this rank's view, for the algorithmic byte count
+    from bloomscene_amd.rasterizer import _rasterize_gaussians_native
+    e = torch.Tensor([])
+    with torch.no_grad():
+        R = _rasterize_gaussians_native(settings.bg, bufs["means3D"], e, bufs["opacities"], bufs["scales"],
+                                        bufs["rotations"], 1.0, e, settings.viewmatrix, settings.projmatrix,
+                                        settings.tanfovx, settings.tanfovy, H, W, bufs["shs"], deg, settings.campos,
+                                        False, False)[0]
+    visible = int((state["radii"] > 0).sum().item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * P * args.steps / dt / 1e6
+        stages = {k: v[0] / max(v[1], 1) for k, v in prof.items()}  # mean ms per launch
+        alg = algorithmic_bytes(P, M, R, N)
+        dom = max(stages, key=lambda k: stages[k]) if stages else None
+        roofline = None
+        if dom is not None:
+            achieved = alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4)}
+        whole = step_bytes(P, M, R, N, do_bwd) / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if args.config == "c3"
+            else f"Msplats/s ({args.config})",
+            "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P} Gaussians, SH deg {deg}, {W}x{H}, "
+                                   f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}, synthetic scene A seed 0",
+                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
+                       "visible": visible, "parallelism": f"view-parallel x{world}",
+                       "broadcast_ms": round(bcast_ms, 3)},
+            "roofline": roofline,
+            "roofline_step": {"algorithmic_bytes": step_bytes(P, M, R, N, do_bwd), "achieved": round(whole, 2),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},
+            "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, P, W, H, deg, do_bwd):
+    """The CPU oracle (oracle/bsr_oracle.c: a port of the reference algorithm, OpenMP over
+    Gaussians/tiles) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from bloomscene_amd.synthetic import scene_a, upstream_grads
+    cores = os.cpu_count() or 1
+    Ps = args.cpu_sample or min(P, max(50_000, 125_000 * cores))   # ~10-30 s of CPU work
+    sc = scene_a(Ps, W, H, deg, seed=0)
+    cam = sc.cameras[0]
+    rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
+                         cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center)
+    gC, gD = upstream_grads(W, H, seed=1)
+    O.lib()
+    t0 = time.perf_counter()
+    st = O.forward(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    if do_bwd:
+        O.backward(st, gC, gD)
+    dt = time.perf_counter() - t0
+    return {"value": round(Ps / dt / 1e6, 4), "unit": "Msplats/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of the same workload with {Ps} Gaussians ({'fwd+bwd' if do_bwd else 'fwd'}, "
+                      f"{W}x{H}, SH deg {deg}), {dt:.1f} s, OpenMP over {cores} host threads"}
+
+
+if __name__ == "__main__":
+    main()

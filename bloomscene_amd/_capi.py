@@ -1,0 +1,96 @@
+"""ctypes binding of ``libbloomscene_rast.so`` (C ABI declared in ``include/bloomscene_rast.h``).
+
+The library is built in-tree (``bloomscene_amd/csrc/Makefile``, hipcc --offload-arch=gfx950).
+There is deliberately NO fallback: if the shared object is missing or a call fails, this module
+raises -- the product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbloomscene_rast.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+_F = C.c_void_p  # device pointer
+
+
+class StageProfile(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/bloomscene_rast.h declares
+SIGNATURES = {
+    "bsr_version": (C.c_int, []),
+    "bsr_last_error": (C.c_char_p, []),
+    "bsr_mark_visible": (C.c_int, [C.c_int, _F, _F, _F, _F, C.c_void_p]),
+    "bsr_forward": (C.c_int, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                              C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, C.c_float, _F, _F,
+                              _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int, C.c_void_p,
+                              C.POINTER(C.c_int)]),
+    "bsr_visible_filter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
+                                     C.c_float, C.c_float, C.c_int, _F, C.c_int, C.c_void_p]),
+    "bsr_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
+                               _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
+                               _F, _F, _F, _F, C.c_int, C.c_void_p]),
+    "bsr_geometry_bytes": (C.c_size_t, [C.c_int]),
+    "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
+    "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "bsr_profile_enable": (C.c_int, [C.c_int]),
+    "bsr_profile_reset": (C.c_int, []),
+    "bsr_profile_read": (C.c_int, [C.POINTER(StageProfile), C.c_int]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Load the library; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+                "bloomscene_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().bsr_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {last_error()}")
+
+
+def profile_enable(on: bool):
+    lib().bsr_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().bsr_profile_reset()
+
+
+def profile_read():
+    """-> {stage name: (total_ms, launches)} accumulated since the last reset."""
+    arr = (StageProfile * 16)()
+    n = lib().bsr_profile_read(arr, 16)
+    return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n)}

@@ -1,0 +1,443 @@
+// C ABI (include/bloomscene_rast.h) and host orchestration of the gfx950 rasterizer.
+//
+// Stage order of one forward call (cf. the reference's CudaRasterizer::Rasterizer::forward,
+// cuda_rasterizer/rasterizer_impl.cu:198-339):
+//   memset(tile_count) -> k_preprocess (project, cull, SH, count instances per tile)
+//   -> k_scan_tiles (tile ranges) -> 4-byte D2H read of R -> binning alloc
+//   -> k_scatter -> k_sort_tiles (per-tile LDS sort) -> k_render_fwd.
+// Backward (rasterizer_impl.cu:403-504): memset(4 accumulators) -> k_render_bwd -> k_preprocess_bwd.
+#include "../../include/bloomscene_rast.h"
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace bsr {
+
+// ---------------------------------------------------------------- scratch layouts
+size_t GeomState::bytes(size_t P)
+{
+	size_t s = 0;
+	s += align_up(P * 3 * sizeof(float4), 256);
+	s += align_up(P * sizeof(ushort4), 256);
+	s += align_up(P * 6 * sizeof(float), 256);
+	s += align_up(P * sizeof(uint8_t), 256);
+	return s + 256;
+}
+GeomState GeomState::carve(char* p, size_t P)
+{
+	GeomState g;
+	p = (char*)align_up((size_t)p, 256);
+	g.rec = (float4*)p;      p += align_up(P * 3 * sizeof(float4), 256);
+	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
+	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
+	g.clamped = (uint8_t*)p;
+	return g;
+}
+size_t BinState::bytes(size_t R)
+{
+	return align_up(R * sizeof(uint64_t), 256) + align_up(R * sizeof(uint32_t), 256) + 256;
+}
+BinState BinState::carve(char* p, size_t R)
+{
+	BinState b;
+	p = (char*)align_up((size_t)p, 256);
+	b.keys = (uint64_t*)p;   p += align_up(R * sizeof(uint64_t), 256);
+	b.point_list = (uint32_t*)p;
+	return b;
+}
+size_t ImgState::bytes(size_t N, size_t T)
+{
+	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 2 * align_up(T * 4, 256) + 256 + 256;
+}
+ImgState ImgState::carve(char* p, size_t N, size_t T)
+{
+	ImgState i;
+	p = (char*)align_up((size_t)p, 256);
+	i.final_T = (float*)p;        p += align_up(N * 4, 256);
+	i.n_contrib = (uint32_t*)p;   p += align_up(N * 4, 256);
+	i.tile_start = (uint32_t*)p;  p += align_up((T + 1) * 4, 256);
+	i.tile_count = (uint32_t*)p;  p += align_up(T * 4, 256);
+	i.tile_cursor = (uint32_t*)p; p += align_up(T * 4, 256);
+	i.flags = (int*)p;
+	return i;
+}
+
+// ---------------------------------------------------------------- kernels (other translation units)
+void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
+void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, hipStream_t s);
+void launch_scatter(int P, int gx, const ushort4* rect, const float4* rec, const uint32_t* tile_start,
+                    uint32_t* tile_cursor, uint64_t* keys, hipStream_t s);
+void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
+                       hipStream_t s);
+void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+                       const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                       float* out_depth, hipStream_t s);
+void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                       hipStream_t s);
+void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return 1;
+}
+
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t _e = (expr);                                                                    \
+		if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+	} while (0)
+
+// After a launch: always catch launch errors; with debug also synchronise (reference CHECK_CUDA,
+// cuda_rasterizer/auxiliary.h:166-173).
+#define STAGE_CHECK(name, debug, stream)                                                           \
+	do {                                                                                           \
+		hipError_t _e = hipGetLastError();                                                         \
+		if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                        \
+		if (_e != hipSuccess) return fail("stage %s failed: %s", name, hipGetErrorString(_e));     \
+	} while (0)
+
+// ---------------------------------------------------------------- stage profiler (bench only)
+struct StageRec {
+	const char* name;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	double total_ms = 0;
+	int launches = 0;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<StageRec> g_stages;
+
+struct StageTimer {
+	hipStream_t s;
+	StageRec* rec = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	StageTimer(const char* name, hipStream_t stream) : s(stream)
+	{
+		if (!g_prof_on) return;
+		std::lock_guard<std::mutex> lk(g_prof_mu);
+		for (auto& r : g_stages)
+			if (r.name == name || !strcmp(r.name, name)) rec = &r;
+		if (!rec) {
+			if (g_stages.size() >= BSR_PROFILE_MAX_STAGES) return;
+			g_stages.reserve(BSR_PROFILE_MAX_STAGES);
+			g_stages.push_back(StageRec{name});
+			rec = &g_stages.back();
+		}
+		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rec = nullptr; return; }
+		(void)hipEventRecord(e0, s);
+	}
+	~StageTimer()
+	{
+		if (!rec) return;
+		(void)hipEventRecord(e1, s);
+		std::lock_guard<std::mutex> lk(g_prof_mu);
+		rec->ev.emplace_back(e0, e1);
+	}
+};
+
+}  // namespace bsr
+
+using namespace bsr;
+
+extern "C" {
+
+int bsr_version(void) { return BSR_VERSION; }
+const char* bsr_last_error(void) { return g_err; }
+
+size_t bsr_geometry_bytes(int P) { return GeomState::bytes((size_t)(P > 0 ? P : 0)); }
+size_t bsr_binning_bytes(int R) { return BinState::bytes((size_t)(R > 0 ? R : 0)); }
+size_t bsr_image_bytes(int W, int H)
+{
+	const size_t gx = (W + BSR_TILE - 1) / BSR_TILE, gy = (H + BSR_TILE - 1) / BSR_TILE;
+	return ImgState::bytes((size_t)W * H, gx * gy);
+}
+
+int bsr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+
+int bsr_profile_reset(void)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	for (auto& r : g_stages) {
+		for (auto& p : r.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+		r.ev.clear();
+		r.total_ms = 0;
+		r.launches = 0;
+	}
+	return 0;
+}
+
+int bsr_profile_read(bsr_stage_profile* out, int max_stages)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	int n = 0;
+	for (auto& r : g_stages) {
+		for (auto& p : r.ev) {
+			float ms = 0;
+			if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+				r.total_ms += ms;
+				r.launches++;
+			}
+			(void)hipEventDestroy(p.first);
+			(void)hipEventDestroy(p.second);
+		}
+		r.ev.clear();
+		if (n < max_stages) {
+			out[n].name = r.name;
+			out[n].total_ms = r.total_ms;
+			out[n].launches = r.launches;
+			n++;
+		}
+	}
+	return n;
+}
+
+int bsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+	(void)projmatrix;
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (P <= 0) return 0;
+	if (!means3D || !viewmatrix || !present) return fail("bsr_mark_visible: null pointer");
+	{
+		StageTimer t("mark_visible", s);
+		launch_mark_visible(P, means3D, viewmatrix, present, s);
+	}
+	STAGE_CHECK("mark_visible", 0, s);
+	return 0;
+}
+
+static int check_common(int P, int width, int height, const float* means3D, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix)
+{
+	if (P < 0 || width <= 0 || height <= 0) return fail("invalid sizes: P=%d width=%d height=%d", P, width, height);
+	if ((width + BSR_TILE - 1) / BSR_TILE > 65535 || (height + BSR_TILE - 1) / BSR_TILE > 65535)
+		return fail("image too large for 16-bit tile coordinates");
+	if (P > 0 && !means3D) return fail("means3D is null");
+	if (!viewmatrix || !projmatrix) return fail("viewmatrix/projmatrix is null");
+	const bool has_sr = scales != nullptr && rotations != nullptr;
+	const bool has_any_sr = scales != nullptr || rotations != nullptr;
+	if (P > 0 && ((!has_sr && !cov3D_precomp) || (has_any_sr && cov3D_precomp)))
+		return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+	return 0;
+}
+
+int bsr_visible_filter(int P, int M, int width, int height, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, float tan_fovx, float tan_fovy,
+                       int prefiltered, int* radii, int debug, void* stream)
+{
+	(void)M;
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
+	if (P == 0) return 0;
+	if (!radii) return fail("radii is null");
+	int* d_flag = nullptr;
+	if (prefiltered) {
+		HIP_TRY(hipMallocAsync((void**)&d_flag, sizeof(int), s));
+		HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+	}
+	PreArgs a;
+	memset(&a, 0, sizeof(a));
+	a.P = P; a.D = 0; a.M = 0;
+	a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
+	a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix;
+	a.W = width; a.H = height; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+	a.focal_y = height / (2.0f * tan_fovy);
+	a.focal_x = width / (2.0f * tan_fovx);
+	a.gx = (width + BSR_TILE - 1) / BSR_TILE; a.gy = (height + BSR_TILE - 1) / BSR_TILE;
+	a.prefiltered = prefiltered; a.radii = radii; a.flags = d_flag;
+	{
+		StageTimer t("visible_filter", s);
+		launch_preprocess(a, true, s);
+	}
+	STAGE_CHECK("visible_filter", debug, s);
+	if (prefiltered) {
+		int h = 0;
+		HIP_TRY(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+		HIP_TRY(hipStreamSynchronize(s));
+		HIP_TRY(hipFreeAsync(d_flag, s));
+		if (h) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+	}
+	return 0;
+}
+
+int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer, void* binning_user,
+                bsr_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
+                int debug, void* stream, int* num_rendered)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (num_rendered) *num_rendered = 0;
+	if (P == 0) {   // reference rasterize_points.cu:68-82: zero images, no scratch, num_rendered = 0
+		if (width <= 0 || height <= 0 || !out_color || !out_depth) return fail("invalid image outputs");
+		HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), s));
+		HIP_TRY(hipMemsetAsync(out_depth, 0, (size_t)width * height * sizeof(float), s));
+		return 0;
+	}
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
+	if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail("scratch allocation callback is null");
+	if (!out_color || !out_depth || !background) return fail("out_color/out_depth/background is null");
+	if (P > 0) {
+		if (!opacities) return fail("opacities is null");
+		if ((shs == nullptr) == (colors_precomp == nullptr))
+			return fail("Please provide excatly one of either SHs or precomputed colors!");
+		if (shs && (!cam_pos || M <= 0)) return fail("SH colours need cam_pos and M > 0");
+		if (shs && D >= 0 && (D + 1) * (D + 1) > M && D <= 3)
+			return fail("sh_degree %d needs %d coefficients but M = %d", D, (D + 1) * (D + 1), M);
+	}
+	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
+	const int T = gx * gy;
+	const size_t N = (size_t)width * height;
+
+	char* geom_p = geometryBuffer(geometry_user, GeomState::bytes((size_t)P));
+	char* img_p = imageBuffer(image_user, ImgState::bytes(N, (size_t)T));
+	if (!geom_p || !img_p) return fail("scratch allocation callback returned null");
+	GeomState geom = GeomState::carve(geom_p, (size_t)P);
+	ImgState img = ImgState::carve(img_p, N, (size_t)T);
+
+	// tile_count, tile_cursor and flags are contiguous: clear them in one go
+	HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)img.flags - (char*)img.tile_count) + 4 * sizeof(int), s));
+
+	if (P > 0) {
+		PreArgs a;
+		memset(&a, 0, sizeof(a));
+		a.P = P; a.D = D; a.M = M;
+		a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
+		a.opacities = opacities; a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+		a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
+		a.W = width; a.H = height; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+		a.focal_y = height / (2.0f * tan_fovy);   // reference rasterizer_impl.cu:223-224
+		a.focal_x = width / (2.0f * tan_fovx);
+		a.gx = gx; a.gy = gy; a.prefiltered = prefiltered; a.radii = radii; a.geom = geom;
+		a.tile_count = img.tile_count; a.flags = img.flags;
+		{
+			StageTimer t("preprocess", s);
+			launch_preprocess(a, false, s);
+		}
+		STAGE_CHECK("preprocess", debug, s);
+	}
+	{
+		StageTimer t("scan_tiles", s);
+		launch_scan_tiles(T, img.tile_count, img.tile_start, img.tile_cursor, s);
+	}
+	STAGE_CHECK("scan_tiles", debug, s);
+
+	// num_rendered (and the prefiltered flag) -> host; the one blocking read of the forward pass
+	uint32_t h_R = 0;
+	int h_flag = 0;
+	HIP_TRY(hipMemcpyAsync(&h_R, img.tile_start + T, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	if (prefiltered) HIP_TRY(hipMemcpyAsync(&h_flag, img.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipStreamSynchronize(s));
+	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
+	const int R = (int)h_R;
+	if (num_rendered) *num_rendered = R;
+
+	char* bin_p = binningBuffer(binning_user, BinState::bytes((size_t)R));
+	if (!bin_p) return fail("scratch allocation callback returned null");
+	BinState bin = BinState::carve(bin_p, (size_t)R);
+
+	if (R > 0) {
+		{
+			StageTimer t("scatter", s);
+			launch_scatter(P, gx, geom.rect, geom.rec, img.tile_start, img.tile_cursor, bin.keys, s);
+		}
+		STAGE_CHECK("scatter", debug, s);
+		{
+			StageTimer t("sort_tiles", s);
+			launch_sort_tiles(T, 0, img.tile_start, bin.keys, bin.point_list, s);
+		}
+		STAGE_CHECK("sort_tiles", debug, s);
+	}
+	{
+		StageTimer t("render_fwd", s);
+		launch_render_fwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
+		                  img.n_contrib, out_color, out_depth, s);
+	}
+	STAGE_CHECK("render_fwd", debug, s);
+	return 0;
+}
+
+int bsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                 char* binning_buffer, char* image_buffer, const float* dL_dpix, const float* dL_depths,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+	(void)dL_depths;   // accepted and ignored, as in the reference (backward.cu:457-463,539-554)
+	(void)colors_precomp;
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (P == 0) return 0;
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
+	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("scratch buffer is null");
+	if (!dL_dpix || !background) return fail("dL_dpix/background is null");
+	if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+		return fail("gradient output is null");
+	if (shs && (M <= 0 || !dL_dsh || !campos)) return fail("SH backward needs M > 0, dL_dsh and campos");
+	if (scales && (!dL_dscale || !dL_drot)) return fail("dL_dscale/dL_drot is null");
+
+	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
+	const int T = gx * gy;
+	const size_t N = (size_t)width * height;
+	GeomState geom = GeomState::carve(geom_buffer, (size_t)P);
+	ImgState img = ImgState::carve(image_buffer, N, (size_t)T);
+	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0));
+
+	{
+		StageTimer t("zero_grads", s);
+		HIP_TRY(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), s));
+		HIP_TRY(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), s));
+		HIP_TRY(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), s));
+		HIP_TRY(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * sizeof(float), s));
+	}
+	if (R > 0) {
+		{
+			StageTimer t("render_bwd", s);
+			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
+			                  img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
+		}
+		STAGE_CHECK("render_bwd", debug, s);
+	}
+	BwdArgs a;
+	memset(&a, 0, sizeof(a));
+	a.P = P; a.D = D; a.M = M;
+	a.means3D = means3D; a.radii = radii; a.shs = shs; a.scales = scales; a.rotations = rotations;
+	a.scale_modifier = scale_modifier; a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix;
+	a.projmatrix = projmatrix; a.campos = campos; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+	a.focal_y = height / (2.0f * tan_fovy);
+	a.focal_x = width / (2.0f * tan_fovx);
+	a.geom = geom;
+	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dcolor = dL_dcolor;
+	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
+	{
+		StageTimer t("preprocess_bwd", s);
+		launch_preprocess_bwd(a, s);
+	}
+	STAGE_CHECK("preprocess_bwd", debug, s);
+	return 0;
+}
+
+}  // extern "C"

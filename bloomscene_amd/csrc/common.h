@@ -1,0 +1,120 @@
+// Shared declarations for the gfx950 rasterizer kernels.  Built with -ffp-contract=off: every
+// fp32 expression is evaluated in source order; the only fused multiply-adds are the explicit
+// fmaf() calls in bsr_expf, so forward results can be compared bit for bit with the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BSR_TILE 16          // reference cuda_rasterizer/config.h:15-16
+#define BSR_BLOCK 256        // one 16x16 tile per workgroup = 4 wave64
+#define BSR_NEAR 0.2f        // reference cuda_rasterizer/auxiliary.h:154
+
+namespace bsr {
+
+// Private layout of the three scratch buffers (opaque to callers).
+// Per-Gaussian "splat record": everything the tile kernels gather per list entry, 48 B:
+//   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, power_cut, opacity, depth)   q2 = (r, g, b, 0)
+struct GeomState {
+	float4* rec;        // [P][3]
+	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
+	float* cov3D;       // [P][6]
+	uint8_t* clamped;   // [P] bit ch = SH colour channel ch was clamped at 0
+	static size_t bytes(size_t P);
+	static GeomState carve(char* p, size_t P);
+};
+struct BinState {
+	uint64_t* keys;       // [R] (depth_bits << 32 | gaussian id), tile-major, unsorted then sorted
+	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted
+	static size_t bytes(size_t R);
+	static BinState carve(char* p, size_t R);
+};
+struct ImgState {
+	float* final_T;        // [N]
+	uint32_t* n_contrib;   // [N]
+	uint32_t* tile_start;  // [T + 1] exclusive scan of tile_count; ranges[t] = [start[t], start[t+1])
+	uint32_t* tile_count;  // [T]
+	uint32_t* tile_cursor; // [T]
+	int* flags;            // [4]: 0 = prefiltered violation
+	static size_t bytes(size_t N, size_t T);
+	static ImgState carve(char* p, size_t N, size_t T);
+};
+
+// Kernel argument blocks (passed by value).
+struct PreArgs {
+	int P, D, M;
+	const float* means3D;
+	const float* scales;
+	float scale_modifier;
+	const float* rotations;
+	const float* opacities;
+	const float* shs;
+	const float* cov3D_precomp;
+	const float* colors_precomp;
+	const float* viewmatrix;
+	const float* projmatrix;
+	const float* cam_pos;
+	int W, H;
+	float tan_fovx, tan_fovy, focal_x, focal_y;
+	int gx, gy;
+	int prefiltered;
+	int* radii;          // may be NULL
+	GeomState geom;
+	uint32_t* tile_count;
+	int* flags;
+};
+
+struct BwdArgs {
+	int P, D, M;
+	const float* means3D;
+	const int* radii;
+	const float* shs;
+	const float* scales;
+	const float* rotations;
+	float scale_modifier;
+	const float* cov3D_precomp;
+	const float* viewmatrix;
+	const float* projmatrix;
+	const float* campos;
+	float tan_fovx, tan_fovy, focal_x, focal_y;
+	GeomState geom;
+	const float* dL_dmean2D;   // [P,3]
+	const float* dL_dconic;    // [P,4]
+	const float* dL_dcolor;    // [P,3]
+	float* dL_dmean3D;         // [P,3]
+	float* dL_dcov3D;          // [P,6]
+	float* dL_dsh;             // [P,M,3]
+	float* dL_dscale;          // [P,3]
+	float* dL_drot;            // [P,4]
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+
+// ---- pinned exp: identical algorithm to bsro_expf in oracle/bsr_oracle.c (<= 1 ulp) ----
+__device__ __forceinline__ float bsr_expf(float x)
+{
+	if (x != x) return x;
+	if (x < -104.0f) return 0.0f;
+	if (x > 88.72284f) return __builtin_inff();
+	const float k = __builtin_rintf(x * 1.44269504088896341f);
+	float r = __builtin_fmaf(-k, 0.693359375f, x);
+	r = __builtin_fmaf(-k, -2.12194440e-4f, r);
+	float p = 1.0f / 5040.0f;
+	p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+	p = __builtin_fmaf(p, r, 0.5f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	return __builtin_ldexpf(p, (int)k);
+}
+
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a
+// contiguous band of tiles; neighbouring tiles gather many of the same splat records.
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles)
+{
+	const int per = (n_tiles + 7) >> 3;
+	return (b & 7) * per + (b >> 3);
+}
+
+}  // namespace bsr

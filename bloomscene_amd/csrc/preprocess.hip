@@ -1,0 +1,204 @@
+// Per-Gaussian front end: view-space projection, near cull, cov3D/cov2D/conic, radius, tile rect,
+// SH -> RGB, per-tile instance counting.  One thread per Gaussian (HBM-bound streaming kernel).
+//
+// Semantics follow the reference kernels preprocessCUDA / filter_preprocessCUDA / checkFrustum
+// (cuda_rasterizer/forward.cu:155-335, rasterizer_impl.cu:54-66 under
+// /root/reference/submodules/depth-diff-gaussian-rasterization); the GLM column-major products
+// are written out with their zero terms dropped, keeping the order of the remaining operations.
+#include "common.h"
+#include "sh.h"
+
+namespace bsr {
+
+struct Cov2DTerms {
+	float t0[3], t1[3];   // T[0][k], T[1][k] in the reference's glm indexing (rows of J*Rwc)
+	float tx, ty, tz;     // clamped view-space mean
+	float xmul, ymul;     // 0 where the +-1.3 guard-band clamp was active
+};
+
+// reference forward.cu:74-113 / backward.cu:162-194 (shared prologue)
+__device__ __forceinline__ void cov2d_terms(const float3 mean, float focal_x, float focal_y, float tan_fovx,
+                                            float tan_fovy, const float* __restrict__ vm, Cov2DTerms& o)
+{
+	float tx = vm[0] * mean.x + vm[4] * mean.y + vm[8] * mean.z + vm[12];
+	float ty = vm[1] * mean.x + vm[5] * mean.y + vm[9] * mean.z + vm[13];
+	const float tz = vm[2] * mean.x + vm[6] * mean.y + vm[10] * mean.z + vm[14];
+	const float limx = 1.3f * tan_fovx;
+	const float limy = 1.3f * tan_fovy;
+	const float txtz = tx / tz;
+	const float tytz = ty / tz;
+	tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+	ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+	o.xmul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+	o.ymul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+	const float J00 = focal_x / tz;
+	const float J02 = -(focal_x * tx) / (tz * tz);
+	const float J11 = focal_y / tz;
+	const float J12 = -(focal_y * ty) / (tz * tz);
+	// T = W * J with W[0]=(vm0,vm4,vm8), W[1]=(vm1,vm5,vm9), W[2]=(vm2,vm6,vm10)
+	o.t0[0] = vm[0] * J00 + vm[2] * J02;
+	o.t0[1] = vm[4] * J00 + vm[6] * J02;
+	o.t0[2] = vm[8] * J00 + vm[10] * J02;
+	o.t1[0] = vm[1] * J11 + vm[2] * J12;
+	o.t1[1] = vm[5] * J11 + vm[6] * J12;
+	o.t1[2] = vm[9] * J11 + vm[10] * J12;
+	o.tx = tx; o.ty = ty; o.tz = tz;
+}
+
+// cov = T^t * Vrk^t * T, entries (0,0), (0,1), (1,1), +0.3 low-pass (forward.cu:104-112)
+__device__ __forceinline__ void cov2d_eval(const Cov2DTerms& t, const float* c, float& a, float& b, float& cc)
+{
+	// A[col][0] = T0 . V[:,col],  A[col][1] = T1 . V[:,col]
+	const float A00 = t.t0[0] * c[0] + t.t0[1] * c[1] + t.t0[2] * c[2];
+	const float A10 = t.t0[0] * c[1] + t.t0[1] * c[3] + t.t0[2] * c[4];
+	const float A20 = t.t0[0] * c[2] + t.t0[1] * c[4] + t.t0[2] * c[5];
+	const float A01 = t.t1[0] * c[0] + t.t1[1] * c[1] + t.t1[2] * c[2];
+	const float A11 = t.t1[0] * c[1] + t.t1[1] * c[3] + t.t1[2] * c[4];
+	const float A21 = t.t1[0] * c[2] + t.t1[1] * c[4] + t.t1[2] * c[5];
+	a = A00 * t.t0[0] + A10 * t.t0[1] + A20 * t.t0[2];
+	b = A01 * t.t0[0] + A11 * t.t0[1] + A21 * t.t0[2];
+	cc = A01 * t.t1[0] + A11 * t.t1[1] + A21 * t.t1[2];
+	a += 0.3f;
+	cc += 0.3f;
+}
+
+// reference forward.cu:118-152 (quaternion NOT normalised, :127)
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float4 q, float* cov3D)
+{
+	const float s0 = mod * scale[0], s1 = mod * scale[1], s2 = mod * scale[2];
+	const float r = q.x, x = q.y, y = q.z, z = q.w;
+	// M[c][k] = s_k * R[c][k]
+	const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)), m02 = s2 * (2.f * (x * z + r * y));
+	const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)), m12 = s2 * (2.f * (y * z - r * x));
+	const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)), m22 = s2 * (1.f - 2.f * (x * x + y * y));
+	cov3D[0] = m00 * m00 + m01 * m01 + m02 * m02;
+	cov3D[1] = m10 * m00 + m11 * m01 + m12 * m02;
+	cov3D[2] = m20 * m00 + m21 * m01 + m22 * m02;
+	cov3D[3] = m10 * m10 + m11 * m11 + m12 * m12;
+	cov3D[4] = m20 * m10 + m21 * m11 + m22 * m12;
+	cov3D[5] = m20 * m20 + m21 * m21 + m22 * m22;
+}
+
+// reference auxiliary.h:41-44 (double-precision literals)
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// reference auxiliary.h:46-56
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, int* rmin, int* rmax)
+{
+	rmin[0] = min(gx, max(0, (int)((px - max_radius) / BSR_TILE)));
+	rmin[1] = min(gy, max(0, (int)((py - max_radius) / BSR_TILE)));
+	rmax[0] = min(gx, max(0, (int)((px + max_radius + BSR_TILE - 1) / BSR_TILE)));
+	rmax[1] = min(gy, max(0, (int)((py + max_radius + BSR_TILE - 1) / BSR_TILE)));
+}
+
+
+template <bool FILTER_ONLY>
+__global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= a.P) return;
+
+	int radius_out = 0;
+	ushort4 rect_out = make_ushort4(0, 0, 0, 0);
+
+	const float3 p = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+	const float* vm = a.viewmatrix;
+	const float* pm = a.projmatrix;
+	const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+	bool alive = !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
+	if (!alive && a.prefiltered) a.flags[0] = 1;
+
+	if (alive) {
+		const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+		const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+		const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+		const float p_w = 1.0f / (hw + 0.0000001f);
+		const float projx = hx * p_w, projy = hy * p_w;
+
+		float cov3D[6];
+		if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
+		} else {
+			const float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+			const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+			cov3d_from_scale_rot(sc, a.scale_modifier, q, cov3D);
+		}
+		if (!FILTER_ONLY) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)idx * 6 + k] = cov3D[k];
+		}
+
+		Cov2DTerms tt;
+		cov2d_terms(p, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, vm, tt);
+		float ca, cb, cc;
+		cov2d_eval(tt, cov3D, ca, cb, cc);
+
+		const float det = (ca * cc - cb * cb);
+		if (det != 0.0f) {
+			const float det_inv = 1.f / det;
+			const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+			const float mid = 0.5f * (ca + cc);
+			const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+			const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+			const float pix_x = ndc2pix(projx, a.W), pix_y = ndc2pix(projy, a.H);
+			int rmin[2], rmax[2];
+			get_rect(pix_x, pix_y, (int)my_radius, a.gx, a.gy, rmin, rmax);
+			if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) != 0) {
+				radius_out = (int)my_radius;
+				if (!FILTER_ONLY) {
+					rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)rmin[1],
+					                        (unsigned short)rmax[0], (unsigned short)rmax[1]);
+					float rgb[3];
+					uint8_t clamp_bits = 0;
+					if (a.colors_precomp == nullptr) {
+						sh_to_rgb(a.D, a.M, p, a.cam_pos, a.shs + (size_t)idx * a.M * 3, rgb, clamp_bits);
+					} else {
+						rgb[0] = a.colors_precomp[3 * idx];
+						rgb[1] = a.colors_precomp[3 * idx + 1];
+						rgb[2] = a.colors_precomp[3 * idx + 2];
+					}
+					const float opacity = a.opacities[idx];
+					// alpha = min(0.99, o*exp(power)) < 1/255  <=>  power < -ln(255*o); keep a margin far
+					// above the rounding of logf/expf so the cut only skips pairs the exact test rejects.
+					const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
+					float4* rec = a.geom.rec + (size_t)idx * 3;
+					rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
+					rec[1] = make_float4(conic_c, power_cut, opacity, pvz);
+					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
+					a.geom.clamped[idx] = clamp_bits;
+					for (int y = rmin[1]; y < rmax[1]; y++)
+						for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+				}
+			}
+		}
+	}
+	if (a.radii) a.radii[idx] = radius_out;
+	if (!FILTER_ONLY) a.geom.rect[idx] = rect_out;
+}
+
+__global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __restrict__ means3D,
+                                                      const float* __restrict__ vm, uint8_t* __restrict__ present)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const float pvz = vm[2] * means3D[3 * idx] + vm[6] * means3D[3 * idx + 1] + vm[10] * means3D[3 * idx + 2] + vm[14];
+	present[idx] = !(pvz <= BSR_NEAR);
+}
+
+void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s)
+{
+	const int blocks = (a.P + 255) / 256;
+	if (filter_only)
+		hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, s, a);
+	else
+		hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, s, a);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vm, present);
+}
+
+}  // namespace bsr

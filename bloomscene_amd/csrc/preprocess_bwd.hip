@@ -1,0 +1,233 @@
+// Per-Gaussian backward: dL/d(conic, mean2D, colour) -> dL/d(mean3D, cov3D, SH, scale, rotation).
+//
+// Fuses the reference's two kernels computeCov2DCUDA (cuda_rasterizer/backward.cu:144-274) and
+// preprocessCUDA (:346-396, with computeColorFromSH :20-139 and computeCov3D :278-341) into one
+// streaming pass: dL_dmean3D is assigned by the cov2D part and then incremented by the projection
+// and SH parts in the reference's order, without the round trip through HBM.  Rows of culled
+// Gaussians are written as zeros here, so callers need no 300 MB memset
+// (rasterize_points.cu:154-162 zero-fills everything up front).
+#include "common.h"
+#include "sh.h"
+
+namespace bsr {
+
+
+__device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, const float* v, int n_valid)
+{
+	// dst: 3*M floats of this Gaussian; v holds n_valid floats, the rest are zero.
+	if ((M & 3) == 0) {
+		float4* d4 = reinterpret_cast<float4*>(dst);
+		const int nv = (M * 3) >> 2;
+#pragma unroll 12
+		for (int i = 0; i < nv; i++) {
+			float4 o;
+			o.x = (i * 4 + 0 < n_valid) ? v[i * 4 + 0] : 0.f;
+			o.y = (i * 4 + 1 < n_valid) ? v[i * 4 + 1] : 0.f;
+			o.z = (i * 4 + 2 < n_valid) ? v[i * 4 + 2] : 0.f;
+			o.w = (i * 4 + 3 < n_valid) ? v[i * 4 + 3] : 0.f;
+			d4[i] = o;
+		}
+	} else {
+		for (int i = 0; i < M * 3; i++) dst[i] = (i < n_valid) ? v[i] : 0.f;
+	}
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const float3 m, float* dmean)
+{
+	constexpr int NC = (DEG + 1) * (DEG + 1);
+	float c[NC * 3];
+	load_sh<NC>(a.shs + (size_t)idx * a.M * 3, a.M, c);
+	const float ox = m.x - a.campos[0], oy = m.y - a.campos[1], oz = m.z - a.campos[2];
+	const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+	const float x = ox / len, y = oy / len, z = oz / len;
+	const uint8_t cl = a.geom.clamped[idx];
+	float dL_dRGB[3] = {a.dL_dcolor[3 * idx], a.dL_dcolor[3 * idx + 1], a.dL_dcolor[3 * idx + 2]};
+	dL_dRGB[0] *= (cl & 1) ? 0.f : 1.f;
+	dL_dRGB[1] *= (cl & 2) ? 0.f : 1.f;
+	dL_dRGB[2] *= (cl & 4) ? 0.f : 1.f;
+	float dsh[NC * 3];
+	float dL_ddir[3];
+	sh_backward<DEG>(c, x, y, z, dL_dRGB, dsh, dL_ddir);
+	store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, NC * 3);
+	// dnormvdv(dir_orig, dL_ddir), reference auxiliary.h:107-117
+	const float sum2 = ox * ox + oy * oy + oz * oz;
+	const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+	dmean[0] += ((+sum2 - ox * ox) * dL_ddir[0] - oy * ox * dL_ddir[1] - oz * ox * dL_ddir[2]) * invsum32;
+	dmean[1] += (-ox * oy * dL_ddir[0] + (sum2 - oy * oy) * dL_ddir[1] - oz * oy * dL_ddir[2]) * invsum32;
+	dmean[2] += (-ox * oz * dL_ddir[0] - oy * oz * dL_ddir[1] + (sum2 - oz * oz) * dL_ddir[2]) * invsum32;
+}
+
+__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= a.P) return;
+	const ushort4 rc = a.geom.rect[idx];
+	const bool visible = a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y);
+
+	float dmean[3] = {0.f, 0.f, 0.f};
+	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float dscale[3] = {0.f, 0.f, 0.f};
+	float drot[4] = {0.f, 0.f, 0.f, 0.f};
+
+	if (visible) {
+		const float* vm = a.viewmatrix;
+		const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+
+		// ------------------------------------------------ computeCov2DCUDA, backward.cu:144-274
+		float V[6];
+		const float* cov_src = a.cov3D_precomp ? a.cov3D_precomp + (size_t)idx * 6 : a.geom.cov3D + (size_t)idx * 6;
+#pragma unroll
+		for (int k = 0; k < 6; k++) V[k] = cov_src[k];
+		const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcw = a.dL_dconic[4 * idx + 3];
+
+		// shared prologue (same expressions as the forward)
+		float tx = vm[0] * m.x + vm[4] * m.y + vm[8] * m.z + vm[12];
+		float ty = vm[1] * m.x + vm[5] * m.y + vm[9] * m.z + vm[13];
+		const float tz_ = vm[2] * m.x + vm[6] * m.y + vm[10] * m.z + vm[14];
+		const float limx = 1.3f * a.tan_fovx;
+		const float limy = 1.3f * a.tan_fovy;
+		const float txtz = tx / tz_;
+		const float tytz = ty / tz_;
+		tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+		ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+		const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+		const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+		const float h_x = a.focal_x, h_y = a.focal_y;
+		const float J00 = h_x / tz_;
+		const float J02 = -(h_x * tx) / (tz_ * tz_);
+		const float J11 = h_y / tz_;
+		const float J12 = -(h_y * ty) / (tz_ * tz_);
+		const float T00 = vm[0] * J00 + vm[2] * J02, T01 = vm[4] * J00 + vm[6] * J02, T02 = vm[8] * J00 + vm[10] * J02;
+		const float T10 = vm[1] * J11 + vm[2] * J12, T11 = vm[5] * J11 + vm[6] * J12, T12 = vm[9] * J11 + vm[10] * J12;
+		// Vrk (symmetric): V00=V[0] V01=V[1] V02=V[2] V11=V[3] V12=V[4] V22=V[5]
+		const float V00 = V[0], V01 = V[1], V02 = V[2], V11 = V[3], V12 = V[4], V22 = V[5];
+		const float A00 = T00 * V00 + T01 * V01 + T02 * V02;
+		const float A10 = T00 * V01 + T01 * V11 + T02 * V12;
+		const float A20 = T00 * V02 + T01 * V12 + T02 * V22;
+		const float A01 = T10 * V00 + T11 * V01 + T12 * V02;
+		const float A11 = T10 * V01 + T11 * V11 + T12 * V12;
+		const float A21 = T10 * V02 + T11 * V12 + T12 * V22;
+		float ca = A00 * T00 + A10 * T01 + A20 * T02;
+		const float cb = A01 * T00 + A11 * T01 + A21 * T02;
+		float cc = A01 * T10 + A11 * T11 + A21 * T12;
+		ca += 0.3f;
+		cc += 0.3f;
+		const float a_ = ca, b_ = cb, c_ = cc;
+		const float denom = a_ * c_ - b_ * b_;
+		float dL_da = 0, dL_db = 0, dL_dc = 0;
+		const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+		if (denom2inv != 0) {
+			dL_da = denom2inv * (-c_ * c_ * dcx + 2 * b_ * c_ * dcy + (denom - a_ * c_) * dcw);
+			dL_dc = denom2inv * (-a_ * a_ * dcw + 2 * a_ * b_ * dcy + (denom - a_ * c_) * dcx);
+			dL_db = denom2inv * 2 * (b_ * c_ * dcx - (denom + 2 * b_ * b_) * dcy + a_ * b_ * dcw);
+			dcov[0] = (T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc);
+			dcov[3] = (T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc);
+			dcov[5] = (T02 * T02 * dL_da + T02 * T12 * dL_db + T12 * T12 * dL_dc);
+			dcov[1] = 2 * T00 * T01 * dL_da + (T00 * T11 + T01 * T10) * dL_db + 2 * T10 * T11 * dL_dc;
+			dcov[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
+			dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
+		}
+		const float dL_dT00 = 2 * (T00 * V00 + T01 * V01 + T02 * V02) * dL_da + (T10 * V00 + T11 * V01 + T12 * V02) * dL_db;
+		const float dL_dT01 = 2 * (T00 * V01 + T01 * V11 + T02 * V12) * dL_da + (T10 * V01 + T11 * V11 + T12 * V12) * dL_db;
+		const float dL_dT02 = 2 * (T00 * V02 + T01 * V12 + T02 * V22) * dL_da + (T10 * V02 + T11 * V12 + T12 * V22) * dL_db;
+		const float dL_dT10 = 2 * (T10 * V00 + T11 * V01 + T12 * V02) * dL_dc + (T00 * V00 + T01 * V01 + T02 * V02) * dL_db;
+		const float dL_dT11 = 2 * (T10 * V01 + T11 * V11 + T12 * V12) * dL_dc + (T00 * V01 + T01 * V11 + T02 * V12) * dL_db;
+		const float dL_dT12 = 2 * (T10 * V02 + T11 * V12 + T12 * V22) * dL_dc + (T00 * V02 + T01 * V12 + T02 * V22) * dL_db;
+		// W[0][k] = vm[4k], W[1][k] = vm[1+4k], W[2][k] = vm[2+4k]
+		const float dL_dJ00 = vm[0] * dL_dT00 + vm[4] * dL_dT01 + vm[8] * dL_dT02;
+		const float dL_dJ02 = vm[2] * dL_dT00 + vm[6] * dL_dT01 + vm[10] * dL_dT02;
+		const float dL_dJ11 = vm[1] * dL_dT10 + vm[5] * dL_dT11 + vm[9] * dL_dT12;
+		const float dL_dJ12 = vm[2] * dL_dT10 + vm[6] * dL_dT11 + vm[10] * dL_dT12;
+		const float tz = 1.f / tz_;
+		const float tz2 = tz * tz;
+		const float tz3 = tz2 * tz;
+		const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+		const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+		const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 + (2 * h_y * ty) * tz3 * dL_dJ12;
+		dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+		dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+		dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+
+		// ------------------------------------------------ preprocessCUDA (backward), backward.cu:346-396
+		const float* proj = a.projmatrix;
+		const float m_homw = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
+		const float m_w = 1.0f / (m_homw + 0.0000001f);
+		const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+		const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+		const float g2x = a.dL_dmean2D[3 * idx], g2y = a.dL_dmean2D[3 * idx + 1];
+		const float pdx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+		const float pdy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+		const float pdz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+		dmean[0] += pdx;
+		dmean[1] += pdy;
+		dmean[2] += pdz;
+
+		if (a.shs) {
+			if (a.D <= 0) sh_bwd_deg<0>(a, idx, m, dmean);
+			else if (a.D == 1) sh_bwd_deg<1>(a, idx, m, dmean);
+			else if (a.D == 2) sh_bwd_deg<2>(a, idx, m, dmean);
+			else sh_bwd_deg<3>(a, idx, m, dmean);
+		}
+
+		if (a.scales) {
+			// computeCov3D (backward), backward.cu:278-341
+			const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+			const float r = q.x, x = q.y, y = q.z, z = q.w;
+			const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+			                    a.scale_modifier * a.scales[3 * idx + 2]};
+			// Rm[c][k] = R[c][k] (glm column c, row k)
+			const float Rm[3][3] = {
+			    {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+			    {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+			    {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+			float M2[3][3];   // 2 * M, M[c][k] = s_k * R[c][k]
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+#pragma unroll
+				for (int k = 0; k < 3; k++) M2[c][k] = 2.0f * (s[k] * Rm[c][k]);
+			const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+			                        {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+			                        {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+			float dM[3][3];   // dL_dM[c][rr] = sum_k M2[k][rr] * dS[c][k]
+#pragma unroll
+			for (int c = 0; c < 3; c++)
+#pragma unroll
+				for (int rr = 0; rr < 3; rr++) dM[c][rr] = M2[0][rr] * dS[c][0] + M2[1][rr] * dS[c][1] + M2[2][rr] * dS[c][2];
+			// dL_dscale_i = dot(Rt[i], dL_dMt[i]) = sum_j R[j][i] * dM[j][i]
+#pragma unroll
+			for (int i = 0; i < 3; i++) dscale[i] = (Rm[0][i] * dM[0][i] + Rm[1][i] * dM[1][i]) + Rm[2][i] * dM[2][i];
+			float G[3][3];    // dL_dMt[i][j] * s_i = dM[j][i] * s_i
+#pragma unroll
+			for (int i = 0; i < 3; i++)
+#pragma unroll
+				for (int j = 0; j < 3; j++) G[i][j] = dM[j][i] * s[i];
+			drot[0] = 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
+			drot[1] = 2 * y * (G[1][0] + G[0][1]) + 2 * z * (G[2][0] + G[0][2]) + 2 * r * (G[1][2] - G[2][1]) - 4 * x * (G[2][2] + G[1][1]);
+			drot[2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
+			drot[3] = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
+		}
+	} else if (a.shs && a.dL_dsh) {
+		const float zero = 0.f;
+		store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, &zero, 0);
+	}
+
+	a.dL_dmean3D[3 * idx] = dmean[0];
+	a.dL_dmean3D[3 * idx + 1] = dmean[1];
+	a.dL_dmean3D[3 * idx + 2] = dmean[2];
+#pragma unroll
+	for (int k = 0; k < 6; k++) a.dL_dcov3D[(size_t)idx * 6 + k] = dcov[k];
+	if (a.scales) {
+		a.dL_dscale[3 * idx] = dscale[0];
+		a.dL_dscale[3 * idx + 1] = dscale[1];
+		a.dL_dscale[3 * idx + 2] = dscale[2];
+		reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+	}
+}
+
+void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace bsr

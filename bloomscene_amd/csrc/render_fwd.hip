@@ -1,0 +1,116 @@
+// Forward tile renderer: front-to-back alpha blending of colour + depth per 16x16 tile.
+//
+// Semantics: reference renderCUDA, cuda_rasterizer/forward.cu:341-471 (under
+// /root/reference/submodules/depth-diff-gaussian-rasterization).  Per pixel the arithmetic and
+// every decision (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4, depth normalisation) are
+// evaluated in the reference's order, so results match the CPU oracle bit for bit.
+//
+// MI355X mapping: one tile = one 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel
+// quadrant (compact footprint -> whole-wave skips of splats that miss the quadrant).  List
+// entries are staged 256 at a time: each thread gathers one 48-byte splat record (3 x 16-B loads
+// from the L2/Infinity-Cache resident record table) into LDS; waves then walk the batch with
+// broadcast LDS reads.  The reject path needs only 24 B per entry (position, conic, power cut)
+// and no exp: `power < power_cut` (precomputed -ln(255*opacity) minus a safety margin) proves
+// alpha < 1/255 without evaluating it.
+#include "common.h"
+
+namespace bsr {
+
+__global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int W, int H,
+                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const float4* __restrict__ rec,
+                                                          const float* __restrict__ bg_color,
+                                                          float* __restrict__ final_T,
+                                                          uint32_t* __restrict__ n_contrib,
+                                                          float* __restrict__ out_color,
+                                                          float* __restrict__ out_depth)
+{
+	__shared__ float4 s_q0[BSR_BLOCK];
+	__shared__ float4 s_q1[BSR_BLOCK];
+	__shared__ float4 s_q2[BSR_BLOCK];
+
+	const int tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int tx = tile % gx, ty = tile / gx;
+	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
+	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+
+	const uint32_t start = tile_start[tile];
+	const uint32_t end = tile_start[tile + 1];
+	const int n = (int)(end - start);
+
+	bool done = !inside;
+	float T = 1.0f;
+	uint32_t last_contributor = 0;
+	float C0 = 0.f, C1 = 0.f, C2 = 0.f;
+	float D = 0.f;
+	float acc = 0.000001f;
+
+	for (int base = 0; base < n; base += BSR_BLOCK) {
+		// whole tile finished?  (also the WAR barrier for the staging buffers)
+		if (__syncthreads_and(done)) break;
+		const int cnt = min(BSR_BLOCK, n - base);
+		if (tid < cnt) {
+			const uint32_t id = point_list[start + base + tid];
+			const float4* r = rec + (size_t)id * 3;
+			s_q0[tid] = r[0];
+			s_q1[tid] = r[1];
+			s_q2[tid] = r[2];
+		}
+		__syncthreads();
+
+		for (int j = 0; !done && j < cnt; j++) {
+			const float4 q0 = s_q0[j];                                              // x, y, conic a, conic b
+			const float2 ct = *reinterpret_cast<const float2*>(&s_q1[j]);            // conic c, power cut
+			const float dx = q0.x - pixfx;
+			const float dy = q0.y - pixfy;
+			const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
+			if (power > 0.0f) continue;
+			if (power < ct.y) continue;   // alpha < 1/255 for certain
+			const float2 od = *(reinterpret_cast<const float2*>(&s_q1[j]) + 1);      // opacity, depth
+			const float alpha = fminf(0.99f, od.x * bsr_expf(power));
+			if (alpha < 1.0f / 255.0f) continue;
+			const float test_T = T * (1 - alpha);
+			if (test_T < 0.0001f) {
+				done = true;
+				continue;
+			}
+			const float4 q2 = s_q2[j];
+			C0 += q2.x * alpha * T;
+			C1 += q2.y * alpha * T;
+			C2 += q2.z * alpha * T;
+			D += od.y * alpha * T;
+			acc += alpha * T;
+			T = test_T;
+			last_contributor = (uint32_t)(base + j + 1);
+		}
+	}
+
+	if (inside) {
+		const size_t pix_id = (size_t)W * py + px;
+		const size_t plane = (size_t)H * W;
+		final_T[pix_id] = T;
+		n_contrib[pix_id] = last_contributor;
+		out_color[pix_id] = C0 + T * bg_color[0];
+		out_color[plane + pix_id] = C1 + T * bg_color[1];
+		out_color[2 * plane + pix_id] = C2 + T * bg_color[2];
+		out_depth[pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
+	}
+}
+
+void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+                       const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
+                       float* out_depth, hipStream_t s)
+{
+	const int n_tiles = gx * gy;
+	const int blocks = ((n_tiles + 7) / 8) * 8;
+	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
+	                   bg, final_T, n_contrib, out_color, out_depth);
+}
+
+}  // namespace bsr

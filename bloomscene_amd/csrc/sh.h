@@ -1,0 +1,172 @@
+// Spherical-harmonics colour evaluation and its backward, per Gaussian.
+// Semantics: reference cuda_rasterizer/forward.cu:20-71 and backward.cu:20-139, constants
+// auxiliary.h:22-39.  The [P][M][3] coefficient block of one Gaussian is contiguous (12*M bytes);
+// it is pulled in with 16-byte loads when 12*M is a multiple of 16 (M = 4, 16).
+#pragma once
+#include "common.h"
+
+namespace bsr {
+
+__device__ static const float SH_C0 = 0.28209479177387814f;
+__device__ static const float SH_C1 = 0.4886025119029199f;
+__device__ static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// Load the first n_coef coefficients (n_coef*3 floats) of one Gaussian into registers.
+template <int NC>
+__device__ __forceinline__ void load_sh(const float* __restrict__ sh, int M, float* c)
+{
+	if ((M & 3) == 0) {   // 12*M bytes per Gaussian is a multiple of 16 -> block is 16-B aligned
+		const float4* s4 = reinterpret_cast<const float4*>(sh);
+		constexpr int NV = (NC * 3 + 3) / 4;
+#pragma unroll
+		for (int i = 0; i < NV; i++) {
+			if (i * 4 < M * 3) {
+				const float4 v = s4[i];
+				if (i * 4 + 0 < NC * 3) c[i * 4 + 0] = v.x;
+				if (i * 4 + 1 < NC * 3) c[i * 4 + 1] = v.y;
+				if (i * 4 + 2 < NC * 3) c[i * 4 + 2] = v.z;
+				if (i * 4 + 3 < NC * 3) c[i * 4 + 3] = v.w;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < NC * 3; i++) c[i] = sh[i];
+	}
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_eval(const float* c, float x, float y, float z, float* res)
+{
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+#define SH(k) c[(k) * 3 + ch]
+		float r = SH_C0 * SH(0);
+		if (DEG > 0) {
+			r = r - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+			if (DEG > 1) {
+				const float xx = x * x, yy = y * y, zz = z * z;
+				const float xy = x * y, yz = y * z, xz = x * z;
+				r = r + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.0f * zz - xx - yy) * SH(6) +
+				    SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+				if (DEG > 2) {
+					r = r + SH_C3[0] * y * (3.0f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+					    SH_C3[2] * y * (4.0f * zz - xx - yy) * SH(11) +
+					    SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SH(12) +
+					    SH_C3[4] * x * (4.0f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+					    SH_C3[6] * x * (xx - 3.0f * yy) * SH(15);
+				}
+			}
+		}
+#undef SH
+		res[ch] = r + 0.5f;
+	}
+}
+
+// forward: rgb = max(0, 0.5 + sum basis*coef); clamp_bits bit ch set where the raw value was < 0
+__device__ __forceinline__ void sh_to_rgb(int deg, int M, const float3 pos, const float* __restrict__ campos,
+                                          const float* __restrict__ sh, float* rgb, uint8_t& clamp_bits)
+{
+	float dx = pos.x - campos[0], dy = pos.y - campos[1], dz = pos.z - campos[2];
+	const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+	dx = dx / len; dy = dy / len; dz = dz / len;
+	float raw[3];
+	if (deg <= 0) {
+		float c[3];
+		load_sh<1>(sh, M, c);
+		sh_eval<0>(c, dx, dy, dz, raw);
+	} else if (deg == 1) {
+		float c[12];
+		load_sh<4>(sh, M, c);
+		sh_eval<1>(c, dx, dy, dz, raw);
+	} else if (deg == 2) {
+		float c[27];
+		load_sh<9>(sh, M, c);
+		sh_eval<2>(c, dx, dy, dz, raw);
+	} else {
+		float c[48];
+		load_sh<16>(sh, M, c);
+		sh_eval<3>(c, dx, dy, dz, raw);
+	}
+	clamp_bits = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+		if (raw[ch] < 0) clamp_bits |= (uint8_t)(1u << ch);
+		rgb[ch] = fmaxf(raw[ch], 0.0f);
+	}
+}
+
+// backward (reference backward.cu:20-139): writes dL_dsh[0..(DEG+1)^2) (remaining coefficients,
+// if M is larger, are zeroed by the caller) and returns dL_ddir = (dRGBdx.dL, dRGBdy.dL, dRGBdz.dL).
+template <int DEG>
+__device__ __forceinline__ void sh_backward(const float* c, float x, float y, float z, const float* dL_dRGB,
+                                            float* dsh /* [(DEG+1)^2*3] */, float* dL_ddir)
+{
+	float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+#define SH(k) c[(k) * 3 + ch]
+#define DSH(k, v)                                                    \
+	do {                                                             \
+		const float _v = (v);                                        \
+		_Pragma("unroll") for (int ch = 0; ch < 3; ch++) dsh[(k) * 3 + ch] = _v * dL_dRGB[ch]; \
+	} while (0)
+	DSH(0, SH_C0);
+	if (DEG > 0) {
+		DSH(1, -SH_C1 * y);
+		DSH(2, SH_C1 * z);
+		DSH(3, -SH_C1 * x);
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) {
+			dRGBdx[ch] = -SH_C1 * SH(3);
+			dRGBdy[ch] = -SH_C1 * SH(1);
+			dRGBdz[ch] = SH_C1 * SH(2);
+		}
+		if (DEG > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			DSH(4, SH_C2[0] * xy);
+			DSH(5, SH_C2[1] * yz);
+			DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+			DSH(7, SH_C2[3] * xz);
+			DSH(8, SH_C2[4] * (xx - yy));
+#pragma unroll
+			for (int ch = 0; ch < 3; ch++) {
+				dRGBdx[ch] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+				dRGBdy[ch] += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+				dRGBdz[ch] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+			}
+			if (DEG > 2) {
+				DSH(9, SH_C3[0] * y * (3.f * xx - yy));
+				DSH(10, SH_C3[1] * xy * z);
+				DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+				DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+				DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+				DSH(14, SH_C3[5] * z * (xx - yy));
+				DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+#pragma unroll
+				for (int ch = 0; ch < 3; ch++) {
+					dRGBdx[ch] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz +
+					               SH_C3[2] * SH(11) * -2.f * xy + SH_C3[3] * SH(12) * -3.f * 2.f * xz +
+					               SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * SH(14) * 2.f * xz +
+					               SH_C3[6] * SH(15) * 3.f * (xx - yy));
+					dRGBdy[ch] += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+					               SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+					               SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+					               SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+					dRGBdz[ch] += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+					               SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+					               SH_C3[5] * SH(14) * (xx - yy));
+				}
+			}
+		}
+	}
+#undef SH
+#undef DSH
+	dL_ddir[0] = (dRGBdx[0] * dL_dRGB[0] + dRGBdx[1] * dL_dRGB[1]) + dRGBdx[2] * dL_dRGB[2];
+	dL_ddir[1] = (dRGBdy[0] * dL_dRGB[0] + dRGBdy[1] * dL_dRGB[1]) + dRGBdy[2] * dL_dRGB[2];
+	dL_ddir[2] = (dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1]) + dRGBdz[2] * dL_dRGB[2];
+}
+
+}  // namespace bsr

@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's ``depth_diff_gaussian_rasterization`` python module.
+
+Same names, argument meaning, return order and error behaviour as
+``/root/reference/submodules/depth-diff-gaussian-rasterization/depth_diff_gaussian_rasterization/__init__.py``
+(cited below as PYW) plus the torch glue of ``rasterize_points.cu`` (RP), but every native call
+goes through the C ABI of ``include/bloomscene_rast.h`` into hand-written gfx950 kernels.
+
+There is no CPU path here: tensors must live on the GPU and the HIP library must be present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+def cpu_deep_copy_tuple(input_tuple):  # PYW:17-19
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class GaussianRasterizationSettings(NamedTuple):  # PYW:158-170 (same 12 fields, same order)
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# ------------------------------------------------------------------ pointer plumbing
+def _dev_f32(t: torch.Tensor, name: str, device: torch.device):
+    """contiguous fp32 tensor on `device`, or None for an absent (empty) optional input.
+    RP:95-113 calls .contiguous().data_ptr<float>() on everything; an empty CPU tensor is the
+    reference's encoding of nullptr (PYW:198-208)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"{name} must be on {device} (got {t.device}); bloomscene_amd has no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream_handle(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _Scratch:
+    """One growable byte tensor + the C callback that resizes it: the counterpart of
+    resizeFunctional (RP:27-33)."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+
+        def _resize(_user, nbytes):
+            self.tensor.resize_(int(nbytes))
+            return self.tensor.data_ptr()
+
+        self.callback = _capi.ALLOC_FN(_resize)
+
+
+def _check_means3D(means3D):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # RP:57-59
+
+
+# ------------------------------------------------------------------ native entry points
+def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                                campos, prefiltered, debug):
+    """Counterpart of `_C.rasterize_gaussians` = RasterizeGaussiansCUDA (RP:35-117)."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0  # RP:84-88
+    t = dict(bg=_dev_f32(bg, "bg", dev), means3D=_dev_f32(means3D, "means3D", dev),
+             colors=_dev_f32(colors, "colors_precomp", dev), opacity=_dev_f32(opacity, "opacities", dev),
+             scales=_dev_f32(scales, "scales", dev), rotations=_dev_f32(rotations, "rotations", dev),
+             cov3D=_dev_f32(cov3D_precomp, "cov3D_precomp", dev), view=_dev_f32(viewmatrix, "viewmatrix", dev),
+             proj=_dev_f32(projmatrix, "projmatrix", dev), sh=_dev_f32(sh, "shs", dev),
+             campos=_dev_f32(campos, "campos", dev))
+    num_rendered = C.c_int(0)
+    with torch.cuda.device(dev):
+        rc = _capi.lib().bsr_forward(
+            geom.callback, None, binning.callback, None, img.callback, None,
+            P, int(degree), int(M), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]), _ptr(t["colors"]),
+            _ptr(t["opacity"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
+            _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]), float(tan_fovx), float(tan_fovy),
+            int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr() if P else None,
+            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered))
+    _capi.check(rc, "rasterize_gaussians")
+    return num_rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rotations, scale_modifier,
+                                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                         dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                         imageBuffer, debug):
+    """Counterpart of `_C.rasterize_gaussians_backward` = RasterizeGaussiansBackwardCUDA (RP:119-200)."""
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+    o = dict(device=dev, dtype=torch.float32)
+    # every output is fully written by bsr_backward (rows of culled Gaussians = 0): no zero-fill pass
+    dL_dmeans3D = torch.empty((P, 3), **o)
+    dL_dmeans2D = torch.empty((P, 3), **o)
+    dL_dcolors = torch.empty((P, 3), **o)
+    dL_dconic = torch.empty((P, 2, 2), **o)
+    dL_dopacity = torch.empty((P, 1), **o)
+    dL_dcov3D = torch.empty((P, 6), **o)
+    dL_dsh = torch.empty((P, M, 3), **o)
+    has_sr = scales is not None and scales.numel() != 0
+    dL_dscales = torch.empty((P, 3), **o) if has_sr else torch.zeros((P, 3), **o)
+    dL_drotations = torch.empty((P, 4), **o) if has_sr else torch.zeros((P, 4), **o)
+    if P != 0:
+        t = dict(bg=_dev_f32(bg, "bg", dev), means3D=_dev_f32(means3D, "means3D", dev),
+                 colors=_dev_f32(colors, "colors_precomp", dev), scales=_dev_f32(scales, "scales", dev),
+                 rotations=_dev_f32(rotations, "rotations", dev), cov3D=_dev_f32(cov3D_precomp, "cov3D_precomp", dev),
+                 view=_dev_f32(viewmatrix, "viewmatrix", dev), proj=_dev_f32(projmatrix, "projmatrix", dev),
+                 sh=_dev_f32(sh, "shs", dev), campos=_dev_f32(campos, "campos", dev),
+                 gcol=_dev_f32(dL_dout_color, "dL_dout_color", dev), gdep=_dev_f32(dL_dout_depth, "dL_dout_depth", dev))
+        radii_c = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = _capi.lib().bsr_backward(
+                P, int(degree), int(M), int(R), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]),
+                _ptr(t["colors"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
+                _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]), float(tan_fovx), float(tan_fovy),
+                radii_c.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr() if binningBuffer.numel() else None,
+                imageBuffer.data_ptr(), _ptr(t["gcol"]), _ptr(t["gdep"]), dL_dmeans2D.data_ptr(),
+                dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
+                dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
+                dL_drotations.data_ptr(), int(bool(debug)), _stream_handle(dev))
+        _capi.check(rc, "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def _mark_visible_native(means3D, viewmatrix, projmatrix):
+    """Counterpart of `_C.mark_visible` = markVisible (RP:202-221)."""
+    dev = means3D.device
+    if not means3D.is_cuda:
+        raise RuntimeError("positions must be a GPU tensor; bloomscene_amd has no CPU path")
+    P = means3D.size(0)
+    present = torch.full((P,), False, dtype=torch.bool, device=dev)
+    if P != 0:
+        m, v, p = _dev_f32(means3D, "means3D", dev), _dev_f32(viewmatrix, "viewmatrix", dev), _dev_f32(projmatrix, "projmatrix", dev)
+        with torch.cuda.device(dev):
+            rc = _capi.lib().bsr_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr(),
+                                              _stream_handle(dev))
+        _capi.check(rc, "mark_visible")
+    return present
+
+
+def _rasterize_gaussians_filter_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                       projmatrix, tan_fovx, tan_fovy, image_height, image_width, prefiltered, debug):
+    """Counterpart of `_C.rasterize_aussians_filter` [sic] = RasterizeGaussiansfilterCUDA (RP:224-288)."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P = means3D.size(0)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    if P != 0:
+        m = _dev_f32(means3D, "means3D", dev)
+        s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)
+        c = _dev_f32(cov3D_precomp, "cov3D_precomp", dev)
+        v, p = _dev_f32(viewmatrix, "viewmatrix", dev), _dev_f32(projmatrix, "projmatrix", dev)
+        with torch.cuda.device(dev):
+            rc = _capi.lib().bsr_visible_filter(
+                P, 0, int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier), _ptr(r),
+                _ptr(c), v.data_ptr(), p.data_ptr(), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                radii.data_ptr(), int(bool(debug)), _stream_handle(dev))
+        _capi.check(rc, "rasterize_gaussians_filter")
+    return radii
+
+
+# ------------------------------------------------------------------ autograd (PYW:21-156)
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        # same argument order as the reference hands to its C++ lib (PYW:60-80)
+        args = (
+            raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
+            raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix, raster_settings.projmatrix,
+            raster_settings.tanfovx, raster_settings.tanfovy, raster_settings.image_height,
+            raster_settings.image_width, sh, raster_settings.sh_degree, raster_settings.campos,
+            raster_settings.prefiltered, raster_settings.debug,
+        )
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted (PYW:84)
+            try:
+                num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
+                    _rasterize_gaussians_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
+                _rasterize_gaussians_native(*args)
+
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
+            ctx.saved_tensors
+        if grad_out_color is None:  # only the depth output was used downstream; it carries no gradient
+            grad_out_color = torch.zeros((3, raster_settings.image_height, raster_settings.image_width),
+                                         dtype=torch.float32, device=means3D.device)
+        if grad_depth is None:
+            grad_depth = torch.zeros((1, raster_settings.image_height, raster_settings.image_width),
+                                     dtype=torch.float32, device=means3D.device)
+        args = (raster_settings.bg, means3D, radii, colors_precomp, scales, rotations,
+                raster_settings.scale_modifier, cov3Ds_precomp, raster_settings.viewmatrix,
+                raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
+                grad_depth, sh, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
+                binningBuffer, imgBuffer, raster_settings.debug)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
+                    grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
+                grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args)
+
+        # Absent optional inputs were empty tensors: their gradient must have the input's (empty)
+        # shape for autograd's shape check; the reference relies on older, laxer torch here.
+        def _fit(g, inp):
+            return g if inp.numel() != 0 else None
+
+        grads = (
+            grad_means3D,
+            grad_means2D,
+            _fit(grad_sh, sh),
+            _fit(grad_colors_precomp, colors_precomp),
+            grad_opacities,
+            _fit(grad_scales, scales),
+            _fit(grad_rotations, rotations),
+            _fit(grad_cov3Ds_precomp, cov3Ds_precomp),
+            None,
+        )
+        return grads
+
+
+class GaussianRasterizer(nn.Module):  # PYW:172-249
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _mark_visible_native(positions, raster_settings.viewmatrix, raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, raster_settings)
+
+    def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        with torch.no_grad():
+            radii = _rasterize_gaussians_filter_native(
+                means3D, scales, rotations, raster_settings.scale_modifier, cov3D_precomp,
+                raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.tanfovx,
+                raster_settings.tanfovy, raster_settings.image_height, raster_settings.image_width,
+                raster_settings.prefiltered, raster_settings.debug)
+        return radii

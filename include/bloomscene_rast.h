@@ -1,0 +1,171 @@
+/*
+ * bloomscene_rast.h -- C ABI of the MI355X-native (gfx950) differentiable Gaussian-splatting
+ * rasterizer that drops in behind BloomScene's `depth_diff_gaussian_rasterization` module.
+ *
+ * Boundary: plain pointers, ints, floats and a hipStream_t passed as void*.  No torch types.
+ * All pointers are DEVICE pointers unless stated otherwise; a NULL pointer means "optional input
+ * absent" exactly like the empty CPU tensors -> nullptr convention of the reference
+ * (depth_diff_gaussian_rasterization/__init__.py:198-208, rasterize_points.cu:95-113).
+ * Every function returns 0 on success, non-zero on failure; bsr_last_error() then describes it.
+ * The library keeps no state between calls (apart from the opt-in stage profiler); the three
+ * scratch buffers handed from forward to backward are opaque, as in the reference
+ * (__init__.py:97,106).
+ *
+ * Reference paths below are relative to
+ *   /root/reference/submodules/depth-diff-gaussian-rasterization/
+ */
+#ifndef BLOOMSCENE_RAST_H_INCLUDED
+#define BLOOMSCENE_RAST_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSR_VERSION 1
+
+/* Resize callback for an opaque scratch buffer: must return a device pointer to at least
+ * `bytes` bytes (256-byte aligned) that stays valid until the matching backward call.
+ * Replaces std::function<char*(size_t)> geometryBuffer/binningBuffer/imageBuffer of
+ * cuda_rasterizer/rasterizer.h:32-34 (built by resizeFunctional, rasterize_points.cu:27-33). */
+typedef char* (*bsr_alloc_fn)(void* user, size_t bytes);
+
+/* Library version (BSR_VERSION of the build). */
+int bsr_version(void);
+
+/* Message of the last failure on the calling thread ("" if none).  Replaces the exceptions
+ * thrown by CHECK_CUDA (cuda_rasterizer/auxiliary.h:166-173) and AT_ERROR
+ * (rasterize_points.cu:57-59). */
+const char* bsr_last_error(void);
+
+/* present[i] = (view-space z of means3D[i] > 0.2).  present is uint8[P] (torch.bool storage).
+ * Replaces CudaRasterizer::Rasterizer::markVisible, cuda_rasterizer/rasterizer.h:24-29
+ * (= rasterizer_impl.cu:141-153, kernel checkFrustum :54-66); bound by `_C.mark_visible`,
+ * ext.cpp:19 / rasterize_points.cu:202-221. */
+int bsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Forward rasterization.  Writes out_color[3,H,W], out_depth[1,H,W], radii[P] (all fully
+ * overwritten; radii may be NULL) and *num_rendered (HOST int: number of (Gaussian, tile)
+ * instances).  Exactly one of shs / colors_precomp and exactly one of (scales, rotations) /
+ * cov3D_precomp must be non-NULL.  background, viewmatrix, projmatrix, cam_pos are DEVICE
+ * float[3]/[16]/[16]/[3].  debug != 0: synchronise and check after every stage.  prefiltered != 0:
+ * a culled Gaussian is an error (the reference printf+__trap()s, auxiliary.h:156-160).
+ * Performs one blocking 4-byte device->host read, like rasterizer_impl.cu:282.
+ * Replaces CudaRasterizer::Rasterizer::forward, cuda_rasterizer/rasterizer.h:31-54
+ * (= rasterizer_impl.cu:198-339); bound by `_C.rasterize_gaussians`, ext.cpp:16 /
+ * rasterize_points.cu:35-117. */
+int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user,
+                bsr_alloc_fn binningBuffer, void* binning_user,
+                bsr_alloc_fn imageBuffer, void* image_user,
+                int P, int D, int M,
+                const float* background,
+                int width, int height,
+                const float* means3D,
+                const float* shs,
+                const float* colors_precomp,
+                const float* opacities,
+                const float* scales,
+                float scale_modifier,
+                const float* rotations,
+                const float* cov3D_precomp,
+                const float* viewmatrix,
+                const float* projmatrix,
+                const float* cam_pos,
+                float tan_fovx, float tan_fovy,
+                int prefiltered,
+                float* out_color,
+                float* out_depth,
+                int* radii,
+                int debug,
+                void* stream,
+                int* num_rendered);
+
+/* radii[P] of the Gaussians as the forward pass would compute them (0 = culled); nothing else.
+ * Needs no scratch (the reference allocates and discards full state, rasterizer_impl.cu:361-375).
+ * Replaces CudaRasterizer::Rasterizer::visible_filter, cuda_rasterizer/rasterizer.h:57-73
+ * (= rasterizer_impl.cu:342-398); bound by `_C.rasterize_aussians_filter` [sic], ext.cpp:18 /
+ * rasterize_points.cu:224-288. */
+int bsr_visible_filter(int P, int M,
+                       int width, int height,
+                       const float* means3D,
+                       const float* scales,
+                       float scale_modifier,
+                       const float* rotations,
+                       const float* cov3D_precomp,
+                       const float* viewmatrix,
+                       const float* projmatrix,
+                       float tan_fovx, float tan_fovy,
+                       int prefiltered,
+                       int* radii,
+                       int debug,
+                       void* stream);
+
+/* Backward pass for the forward call that produced (radii, geom/binning/image buffers, R).
+ * dL_dpix is [3,H,W]; dL_depths [1,H,W] is accepted and ignored exactly like the reference
+ * (backward.cu:457-463,539-554).  All nine gradient outputs are FULLY OVERWRITTEN (no pre-zeroing
+ * needed): dL_dmean2D[P,3], dL_dconic[P,2,2] (internal, but part of the reference signature),
+ * dL_dopacity[P,1], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
+ * dL_dscale[P,3], dL_drot[P,4]; rows of culled Gaussians are zero.  dL_dsh may be NULL when
+ * M == 0; dL_dscale/dL_drot are written only when scales != NULL.
+ * Replaces CudaRasterizer::Rasterizer::backward, cuda_rasterizer/rasterizer.h:75-105
+ * (= rasterizer_impl.cu:403-504); bound by `_C.rasterize_gaussians_backward`, ext.cpp:17 /
+ * rasterize_points.cu:119-200. */
+int bsr_backward(int P, int D, int M, int R,
+                 const float* background,
+                 int width, int height,
+                 const float* means3D,
+                 const float* shs,
+                 const float* colors_precomp,
+                 const float* scales,
+                 float scale_modifier,
+                 const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix,
+                 const float* projmatrix,
+                 const float* campos,
+                 float tan_fovx, float tan_fovy,
+                 const int* radii,
+                 char* geom_buffer,
+                 char* binning_buffer,
+                 char* image_buffer,
+                 const float* dL_dpix,
+                 const float* dL_depths,
+                 float* dL_dmean2D,
+                 float* dL_dconic,
+                 float* dL_dopacity,
+                 float* dL_dcolor,
+                 float* dL_dmean3D,
+                 float* dL_dcov3D,
+                 float* dL_dsh,
+                 float* dL_dscale,
+                 float* dL_drot,
+                 int debug,
+                 void* stream);
+
+/* Scratch sizes, for callers that pre-allocate instead of growing inside the callback
+ * (the reference's required<T>(n), cuda_rasterizer/rasterizer_impl.h:68-73). */
+size_t bsr_geometry_bytes(int P);
+size_t bsr_binning_bytes(int num_rendered);
+size_t bsr_image_bytes(int width, int height);
+
+/* ---- measurement hooks (no reference counterpart; used by bench.py only) ------------------
+ * bsr_profile_enable(1) makes every kernel stage of subsequent calls be bracketed by hipEvents
+ * on the call's stream; bsr_profile_read() synchronises those events and returns, per stage
+ * name, the accumulated milliseconds and launch count since the last bsr_profile_reset(). */
+#define BSR_PROFILE_MAX_STAGES 16
+typedef struct bsr_stage_profile {
+	const char* name;
+	double total_ms;
+	int launches;
+} bsr_stage_profile;
+int bsr_profile_enable(int on);
+int bsr_profile_reset(void);
+int bsr_profile_read(bsr_stage_profile* out, int max_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,183 @@
+"""Shared helpers for the test-suite: case construction, oracle runs, comparison metrics."""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from bloomscene_amd.synthetic import scene_a, scene_b, upstream_grads  # noqa: E402
+
+
+def cov3d_from_scale_rot(scales, rotations, mod=1.0):
+    """float64 Sigma = Rq S^2 Rq^T packed as (xx, xy, xz, yy, yz, zz) -- used only to build
+    cov3D_precomp *inputs* for tests."""
+    q = rotations.double()
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+    Mx = R * (mod * scales.double())[:, None, :]
+    S = Mx @ Mx.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).float().contiguous()
+
+
+def make_case(P, W, H, deg, seed=0, scene="a", view=0, color_mode="sh", cov_mode="scale_rot", bg=(0.1, 0.2, 0.3),
+              scale_mul=1.0, scale_modifier=1.0, near_fraction=0.0, M_extra=0):
+    """One rasterizer call's worth of CPU inputs (torch fp32) + camera."""
+    sc = scene_a(P, W, H, deg, seed=seed) if scene == "a" else scene_b(P, W, H, deg, seed=seed)
+    cam = sc.cameras[view]
+    c = SimpleNamespace(P=P, W=W, H=H, deg=deg, cam=cam)
+    c.means3D = sc.means3D.clone()
+    if near_fraction > 0 and P > 0:   # push some Gaussians behind / next to the near plane
+        g = torch.Generator().manual_seed(seed + 99)
+        k = max(1, int(P * near_fraction))
+        idx = torch.randperm(P, generator=g)[:k]
+        c.means3D[idx, 2] = torch.rand(k, generator=g) * 0.6 - 0.2
+    c.scales = (sc.scales * scale_mul).contiguous()
+    c.rotations = sc.rotations
+    c.opacities = sc.opacities
+    c.shs = sc.shs
+    if M_extra:   # more coefficients stored than the active degree uses
+        g = torch.Generator().manual_seed(seed + 7)
+        extra = torch.randn(P, M_extra, 3, generator=g) * 0.1
+        c.shs = torch.cat([sc.shs, extra], dim=1).contiguous()
+    c.colors_precomp = None
+    c.cov3D_precomp = None
+    if color_mode == "precomp":
+        g = torch.Generator().manual_seed(seed + 13)
+        c.colors_precomp = torch.rand(P, 3, generator=g)
+        c.shs = None
+    if cov_mode == "precomp":
+        c.cov3D_precomp = cov3d_from_scale_rot(c.scales, c.rotations, 1.0)
+        c.scales = None
+        c.rotations = None
+    c.bg = torch.tensor(bg, dtype=torch.float32)
+    c.tanfovx = math.tan(cam.FoVx * 0.5)
+    c.tanfovy = math.tan(cam.FoVy * 0.5)
+    c.scale_modifier = scale_modifier
+    c.gC, c.gD = upstream_grads(W, H, seed=seed + 1)
+    return c
+
+
+def oracle_settings(c, prefiltered=False):
+    return O.make_settings(c.H, c.W, c.tanfovx, c.tanfovy, c.bg, c.scale_modifier, c.cam.world_view_transform,
+                           c.cam.full_proj_transform, c.deg, c.cam.camera_center, prefiltered=prefiltered)
+
+
+def run_oracle(c, backward=True, want_abs_sums=False):
+    rs = oracle_settings(c)
+    st = O.forward(rs, c.means3D, c.opacities, shs=c.shs, colors_precomp=c.colors_precomp, scales=c.scales,
+                   rotations=c.rotations, cov3D_precomp=c.cov3D_precomp)
+    g = O.backward(st, c.gC, c.gD, want_abs_sums=want_abs_sums) if backward else None
+    return st, g
+
+
+def hip_settings(c, device, debug=False, prefiltered=False):
+    from bloomscene_amd import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=c.H, image_width=c.W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=c.bg.to(device),
+        scale_modifier=c.scale_modifier, viewmatrix=c.cam.world_view_transform.to(device),
+        projmatrix=c.cam.full_proj_transform.to(device), sh_degree=c.deg, campos=c.cam.camera_center.to(device),
+        prefiltered=prefiltered, debug=debug)
+
+
+def run_hip(c, device="cuda", backward=True, debug=False):
+    """The reference call shape (gaussian_renderer/__init__.py:224-262) against the HIP path."""
+    from bloomscene_amd import GaussianRasterizer
+    dev = torch.device(device)
+
+    def leaf(t):
+        return None if t is None else t.to(dev).clone().requires_grad_(True)
+    inp = SimpleNamespace(means3D=leaf(c.means3D), opacities=leaf(c.opacities), shs=leaf(c.shs),
+                          colors_precomp=leaf(c.colors_precomp), scales=leaf(c.scales), rotations=leaf(c.rotations),
+                          cov3D_precomp=leaf(c.cov3D_precomp))
+    means2D = torch.zeros_like(inp.means3D, requires_grad=True) + 0
+    means2D.retain_grad()
+    rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug))
+    color, radii, depth = rast(means3D=inp.means3D, means2D=means2D, opacities=inp.opacities, shs=inp.shs,
+                               colors_precomp=inp.colors_precomp, scales=inp.scales, rotations=inp.rotations,
+                               cov3D_precomp=inp.cov3D_precomp)
+    out = SimpleNamespace(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(),
+                          depth=depth.detach().cpu().numpy(), inp=inp, means2D=means2D)
+    if backward:
+        torch.autograd.backward((color, depth), (c.gC.to(dev), c.gD.to(dev)))
+        torch.cuda.synchronize()
+
+        def grad(t):
+            return None if t is None or t.grad is None else t.grad.detach().cpu().numpy()
+        out.grads = SimpleNamespace(means3D=grad(inp.means3D), means2D=grad(means2D), opacities=grad(inp.opacities),
+                                    shs=grad(inp.shs), colors_precomp=grad(inp.colors_precomp),
+                                    scales=grad(inp.scales), rotations=grad(inp.rotations),
+                                    cov3D_precomp=grad(inp.cov3D_precomp))
+    return out
+
+
+def oracle_grads(c, g):
+    """Oracle gradients keyed like run_hip().grads (mapping of PYW:144-154)."""
+    return SimpleNamespace(
+        means3D=g.dL_dmeans3D, means2D=g.dL_dmeans2D, opacities=g.dL_dopacity,
+        shs=g.dL_dsh if c.shs is not None else None,
+        colors_precomp=g.dL_dcolors if c.colors_precomp is not None else None,
+        scales=g.dL_dscales if c.scales is not None else None,
+        rotations=g.dL_drotations if c.rotations is not None else None,
+        cov3D_precomp=g.dL_dcov3D if c.cov3D_precomp is not None else None)
+
+
+def rel_err(a, b):
+    """SURVEY.md §8d metric: max |a-b| / max(|b|, 1e-6*max|b|); plus the fraction of elements
+    whose own relative error exceeds 1e-4 (reported, not asserted, by callers)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    if b.size == 0:
+        return 0.0, 0.0
+    scale = max(np.abs(b).max(), 1e-30)
+    denom = np.maximum(np.abs(b), 1e-6 * scale)
+    e = np.abs(a - b) / denom
+    return float(e.max()), float((e > 1e-4).mean())
+
+
+def max_err_over_scale(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    if b.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---- test-only introspection of the (private) scratch layout of libbloomscene_rast.so ----
+def _al(x, a=256):
+    return (x + a - 1) // a * a
+
+
+def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
+    """Peek into the opaque buffers (layout in bloomscene_amd/csrc/api.hip).  Tests only."""
+    geom = geom_t.cpu().numpy()
+    img = img_t.cpu().numpy()
+    out = SimpleNamespace()
+    off = 0
+    out.rec = geom[off:off + P * 48].view(np.float32).reshape(P, 12); off += _al(P * 48)
+    out.rect = geom[off:off + P * 8].view(np.uint16).reshape(P, 4); off += _al(P * 8)
+    out.cov3D = geom[off:off + P * 24].view(np.float32).reshape(P, 6); off += _al(P * 24)
+    out.clamped = geom[off:off + P].copy()
+    N = W * H
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    off = 0
+    out.final_T = img[off:off + N * 4].view(np.float32); off += _al(N * 4)
+    out.n_contrib = img[off:off + N * 4].view(np.uint32); off += _al(N * 4)
+    out.tile_start = img[off:off + (T + 1) * 4].view(np.uint32)
+    if R > 0:
+        b = bin_t.cpu().numpy()
+        off = _al(R * 8)
+        out.point_list = b[off:off + R * 4].view(np.uint32)
+    else:
+        out.point_list = np.zeros(0, dtype=np.uint32)
+    return out
