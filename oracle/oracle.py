@@ -225,6 +225,19 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False):
         _p(st.conic_opacity), _p(st.features), _p(st.final_T), _p(st.n_contrib), _p(grad_color), _p(grad_depth),
         _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors),
         _p(g.abs_sums) if want_abs_sums else None)
+    return backward_chain(st, g)
+
+
+def backward_chain(st, g):
+    """The per-Gaussian part of the backward (computeCov2DCUDA + preprocessCUDA,
+    backward.cu:144-274,346-396) applied to the accumulators already present in ``g``
+    (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors).  Split out so tests can feed it the HIP
+    path's accumulators and check the chain in isolation from the unordered float sums."""
+    L = lib()
+    rs, inp = st.rs, st.inputs
+    P, M, W, H = st.P, st.M, st.W, st.H
+    focal_y = np.float32(H) / (np.float32(2.0) * np.float32(rs.tanfovy))
+    focal_x = np.float32(W) / (np.float32(2.0) * np.float32(rs.tanfovx))
     cov3D = inp.cov3D_precomp if inp.cov3D_precomp is not None else st.cov3D
     L.bsro_backward_cov2d(C.c_int(P), _p(inp.means3D), _p(st.radii), _p(cov3D), C.c_float(focal_x),
                           C.c_float(focal_y), C.c_float(rs.tanfovx), C.c_float(rs.tanfovy), _p(rs.viewmatrix),
@@ -234,4 +247,21 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False):
         _p(inp.scales), _p(inp.rotations), C.c_float(rs.scale_modifier), _p(rs.projmatrix), _p(rs.campos),
         _p(g.dL_dmeans2D), _p(g.dL_dmeans3D), _p(g.dL_dcolors), _p(g.dL_dcov3D), _p(g.dL_dsh), _p(g.dL_dscales),
         _p(g.dL_drotations))
+    return g
+
+
+def empty_grads(st):
+    """Zero-filled gradient namespace (RasterizeGaussiansBackwardCUDA, rasterize_points.cu:154-162)."""
+    P, M = st.P, st.M
+    g = SimpleNamespace()
+    g.dL_dmeans3D = np.zeros((P, 3), dtype=np.float32)
+    g.dL_dmeans2D = np.zeros((P, 3), dtype=np.float32)
+    g.dL_dcolors = np.zeros((P, 3), dtype=np.float32)
+    g.dL_dconic = np.zeros((P, 2, 2), dtype=np.float32)
+    g.dL_dopacity = np.zeros((P, 1), dtype=np.float32)
+    g.dL_dcov3D = np.zeros((P, 6), dtype=np.float32)
+    g.dL_dsh = np.zeros((P, M, 3), dtype=np.float32)
+    g.dL_dscales = np.zeros((P, 3), dtype=np.float32)
+    g.dL_drotations = np.zeros((P, 4), dtype=np.float32)
+    g.abs_sums = None
     return g

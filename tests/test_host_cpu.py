@@ -1,0 +1,179 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+python mirror has the reference's API surface and error behaviour, camera conventions, view
+sharding, and the sort network used by the per-tile sort.  No compute call reaches the GPU."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi, cameras, views
+
+ROOT = Hh.ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "bloomscene_rast.h")).read()
+    hdr_nocomment = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(bsr_[a-z_]+)\s*\(", hdr_nocomment))
+    declared -= {"bsr_alloc_fn"}
+    assert {"bsr_forward", "bsr_backward", "bsr_visible_filter", "bsr_mark_visible", "bsr_last_error",
+            "bsr_version"} <= declared
+    lib = _capi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/bloomscene_rast.h but not exported"
+    assert declared == set(_capi.SIGNATURES), "ctypes table and header disagree"
+    assert lib.bsr_version() == 1
+    assert lib.bsr_last_error() == b""
+    # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
+    assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)
+    assert lib.bsr_geometry_bytes(1000) >= 1000 * (48 + 8 + 24 + 1)
+    assert lib.bsr_binning_bytes(1000) >= 1000 * 12
+    assert lib.bsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 12
+
+
+def test_every_entry_point_cites_the_reference_interface_it_replaces():
+    hdr = open(os.path.join(ROOT, "include", "bloomscene_rast.h")).read()
+    for fn, cite in [("bsr_forward", "rasterizer.h:31-54"), ("bsr_backward", "rasterizer.h:75-105"),
+                     ("bsr_visible_filter", "rasterizer.h:57-73"), ("bsr_mark_visible", "rasterizer.h:24-29")]:
+        assert cite in hdr, (fn, cite)
+
+
+def test_settings_tuple_matches_reference_fields():
+    # depth_diff_gaussian_rasterization/__init__.py:158-170
+    assert GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+
+
+def test_shim_import_path_resolves_to_this_package():
+    # reference gaussian_renderer/__init__.py:16
+    from depth_diff_gaussian_rasterization import GaussianRasterizationSettings as S, GaussianRasterizer as R
+    assert S is GaussianRasterizationSettings and R is GaussianRasterizer
+
+
+def _settings():
+    cam = cameras.identity_camera(32, 32, math.radians(60))
+    return views.make_settings(cam, torch.zeros(3), 1)
+
+
+def test_argument_validation_matches_reference_messages():
+    r = GaussianRasterizer(_settings())
+    m = torch.zeros(4, 3)
+    o = torch.ones(4, 1)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, o, scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, o, shs=torch.zeros(4, 1, 3), colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(m, m, o, colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(m, m, o, colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3), rotations=torch.ones(4, 4),
+          cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must fail loudly -- the product never routes through a CPU path or the oracle."""
+    r = GaussianRasterizer(_settings())
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(m, m, torch.ones(4, 1), colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r.visible_filter(m, torch.ones(4, 3), torch.ones(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r.markVisible(m)
+    with pytest.raises(RuntimeError, match="num_points, 3"):   # rasterize_points.cu:57-59
+        r(torch.zeros(4, 2), m, torch.ones(4, 1), colors_precomp=torch.zeros(4, 3), scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    import bloomscene_amd
+    src = "".join(open(os.path.join(os.path.dirname(bloomscene_amd.__file__), f)).read()
+                  for f in os.listdir(os.path.dirname(bloomscene_amd.__file__)) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_camera_conventions():
+    """A0: viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T, campos = inverse(viewmatrix)[3,:3]."""
+    W, H = 64, 48
+    cams = cameras.rotate360_cameras(8, W, H, math.radians(60))
+    assert len(cams) == 8
+    for i, cam in enumerate(cams):
+        V = cam.world_view_transform.double()
+        assert torch.allclose(V[:3, :3] @ V[:3, :3].T, torch.eye(3, dtype=torch.float64), atol=1e-6)
+        assert torch.allclose(V[3, :3], torch.zeros(3, dtype=torch.float64), atol=1e-6)   # zero translation
+        assert torch.allclose(cam.camera_center, torch.zeros(3), atol=1e-6)
+        assert abs(cam.FoVx - 0.95 * math.radians(60)) < 1e-12   # dataset_readers.py:105
+        Pm = cameras.get_projection_matrix(0.01, 100.0, cam.FoVx, cam.FoVy).double()
+        assert torch.allclose(cam.full_proj_transform.double(), V @ Pm.T, atol=1e-5)
+        # a point on the optical axis of view i projects to the image centre with w = depth
+        axis = V[:3, 2]          # third column of the stored matrix = camera z axis in world coords
+        p = torch.cat([axis * 3.0, torch.ones(1, dtype=torch.float64)])
+        hom = p @ cam.full_proj_transform.double()
+        assert abs(hom[0] / hom[3]) < 1e-5 and abs(hom[1] / hom[3]) < 1e-5 and abs(hom[3] - 3.0) < 1e-5
+    # yaw of view i is 360/n * i about +Y (trajectory.py:16-24)
+    z1 = cams[1].world_view_transform[:3, 2]
+    assert abs(math.degrees(math.atan2(abs(z1[0].item()), z1[2].item())) - 45.0) < 1e-3
+    cam0 = views.yawed_camera(W, H, math.radians(60), 0.0)
+    ident = cameras.identity_camera(W, H, math.radians(60))
+    assert torch.equal(cam0.full_proj_transform, ident.full_proj_transform)
+
+
+def test_shard_views_round_robin_partition():
+    for n, world in [(64, 1), (64, 2), (64, 8), (7, 4), (3, 8)]:
+        seen = sorted(i for r in range(world) for i in views.shard_views(n, r, world))
+        assert seen == list(range(n))
+        sizes = [len(views.shard_views(n, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _bitonic_asc(keys):
+    """Python model of bitonic_sort_asc in bloomscene_amd/csrc/binning.hip (same index maths):
+    all-ascending network, compare-exchanges with an upper index >= n are skipped."""
+    k = list(keys)
+    n = len(k)
+    n2 = 1
+    while n2 < n:
+        n2 <<= 1
+    size = 2
+    while size <= n2:
+        half = size >> 1
+        for i in range(n2 >> 1):
+            blk, off = divmod(i, half)
+            lo, hi = blk * size + off, blk * size + size - 1 - off
+            if hi < n and k[lo] > k[hi]:
+                k[lo], k[hi] = k[hi], k[lo]
+        stride = half >> 1
+        while stride > 0:
+            for i in range(n2 >> 1):
+                lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1))
+                hi = lo | stride
+                if hi < n and k[lo] > k[hi]:
+                    k[lo], k[hi] = k[hi], k[lo]
+            stride >>= 1
+        size <<= 1
+    return k
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 8, 17, 100, 255, 256, 257, 1000, 1025])
+def test_sort_network_sorts_any_length(n):
+    rng = np.random.default_rng(n)
+    keys = [int(x) for x in rng.integers(0, 50, size=n)]   # many duplicates
+    keys = [(d << 32) | i for i, d in enumerate(keys)]       # (depth, id) keys are unique
+    rng.shuffle(keys)
+    assert _bitonic_asc(keys) == sorted(keys)
+
+
+def test_algorithmic_byte_model_is_consistent():
+    """bench.py's per-stage bytes must add up to the contract figure of SURVEY.md §8d."""
+    import bench
+    P, M, R, N = 1_000_000, 16, 4_380_000, 1920 * 1080
+    a = bench.algorithmic_bytes(P, M, R, N)
+    fwd = a["preprocess"] + 8 * P + a["scatter"] + a["sort_tiles"] + 8 * R + a["render_fwd"]
+    assert abs(fwd - bench.step_bytes(P, M, R, N, False)) / fwd < 0.01
+    total = fwd + a["render_bwd"] + a["preprocess_bwd"]
+    assert abs(total - bench.step_bytes(P, M, R, N, True)) / total < 0.01
+    assert abs(bench.step_bytes(P, M, R, N, True) - 1.40e9) / 1.40e9 < 0.01

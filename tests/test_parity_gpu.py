@@ -1,0 +1,335 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/bloomscene_rast.h) against the CPU
+oracle and the committed golden fixtures.  Run on the MI355X box: pytest -m gpu.
+
+Bars (north_star: outputs within 1e-4 rel fp32):
+* forward -- radii, sorted per-tile lists, n_contrib, final_T, colour, depth: BIT-EXACT.  The kernels
+  evaluate every fp32 expression in the reference's order (no FMA contraction) and use the same
+  pinned exp as the oracle, so there is no tolerance to argue about.
+* backward, stage A (the 9 per-Gaussian sums the reference forms with unordered float atomicAdd):
+  |hip - oracle| <= 1e-4*|oracle| + 64*eps32*sum|terms|  (the reference itself is only defined up
+  to that reordering error; the oracle reports sum|terms|).
+* backward, stage B (per-Gaussian chain cov2D/cov3D/SH/projection, no sums): fed with the HIP
+  path's own accumulators the oracle must reproduce the HIP outputs to 1e-6 of each tensor's scale
+  and 1e-4 elementwise.
+* end to end through torch.autograd: error <= 1e-5 of each gradient tensor's largest magnitude.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EPS32 = float(np.finfo(np.float32).eps)
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+CASES = {
+    "sh3": dict(P=1500, W=160, H=96, deg=3, seed=0),
+    "sh1_near_ragged": dict(P=2000, W=133, H=75, deg=1, seed=1, scale_mul=4.0, near_fraction=0.1),
+    "precomp_color": dict(P=1500, W=64, H=64, deg=0, seed=2, color_mode="precomp"),
+    "precomp_cov": dict(P=1500, W=100, H=50, deg=2, seed=3, cov_mode="precomp", scale_mul=3.0),
+    "extraM_scalemod_bg": dict(P=1000, W=80, H=48, deg=1, seed=5, M_extra=5, scale_modifier=1.7, bg=(1.0, 0.5, 0.0)),
+    "shell_view": dict(P=2000, W=96, H=64, deg=2, seed=6, scene="b", view=3, scale_mul=5.0),
+    "lists_gt_1024": dict(P=20000, W=48, H=48, deg=1, seed=7, scale_mul=12.0),       # 64-KB LDS sort class
+    "lists_gt_8192": dict(P=30000, W=20, H=20, deg=0, seed=8, scale_mul=30.0),       # global-memory sort class
+    "single_pixel": dict(P=200, W=1, H=1, deg=0, seed=9, scale_mul=50.0),
+    "one_gaussian": dict(P=1, W=40, H=40, deg=3, seed=10, scale_mul=40.0),
+    "huge_splats": dict(P=300, W=70, H=50, deg=0, seed=11, scale_mul=2000.0),
+    "c2_100k_800x800": dict(P=100000, W=800, H=800, deg=1, seed=0),                  # BASELINE config C2
+}
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda")
+
+
+def _native_forward(c, debug=False, prefiltered=False):
+    """bsr_forward through the python host's native entry point; returns outputs + opaque buffers."""
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    e = torch.Tensor([])
+
+    def d(t):
+        return e if t is None else t.to(dev)
+    rs = Hh.hip_settings(c, dev, debug=debug, prefiltered=prefiltered)
+    t = dict(means3D=c.means3D.to(dev), colors=d(c.colors_precomp), opac=c.opacities.to(dev), scales=d(c.scales),
+             rot=d(c.rotations), cov=d(c.cov3D_precomp), shs=d(c.shs))
+    R, color, depth, radii, gb, bb, ib = RZ._rasterize_gaussians_native(
+        rs.bg, t["means3D"], t["colors"], t["opac"], t["scales"], t["rot"], rs.scale_modifier, t["cov"],
+        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, c.H, c.W, t["shs"], c.deg, rs.campos, prefiltered, debug)
+    torch.cuda.synchronize()
+    return rs, t, R, color, depth, radii, gb, bb, ib
+
+
+def _assert_forward_bit_exact(c, st):
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+    assert R == st.num_rendered
+    np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+    b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    np.testing.assert_array_equal(b.point_list, st.point_list)           # (tile, depth bits, id) order
+    if R:
+        np.testing.assert_array_equal(b.tile_start[:-1][st.ranges[:, 1] > st.ranges[:, 0]],
+                                      st.ranges[st.ranges[:, 1] > st.ranges[:, 0], 0])
+    np.testing.assert_array_equal(b.n_contrib, st.n_contrib)
+    np.testing.assert_array_equal(b.final_T.view(np.uint32), st.final_T.view(np.uint32))
+    np.testing.assert_array_equal(color.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(depth.cpu().numpy().view(np.uint32), st.depth.view(np.uint32))
+    vis = st.radii > 0
+    np.testing.assert_array_equal(b.rec[vis][:, 0:2], st.means2D[vis])
+    np.testing.assert_array_equal(b.rec[vis][:, 7], st.depths[vis])
+    return rs, t, R, radii, gb, bb, ib
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_bit_exact_vs_oracle(name):
+    c = Hh.make_case(**CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    _assert_forward_bit_exact(c, st)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_forward_and_backward_vs_golden_fixture(path):
+    """HIP path against the committed vectors alone (inputs and expected outputs from the .npz)."""
+    from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer
+    z = np.load(path)
+    dev = _dev()
+    W, H, deg = int(z["in_scalars"][0]), int(z["in_scalars"][1]), int(z["in_scalars"][2])
+
+    def opt(k):
+        return None if z[k].size == 0 else torch.from_numpy(z[k]).to(dev).requires_grad_(True)
+    means3D = torch.from_numpy(z["in_means3D"]).to(dev).requires_grad_(True)
+    opac = torch.from_numpy(z["in_opacities"]).to(dev).requires_grad_(True)
+    inp = dict(shs=opt("in_shs"), colors_precomp=opt("in_colors_precomp"), scales=opt("in_scales"),
+               rotations=opt("in_rotations"), cov3D_precomp=opt("in_cov3D_precomp"))
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=float(z["in_scalars"][3]), tanfovy=float(z["in_scalars"][4]),
+        bg=torch.from_numpy(z["in_bg"]).to(dev), scale_modifier=float(z["in_scalars"][5]),
+        viewmatrix=torch.from_numpy(z["in_viewmatrix"]).to(dev), projmatrix=torch.from_numpy(z["in_projmatrix"]).to(dev),
+        sh_degree=deg, campos=torch.from_numpy(z["in_campos"]).to(dev), prefiltered=False, debug=False)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    color, radii, depth = GaussianRasterizer(rs)(means3D=means3D, means2D=means2D, opacities=opac, **inp)
+    np.testing.assert_array_equal(radii.cpu().numpy(), z["radii"])
+    np.testing.assert_array_equal(color.detach().cpu().numpy().view(np.uint32), z["color"].view(np.uint32))
+    np.testing.assert_array_equal(depth.detach().cpu().numpy().view(np.uint32), z["depth"].view(np.uint32))
+    torch.autograd.backward((color, depth), (torch.from_numpy(z["in_gC"]).to(dev), torch.from_numpy(z["in_gD"]).to(dev)))
+    pairs = [(means3D.grad, "dL_dmeans3D"), (means2D.grad, "dL_dmeans2D"), (opac.grad, "dL_dopacity")]
+    for k, gname in (("shs", "dL_dsh"), ("colors_precomp", "dL_dcolors"), ("scales", "dL_dscales"),
+                     ("rotations", "dL_drotations"), ("cov3D_precomp", "dL_dcov3D")):
+        if inp[k] is not None:
+            pairs.append((inp[k].grad, gname))
+    for got, gname in pairs:
+        assert Hh.max_err_over_scale(got.cpu().numpy(), z[gname]) < 1e-5, gname
+
+
+def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD):
+    """bsr_backward straight through ctypes, so the internal dL_dconic/dL_dcolor are visible."""
+    from bloomscene_amd import _capi
+    dev = _dev()
+    P = c.P
+    M = 0 if c.shs is None else c.shs.shape[1]
+    o = dict(device=dev, dtype=torch.float32)
+    # fill with NaN: the call must overwrite every element (no pre-zeroing contract)
+    out = dict(mean2D=torch.full((P, 3), float("nan"), **o), conic=torch.full((P, 4), float("nan"), **o),
+               opacity=torch.full((P, 1), float("nan"), **o), color=torch.full((P, 3), float("nan"), **o),
+               mean3D=torch.full((P, 3), float("nan"), **o), cov3D=torch.full((P, 6), float("nan"), **o),
+               sh=torch.full((P, max(M, 1), 3), float("nan"), **o), scale=torch.full((P, 3), float("nan"), **o),
+               rot=torch.full((P, 4), float("nan"), **o))
+
+    def p(x):
+        return None if x is None or x.numel() == 0 else x.data_ptr()
+    gC, gD = gC.to(dev).contiguous(), gD.to(dev).contiguous()
+    rc = _capi.lib().bsr_backward(
+        P, c.deg, M, R, rs.bg.data_ptr(), c.W, c.H, t["means3D"].data_ptr(), p(t["shs"]), p(t["colors"]),
+        p(t["scales"]), float(rs.scale_modifier), p(t["rot"]), p(t["cov"]), rs.viewmatrix.data_ptr(),
+        rs.projmatrix.data_ptr(), rs.campos.data_ptr(), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
+        gb.data_ptr(), p(bb), ib.data_ptr(), gC.data_ptr(), gD.data_ptr(), out["mean2D"].data_ptr(),
+        out["conic"].data_ptr(), out["opacity"].data_ptr(), out["color"].data_ptr(), out["mean3D"].data_ptr(),
+        out["cov3D"].data_ptr(), out["sh"].data_ptr() if M else None, out["scale"].data_ptr(), out["rot"].data_ptr(),
+        0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _capi.check(rc, "bsr_backward")
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, M
+
+
+BWD_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "extraM_scalemod_bg", "shell_view",
+             "lists_gt_1024", "lists_gt_8192", "huge_splats", "c2_100k_800x800"]
+
+
+@pytest.mark.parametrize("name", BWD_CASES)
+def test_backward_stagewise_vs_oracle(name):
+    c = Hh.make_case(**CASES[name])
+    st, g = Hh.run_oracle(c, backward=True, want_abs_sums=True)
+    rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+    out, M = _raw_backward(c, rs, t, R, radii, gb, bb, ib, c.gC, c.gD)
+
+    # ---- stage A: the nine unordered sums
+    S = g.abs_sums.astype(np.float64)   # [P, 9] sum |term|: mean2D.x,y conic.x,y,w opacity colour r,g,b
+    pairs = [(out["mean2D"][:, 0], g.dL_dmeans2D[:, 0], S[:, 0]), (out["mean2D"][:, 1], g.dL_dmeans2D[:, 1], S[:, 1]),
+             (out["conic"][:, 0], g.dL_dconic.reshape(-1, 4)[:, 0], S[:, 2]),
+             (out["conic"][:, 1], g.dL_dconic.reshape(-1, 4)[:, 1], S[:, 3]),
+             (out["conic"][:, 3], g.dL_dconic.reshape(-1, 4)[:, 3], S[:, 4]),
+             (out["opacity"][:, 0], g.dL_dopacity[:, 0], S[:, 5]),
+             (out["color"][:, 0], g.dL_dcolors[:, 0], S[:, 6]), (out["color"][:, 1], g.dL_dcolors[:, 1], S[:, 7]),
+             (out["color"][:, 2], g.dL_dcolors[:, 2], S[:, 8])]
+    for i, (a, b, s) in enumerate(pairs):
+        err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        bound = 1e-4 * np.abs(b.astype(np.float64)) + 64 * EPS32 * s + 1e-30
+        assert (err <= bound).all(), (i, float((err / bound).max()))
+    assert not out["mean2D"][:, 2].any()
+    assert not out["conic"][:, 2].any()
+
+    # ---- stage B: per-Gaussian chain on the HIP path's own accumulators
+    h = O.empty_grads(st)
+    h.dL_dmeans2D[:] = out["mean2D"]
+    h.dL_dconic[:] = out["conic"].reshape(-1, 2, 2)
+    h.dL_dopacity[:] = out["opacity"]
+    h.dL_dcolors[:] = out["color"]
+    O.backward_chain(st, h)
+    chain = [("mean3D", h.dL_dmeans3D), ("cov3D", h.dL_dcov3D)]
+    if M:
+        chain.append(("sh", h.dL_dsh))
+    if c.scales is not None:
+        chain += [("scale", h.dL_dscales), ("rot", h.dL_drotations)]
+    for k, ref in chain:
+        got = out[k].reshape(ref.shape)
+        assert np.isfinite(got).all(), k
+        assert Hh.max_err_over_scale(got, ref) < 1e-6, k
+        m, _ = Hh.rel_err(got, ref)
+        assert m < 1e-4, (k, m)
+    vis = st.radii > 0
+    for k in ("mean2D", "conic", "opacity", "color", "mean3D", "cov3D"):
+        assert not out[k][~vis].any(), k   # culled rows are exactly zero
+
+
+@pytest.mark.parametrize("name", ["sh3", "precomp_color", "precomp_cov", "shell_view", "c2_100k_800x800"])
+def test_autograd_end_to_end(name):
+    """The reference call shape (gaussian_renderer/__init__.py:224-262) through torch.autograd."""
+    c = Hh.make_case(**CASES[name])
+    st, g = Hh.run_oracle(c)
+    out = Hh.run_hip(c)
+    np.testing.assert_array_equal(out.radii, st.radii)
+    np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+    og = Hh.oracle_grads(c, g)
+    for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        ref, got = getattr(og, k), getattr(out.grads, k)
+        if ref is None:
+            assert got is None, k
+            continue
+        assert got is not None and got.shape == ref.shape, k
+        assert Hh.max_err_over_scale(got, ref) < 1e-5, k
+        _, frac = Hh.rel_err(got, ref)
+        assert frac < 5e-3, (k, frac)   # elements losing > 1e-4 to cancellation in the unordered sums
+
+
+def test_visible_filter_and_mark_visible():
+    from bloomscene_amd import GaussianRasterizer
+    c = Hh.make_case(P=50000, W=320, H=200, deg=1, seed=31, near_fraction=0.3, scene="b", view=5, scale_mul=3.0)
+    dev = _dev()
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev))
+    rs = Hh.oracle_settings(c)
+    radii = rast.visible_filter(c.means3D.to(dev), c.scales.to(dev), c.rotations.to(dev))
+    assert radii.dtype == torch.int32
+    np.testing.assert_array_equal(radii.cpu().numpy(), O.visible_filter(rs, c.means3D, c.scales, c.rotations))
+    present = rast.markVisible(c.means3D.to(dev))
+    assert present.dtype == torch.bool
+    np.testing.assert_array_equal(present.cpu().numpy(), O.mark_visible(c.means3D, rs))
+    cov = Hh.cov3d_from_scale_rot(c.scales, c.rotations)
+    radii2 = rast.visible_filter(c.means3D.to(dev), cov3D_precomp=cov.to(dev))
+    np.testing.assert_array_equal(radii2.cpu().numpy(), O.visible_filter(rs, c.means3D, cov3D_precomp=cov))
+
+
+def test_empty_inputs_errors_debug_and_streams():
+    from bloomscene_amd import GaussianRasterizer
+    dev = _dev()
+    c = Hh.make_case(P=500, W=64, H=40, deg=1, seed=41, near_fraction=0.5)
+    st, _ = Hh.run_oracle(c, backward=False)
+    # P == 0 -> zero images, no instances (rasterize_points.cu:68-82)
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev))
+    z3 = torch.zeros(0, 3, device=dev)
+    color, radii, depth = rast(z3, z3, torch.zeros(0, 1, device=dev), shs=torch.zeros(0, 4, 3, device=dev),
+                               scales=z3, rotations=torch.zeros(0, 4, device=dev))
+    assert radii.numel() == 0 and not color.any() and not depth.any()
+    # prefiltered=True with culled points is an error (auxiliary.h:156-160)
+    rast_p = GaussianRasterizer(Hh.hip_settings(c, dev, prefiltered=True))
+    m = c.means3D.to(dev)
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        rast_p(m, torch.zeros_like(m), c.opacities.to(dev), shs=c.shs.to(dev), scales=c.scales.to(dev),
+               rotations=c.rotations.to(dev))
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        rast_p.visible_filter(m, c.scales.to(dev), c.rotations.to(dev))
+    # debug=True (sync + check after every stage) and a non-default stream give the same bits
+    rast_d = GaussianRasterizer(Hh.hip_settings(c, dev, debug=True))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        col, rad, dep = rast_d(m, torch.zeros_like(m), c.opacities.to(dev), shs=c.shs.to(dev),
+                               scales=c.scales.to(dev), rotations=c.rotations.to(dev))
+    s.synchronize()
+    np.testing.assert_array_equal(col.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(rad.cpu().numpy(), st.radii)
+    # sh_degree larger than the stored coefficients is rejected, not read out of bounds
+    bad = Hh.make_case(P=10, W=32, H=32, deg=0, seed=1)
+    bad.deg = 2
+    with pytest.raises(RuntimeError, match="coefficients"):
+        Hh.run_hip(bad, backward=False)
+
+
+def test_renderer_call_shapes():
+    """render()/prefilter_voxel() result shapes (gaussian_renderer/__init__.py:264-291,342-349)."""
+    from bloomscene_amd import views
+    dev = _dev()
+    c = Hh.make_case(P=3000, W=96, H=64, deg=0, seed=51, color_mode="precomp", scale_mul=4.0)
+    cam = c.cam.to(dev)
+    gs = dict(means3D=c.means3D.to(dev).requires_grad_(True), opacities=c.opacities.to(dev),
+              scales=c.scales.to(dev), rotations=c.rotations.to(dev), colors_precomp=c.colors_precomp.to(dev))
+    res = views.render_view(cam, gs, c.bg.to(dev), sh_degree=1, retain_grad=True)
+    assert set(res) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+    assert res["render"].shape == (3, 64, 96) and res["depth"].shape == (1, 64, 96)
+    res["render"].sum().backward()
+    grad = res["viewspace_points"].grad   # read by training_statis (scene/gaussian_model.py:756)
+    assert grad is not None and grad.shape == (3000, 3) and not grad[:, 2].any()
+    assert (grad[~res["visibility_filter"]] == 0).all()
+    mask = views.prefilter(cam, gs["means3D"].detach(), c.scales.to(dev), c.rotations.to(dev), c.bg.to(dev))
+    assert mask.dtype == torch.bool and torch.equal(mask, res["visibility_filter"])
+
+
+def test_full_size_c3_properties_and_parity():
+    """BASELINE config C3 (1 M Gaussians, SH 3, 1920x1080, fwd+bwd, colour + depth targets):
+    bit-exact forward vs the oracle at full size plus size-independent properties."""
+    from bloomscene_amd import GaussianRasterizer
+    dev = _dev()
+    c = Hh.make_case(P=1_000_000, W=1920, H=1080, deg=3, seed=0)
+    st, g = Hh.run_oracle(c)
+    out = Hh.run_hip(c)
+    np.testing.assert_array_equal(out.radii, st.radii)
+    np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+    og = Hh.oracle_grads(c, g)
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        assert Hh.max_err_over_scale(getattr(out.grads, k), getattr(og, k)) < 1e-5, k
+    # run-to-run: forward deterministic to the bit
+    out2 = Hh.run_hip(c, backward=False)
+    np.testing.assert_array_equal(out2.color.view(np.uint32), out.color.view(np.uint32))
+    # linearity of the backward in the upstream gradient, and dL_ddepth ignored
+    c2 = Hh.make_case(P=1_000_000, W=1920, H=1080, deg=3, seed=0)
+    c2.gC = c.gC * 2.0
+    c2.gD = c.gD * -7.0 + 1.0
+    out3 = Hh.run_hip(c2)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert Hh.max_err_over_scale(getattr(out3.grads, k), 2.0 * getattr(out.grads, k)) < 1e-5, k
+    # blend weights + final_T == 1 (colours == bg == 1 -> image == 1)
+    ones = Hh.make_case(P=1_000_000, W=1920, H=1080, deg=0, seed=0, color_mode="precomp", bg=(1.0, 1.0, 1.0))
+    ones.colors_precomp = torch.ones_like(ones.colors_precomp)
+    o1 = Hh.run_hip(ones, backward=False)
+    assert np.abs(o1.color - 1.0).max() < 1e-5
+    # visible_filter == forward radii at full size
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev))
+    rf = rast.visible_filter(c.means3D.to(dev), c.scales.to(dev), c.rotations.to(dev))
+    np.testing.assert_array_equal(rf.cpu().numpy(), out.radii)
