@@ -5,7 +5,8 @@
 //   memset(tile_count) -> k_preprocess (project, cull, SH, count instances per tile)
 //   -> k_scan_tiles (tile ranges) -> 4-byte D2H read of R -> binning alloc
 //   -> k_scatter -> k_sort_tiles (per-tile LDS sort) -> k_render_fwd.
-// Backward (rasterizer_impl.cu:403-504): memset(4 accumulators) -> k_render_bwd -> k_preprocess_bwd.
+// Backward (rasterizer_impl.cu:403-504): k_inst_offsets -> k_render_bwd (per-instance partial sums
+// to a slab, no global atomics) -> k_preprocess_bwd (gathers them per Gaussian, then the chain).
 #include "../../include/bloomscene_rast.h"
 #include "common.h"
 
@@ -77,10 +78,11 @@ void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uin
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
+void launch_inst_offsets(int P, const ushort4* rect, uint32_t* inst_offset, uint32_t* counter, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                       hipStream_t s);
+                       const float4* rec, const ushort4* rect, const uint32_t* inst_offset, const float* bg,
+                       const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of,
+                       float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- errors
@@ -109,6 +111,25 @@ static int fail(const char* fmt, ...)
 		if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                        \
 		if (_e != hipSuccess) return fail("stage %s failed: %s", name, hipGetErrorString(_e));     \
 	} while (0)
+
+// Keep freed stream-ordered allocations cached in the device's default pool (the default release
+// threshold of 0 would hand them back to the driver at every synchronisation).
+static int ensure_pool_keeps_memory()
+{
+	static std::mutex mu;
+	static std::vector<int> done_devices;
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	std::lock_guard<std::mutex> lk(mu);
+	for (int d : done_devices)
+		if (d == dev) return 0;
+	hipMemPool_t pool;
+	HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
+	uint64_t threshold = UINT64_MAX;
+	HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
+	done_devices.push_back(dev);
+	return 0;
+}
 
 // ---------------------------------------------------------------- stage profiler (bench only)
 struct StageRec {
@@ -406,18 +427,36 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	ImgState img = ImgState::carve(image_buffer, N, (size_t)T);
 	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0));
 
-	{
-		StageTimer t("zero_grads", s);
-		HIP_TRY(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), s));
-		HIP_TRY(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), s));
-		HIP_TRY(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), s));
-		HIP_TRY(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * sizeof(float), s));
-	}
+	// Backward-only scratch (stream-ordered, from the device's default memory pool):
+	//   inst_offset[P] u32 | counter | slot_of[R] u32 | slab[R][12] f32
+	const size_t Rn = (size_t)(R > 0 ? R : 0);
+	const size_t off_counter = align_up((size_t)P * 4, 256);
+	const size_t off_slot = off_counter + 256;
+	const size_t off_slab = off_slot + align_up(Rn * 4, 256);
+	const size_t scratch_bytes = off_slab + align_up(Rn * 48, 256);
+	if (ensure_pool_keeps_memory()) return 1;
+	char* scratch = nullptr;
+	HIP_TRY(hipMallocAsync((void**)&scratch, scratch_bytes, s));
+	uint32_t* inst_offset = (uint32_t*)scratch;
+	uint32_t* counter = (uint32_t*)(scratch + off_counter);
+	uint32_t* slot_of = (uint32_t*)(scratch + off_slot);
+	float4* slab = (float4*)(scratch + off_slab);
+	struct ScratchFree {
+		char* p; hipStream_t s;
+		~ScratchFree() { if (p) (void)hipFreeAsync(p, s); }
+	} scratch_guard{scratch, s};
+
 	if (R > 0) {
 		{
+			StageTimer t("inst_offsets", s);
+			HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
+			launch_inst_offsets(P, geom.rect, inst_offset, counter, s);
+		}
+		STAGE_CHECK("inst_offsets", debug, s);
+		{
 			StageTimer t("render_bwd", s);
-			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
-			                  img.n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, s);
+			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.rect, inst_offset,
+			                  background, img.final_T, img.n_contrib, dL_dpix, slot_of, slab, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}
@@ -430,7 +469,8 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	a.focal_y = height / (2.0f * tan_fovy);
 	a.focal_x = width / (2.0f * tan_fovx);
 	a.geom = geom;
-	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dcolor = dL_dcolor;
+	a.inst_offset = inst_offset; a.slot_of = slot_of; a.slab = slab;
+	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
 	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
 	{
 		StageTimer t("preprocess_bwd", s);

@@ -77,9 +77,13 @@ struct BwdArgs {
 	const float* campos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	GeomState geom;
-	const float* dL_dmean2D;   // [P,3]
-	const float* dL_dconic;    // [P,4]
-	const float* dL_dcolor;    // [P,3]
+	const uint32_t* inst_offset;   // [P]  start of the Gaussian's block in slot_of
+	const uint32_t* slot_of;       // [R]  list slot of the k-th tile instance of each Gaussian
+	const float4* slab;            // [R][3] per-instance partial sums written by k_render_bwd
+	float* dL_dmean2D;         // [P,3]  (outputs; fully written)
+	float* dL_dconic;          // [P,4]
+	float* dL_dopacity;        // [P]
+	float* dL_dcolor;          // [P,3]
 	float* dL_dmean3D;         // [P,3]
 	float* dL_dcov3D;          // [P,6]
 	float* dL_dsh;             // [P,M,3]
@@ -107,6 +111,25 @@ __device__ __forceinline__ float bsr_expf(float x)
 	p = __builtin_fmaf(p, r, 1.0f);
 	p = __builtin_fmaf(p, r, 1.0f);
 	return __builtin_ldexpf(p, (int)k);
+}
+
+// Branch-free variant for arguments known to be <= 0 (or NaN): bit-identical to bsr_expf there.
+// NaN flows through the fma chain; huge negative arguments are fixed up by the final select.
+__device__ __forceinline__ float bsr_expf_nonpos(float x)
+{
+	const float k = __builtin_rintf(x * 1.44269504088896341f);
+	float r = __builtin_fmaf(-k, 0.693359375f, x);
+	r = __builtin_fmaf(-k, -2.12194440e-4f, r);
+	float p = 1.0f / 5040.0f;
+	p = __builtin_fmaf(p, r, 1.0f / 720.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 120.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 24.0f);
+	p = __builtin_fmaf(p, r, 1.0f / 6.0f);
+	p = __builtin_fmaf(p, r, 0.5f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	p = __builtin_fmaf(p, r, 1.0f);
+	const float v = __builtin_ldexpf(p, (int)k);
+	return (x < -104.0f) ? 0.0f : v;
 }
 
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a

@@ -3,8 +3,10 @@
 // Fuses the reference's two kernels computeCov2DCUDA (cuda_rasterizer/backward.cu:144-274) and
 // preprocessCUDA (:346-396, with computeColorFromSH :20-139 and computeCov3D :278-341) into one
 // streaming pass: dL_dmean3D is assigned by the cov2D part and then incremented by the projection
-// and SH parts in the reference's order, without the round trip through HBM.  Rows of culled
-// Gaussians are written as zeros here, so callers need no 300 MB memset
+// and SH parts in the reference's order, without the round trip through HBM.  It also performs the
+// gather half of the atomic-free accumulation (see render_bwd.hip): the Gaussian's per-instance
+// partial sums are fetched through the instance->slot map and added in a fixed order.  Every
+// output row is written here (zeros for culled Gaussians), so callers need no 300 MB memset
 // (rasterize_points.cu:154-162 zero-fills everything up front).
 #include "common.h"
 #include "sh.h"
@@ -33,7 +35,7 @@ __device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, co
 }
 
 template <int DEG>
-__device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const float3 m, float* dmean)
+__device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const float3 m, const float* dcolor, float* dmean)
 {
 	constexpr int NC = (DEG + 1) * (DEG + 1);
 	float c[NC * 3];
@@ -42,7 +44,7 @@ __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const floa
 	const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
 	const float x = ox / len, y = oy / len, z = oz / len;
 	const uint8_t cl = a.geom.clamped[idx];
-	float dL_dRGB[3] = {a.dL_dcolor[3 * idx], a.dL_dcolor[3 * idx + 1], a.dL_dcolor[3 * idx + 2]};
+	float dL_dRGB[3] = {dcolor[0], dcolor[1], dcolor[2]};
 	dL_dRGB[0] *= (cl & 1) ? 0.f : 1.f;
 	dL_dRGB[1] *= (cl & 2) ? 0.f : 1.f;
 	dL_dRGB[2] *= (cl & 4) ? 0.f : 1.f;
@@ -65,6 +67,30 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
 	const ushort4 rc = a.geom.rect[idx];
 	const bool visible = a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y);
 
+	// ---- gather: add the per-instance partial sums of this Gaussian in tile (row-major) order.
+	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
+	// the order is fixed, so the per-Gaussian sums do not depend on scheduling.
+	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	{
+		const uint32_t n_inst = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
+		const uint32_t off = n_inst ? a.inst_offset[idx] : 0u;
+		for (uint32_t k = 0; k < n_inst; k++) {
+			const float4* row = a.slab + (size_t)a.slot_of[off + k] * 3;
+			const float4 s0 = row[0], s1 = row[1], s2 = row[2];
+			g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
+			g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
+			g[8] += s2.x;
+		}
+	}
+	a.dL_dmean2D[3 * idx] = g[0];
+	a.dL_dmean2D[3 * idx + 1] = g[1];
+	a.dL_dmean2D[3 * idx + 2] = 0.f;
+	reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g[2], g[3], 0.f, g[4]);
+	a.dL_dopacity[idx] = g[5];
+	a.dL_dcolor[3 * idx] = g[6];
+	a.dL_dcolor[3 * idx + 1] = g[7];
+	a.dL_dcolor[3 * idx + 2] = g[8];
+
 	float dmean[3] = {0.f, 0.f, 0.f};
 	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f};
@@ -79,7 +105,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
 		const float* cov_src = a.cov3D_precomp ? a.cov3D_precomp + (size_t)idx * 6 : a.geom.cov3D + (size_t)idx * 6;
 #pragma unroll
 		for (int k = 0; k < 6; k++) V[k] = cov_src[k];
-		const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcw = a.dL_dconic[4 * idx + 3];
+		const float dcx = g[2], dcy = g[3], dcw = g[4];
 
 		// shared prologue (same expressions as the forward)
 		float tx = vm[0] * m.x + vm[4] * m.y + vm[8] * m.z + vm[12];
@@ -155,7 +181,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
 		const float m_w = 1.0f / (m_homw + 0.0000001f);
 		const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
 		const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-		const float g2x = a.dL_dmean2D[3 * idx], g2y = a.dL_dmean2D[3 * idx + 1];
+		const float g2x = g[0], g2y = g[1];
 		const float pdx = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
 		const float pdy = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
 		const float pdz = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
@@ -164,10 +190,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
 		dmean[2] += pdz;
 
 		if (a.shs) {
-			if (a.D <= 0) sh_bwd_deg<0>(a, idx, m, dmean);
-			else if (a.D == 1) sh_bwd_deg<1>(a, idx, m, dmean);
-			else if (a.D == 2) sh_bwd_deg<2>(a, idx, m, dmean);
-			else sh_bwd_deg<3>(a, idx, m, dmean);
+			if (a.D <= 0) sh_bwd_deg<0>(a, idx, m, &g[6], dmean);
+			else if (a.D == 1) sh_bwd_deg<1>(a, idx, m, &g[6], dmean);
+			else if (a.D == 2) sh_bwd_deg<2>(a, idx, m, &g[6], dmean);
+			else sh_bwd_deg<3>(a, idx, m, &g[6], dmean);
 		}
 
 		if (a.scales) {

@@ -1,57 +1,67 @@
-// Backward tile renderer: back-to-front re-traversal producing dL/d(mean2D, conic, opacity, colour).
+// Backward tile renderer: back-to-front re-traversal producing, per list entry (= per
+// (tile, Gaussian) instance), the nine partial sums dL/d(mean2D.xy, conic.xyw, opacity, colour.rgb).
 //
 // Semantics: reference renderCUDA (backward), cuda_rasterizer/backward.cu:399-586 (under
 // /root/reference/submodules/depth-diff-gaussian-rasterization); dL_depths is ignored exactly as
 // there (:457-463,539-554 are commented out).  Per (pixel, Gaussian) pair the nine contributions
 // are computed with the reference's operation order.
 //
-// The reference issues 9 lane-scattered float atomicAdds per pair.  On MI355X such atomics run
-// ~17x below the contiguous rate, so the 9 partials are first summed over the wave's 64 pixels
-// with DPP row operations (no LDS traffic), then over the tile's 4 waves with LDS atomics, and
-// only one global atomic per (tile, Gaussian, component) is issued -- 256x fewer.
-#include "common.h"
+// The reference issues 9 lane-scattered float atomicAdds per pair.  On MI355X lane-scattered
+// global float atomics run ~17x below the contiguous rate (~20 G/s chip-wide), which would cap this
+// kernel at ~2 ms for C3.  Instead NO global atomic is issued at all:
+//   * the 9 partials are summed over the wave's 64 pixels with DPP row operations (hand
+//     interleaved so no DPP hazard nops are needed) down to four row sums,
+//   * the row sums of the tile's 4 waves are combined with native LDS float atomics,
+//   * each instance's 9 sums are written ONCE, coalesced, to a slab row [R][12] (48 B),
+//   * k_preprocess_bwd later gathers the rows of each Gaussian through an instance->slot map
+//     (written here while staging) and adds them in a fixed order.
+// As in the forward pass, a staged batch is first compacted per 8x8 quadrant (tile_common.h).
+#include "tile_common.h"
 
 namespace bsr {
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v)
+// 64-lane -> 4 row sums (every lane of a row of 16 ends with its row's sum), 9 values at once.
+// Step-major order: consecutive instructions touch different registers, so the 2-wait-state
+// "VALU write -> DPP read" hazard never arises inside the block (s_nop covers the entry).
+#define BSR_DPP9(ctrl)                                                    \
+	"v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
+	"v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+
+__device__ __forceinline__ void row_sums9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
+                                          float& v7, float& v8)
 {
-	const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-	return v + __int_as_float(moved);
+	asm volatile("s_nop 1\n" BSR_DPP9("quad_perm:[1,0,3,2]") BSR_DPP9("quad_perm:[2,3,0,1]") BSR_DPP9("row_half_mirror")
+	                 BSR_DPP9("row_mirror")
+	             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
-// Sum over the 64 lanes of the wave; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-	v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-	v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-	v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
-	v = dpp_add<0x140, 0xf>(v);   // row_mirror      -> every lane holds its row-of-16 sum
-	v = dpp_add<0x142, 0xa>(v);   // row_bcast15     -> rows 1,3 += rows 0,2
-	v = dpp_add<0x143, 0xc>(v);   // row_bcast31     -> rows 2,3 += rows 0+1
-	return v;
-}
+struct BwdShared {
+	TileStage st;
+	float acc[9][BSR_BLOCK];
+	uint32_t max_contrib[4];
+};
 
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, int W, int H,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ rec,
+                                                          const ushort4* __restrict__ rect,
+                                                          const uint32_t* __restrict__ inst_offset,
                                                           const float* __restrict__ bg_color,
                                                           const float* __restrict__ final_Ts,
                                                           const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpixels,
-                                                          float* __restrict__ dL_dmean2D,   // [P,3]
-                                                          float* __restrict__ dL_dconic2D,  // [P,4]
-                                                          float* __restrict__ dL_dopacity,  // [P]
-                                                          float* __restrict__ dL_dcolors)   // [P,3]
+                                                          uint32_t* __restrict__ slot_of,   // [R]
+                                                          float4* __restrict__ slab)        // [R][3]
 {
-	__shared__ float4 s_q0[BSR_BLOCK];
-	__shared__ float4 s_q1[BSR_BLOCK];
-	__shared__ float4 s_q2[BSR_BLOCK];
-	__shared__ uint32_t s_id[BSR_BLOCK];
-	__shared__ float s_acc[9][BSR_BLOCK];
-	__shared__ uint32_t s_touched[BSR_BLOCK];
-	__shared__ uint32_t s_max[4];
+	__shared__ BwdShared sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
@@ -62,10 +72,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixfx = (float)px, pixfy = (float)py;
+	const float tile_x0 = (float)(tx * BSR_TILE), tile_y0 = (float)(ty * BSR_TILE);
 	const size_t pix_id = (size_t)W * py + px;
 	const size_t plane = (size_t)H * W;
 
 	const uint32_t start = tile_start[tile];
+	const int n = (int)(tile_start[tile + 1] - start);
 
 	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
 	float T = T_final;
@@ -88,128 +100,174 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	uint32_t m = last_contributor;
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-	if (lane == 0) s_max[wave] = m;
-	s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f;
-	s_acc[3][tid] = 0.f; s_acc[4][tid] = 0.f; s_acc[5][tid] = 0.f;
-	s_acc[6][tid] = 0.f; s_acc[7][tid] = 0.f; s_acc[8][tid] = 0.f;
-	s_touched[tid] = 0;
+	if (lane == 0) sh.max_contrib[wave] = m;
+#pragma unroll
+	for (int k = 0; k < 9; k++) sh.acc[k][tid] = 0.f;
 	__syncthreads();
-	const int n_walk = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
 
+	// LDS byte address of acc[0][0] for the native ds_add_f32 path
 	for (int base = 0; base < n_walk; base += BSR_BLOCK) {
 		const int cnt = min(BSR_BLOCK, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
-		if (tid < cnt) {
-			const uint32_t id = point_list[start + (uint32_t)(top - tid)];
+		const bool valid = tid < cnt;
+		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+		uint32_t my_slot = 0;
+		if (valid) {
+			my_slot = start + (uint32_t)(top - tid);
+			const uint32_t id = point_list[my_slot];
 			const float4* r = rec + (size_t)id * 3;
-			s_id[tid] = id;
-			s_q0[tid] = r[0];
-			s_q1[tid] = r[1];
-			s_q2[tid] = r[2];
+			r0 = r[0];
+			r1 = r[1];
+			r2 = r[2];
+			const ushort4 rc = rect[id];
+			const uint32_t k = (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
+			slot_of[inst_offset[id] + k] = my_slot;
 		}
-		__syncthreads();
+		// (the trailing barrier of the previous iteration fenced the staging buffers)
+		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
-		for (int j = 0; j < cnt; j++) {
+		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+		for (int i = 0; i < n_u; i++) {
+			const int j = __builtin_amdgcn_readfirstlane((int)sh.st.list[wave][i]);
 			const uint32_t contributor = (uint32_t)(top - j);
-			const float4 q0 = s_q0[j];
-			const float4 q1 = s_q1[j];   // conic c, power cut, opacity, depth
+			const float4 q0 = sh.st.q0[j];
+			const float4 q1 = sh.st.q1[j];   // conic c, power cut, opacity, depth
 			const float dx = q0.x - pixfx;
 			const float dy = q0.y - pixfy;
 			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-			bool active = (contributor < last_contributor) && !(power > 0.0f) && !(power < q1.y);
-			float G = 0.f, alpha = 0.f;
-			if (active) {
-				G = bsr_expf(power);
-				alpha = fminf(0.99f, q1.z * G);
-				active = !(alpha < 1.0f / 255.0f);
-			}
-			if (__ballot(active) == 0ull) continue;   // wave-uniform
+			const bool cand = (contributor < last_contributor) && !(power > 0.0f) && !(power < q1.y);
+			if (__ballot(cand) == 0ull) continue;   // wave-uniform
 
-			float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-			if (active) {
-				const float4 q2 = s_q2[j];
-				T = T / (1.f - alpha);
-				const float dchannel_dcolor = alpha * T;
-				float dL_dalpha = 0.0f;
-				accum_rec0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
-				last_c0 = q2.x;
-				dL_dalpha += (q2.x - accum_rec0) * dpx0;
-				v6 = dchannel_dcolor * dpx0;
-				accum_rec1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
-				last_c1 = q2.y;
-				dL_dalpha += (q2.y - accum_rec1) * dpx1;
-				v7 = dchannel_dcolor * dpx1;
-				accum_rec2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
-				last_c2 = q2.z;
-				dL_dalpha += (q2.z - accum_rec2) * dpx2;
-				v8 = dchannel_dcolor * dpx2;
-				dL_dalpha *= T;
-				last_alpha = alpha;
-				dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-				const float dL_dG = q1.z * dL_dalpha;
-				const float gdx = G * dx;
-				const float gdy = G * dy;
-				const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-				const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-				v0 = dL_dG * dG_ddelx * ddelx_dx;
-				v1 = dL_dG * dG_ddely * ddely_dy;
-				v2 = -0.5f * gdx * dx * dL_dG;
-				v3 = -0.5f * gdx * dy * dL_dG;
-				v4 = -0.5f * gdy * dy * dL_dG;
-				v5 = G * dL_dalpha;
-			}
-			v0 = wave_sum_to_lane63(v0);
-			v1 = wave_sum_to_lane63(v1);
-			v2 = wave_sum_to_lane63(v2);
-			v3 = wave_sum_to_lane63(v3);
-			v4 = wave_sum_to_lane63(v4);
-			v5 = wave_sum_to_lane63(v5);
-			v6 = wave_sum_to_lane63(v6);
-			v7 = wave_sum_to_lane63(v7);
-			v8 = wave_sum_to_lane63(v8);
-			if (lane == 63) {
-				atomicAdd(&s_acc[0][j], v0);
-				atomicAdd(&s_acc[1][j], v1);
-				atomicAdd(&s_acc[2][j], v2);
-				atomicAdd(&s_acc[3][j], v3);
-				atomicAdd(&s_acc[4][j], v4);
-				atomicAdd(&s_acc[5][j], v5);
-				atomicAdd(&s_acc[6][j], v6);
-				atomicAdd(&s_acc[7][j], v7);
-				atomicAdd(&s_acc[8][j], v8);
-				s_touched[j] = 1;
+			// slow path: fully predicated
+			const float4 q2 = sh.st.q2[j];
+			const float G = bsr_expf_nonpos(power);
+			const float alpha = fminf(0.99f, q1.z * G);
+			const bool active = cand && !(alpha < 1.0f / 255.0f);
+			if (__ballot(active) == 0ull) continue;
+
+			const float Tn = T / (1.f - alpha);
+			const float dchannel_dcolor = alpha * Tn;
+			float dL_dalpha = 0.0f;
+			const float ar0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
+			dL_dalpha += (q2.x - ar0) * dpx0;
+			const float ar1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
+			dL_dalpha += (q2.y - ar1) * dpx1;
+			const float ar2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
+			dL_dalpha += (q2.z - ar2) * dpx2;
+			dL_dalpha *= Tn;
+			dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+			const float dL_dG = q1.z * dL_dalpha;
+			const float gdx = G * dx;
+			const float gdy = G * dy;
+			const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+			const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+			float v0 = active ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
+			float v1 = active ? dL_dG * dG_ddely * ddely_dy : 0.f;
+			float v2 = active ? -0.5f * gdx * dx * dL_dG : 0.f;
+			float v3 = active ? -0.5f * gdx * dy * dL_dG : 0.f;
+			float v4 = active ? -0.5f * gdy * dy * dL_dG : 0.f;
+			float v5 = active ? G * dL_dalpha : 0.f;
+			float v6 = active ? dchannel_dcolor * dpx0 : 0.f;
+			float v7 = active ? dchannel_dcolor * dpx1 : 0.f;
+			float v8 = active ? dchannel_dcolor * dpx2 : 0.f;
+			// per-pixel recurrences (reference :522-556)
+			T = active ? Tn : T;
+			accum_rec0 = active ? ar0 : accum_rec0;
+			accum_rec1 = active ? ar1 : accum_rec1;
+			accum_rec2 = active ? ar2 : accum_rec2;
+			last_c0 = active ? q2.x : last_c0;
+			last_c1 = active ? q2.y : last_c1;
+			last_c2 = active ? q2.z : last_c2;
+			last_alpha = active ? alpha : last_alpha;
+
+			row_sums9(v0, v1, v2, v3, v4, v5, v6, v7, v8);
+			if ((lane & 15) == 15) {   // one lane per row of 16: 4 LDS atomics per component and wave
+				atomicAdd(&sh.acc[0][j], v0);
+				atomicAdd(&sh.acc[1][j], v1);
+				atomicAdd(&sh.acc[2][j], v2);
+				atomicAdd(&sh.acc[3][j], v3);
+				atomicAdd(&sh.acc[4][j], v4);
+				atomicAdd(&sh.acc[5][j], v5);
+				atomicAdd(&sh.acc[6][j], v6);
+				atomicAdd(&sh.acc[7][j], v7);
+				atomicAdd(&sh.acc[8][j], v8);
 			}
 		}
 		__syncthreads();
-		if (tid < cnt && s_touched[tid]) {
-			const uint32_t id = s_id[tid];
-			atomicAdd(&dL_dmean2D[(size_t)id * 3 + 0], s_acc[0][tid]);
-			atomicAdd(&dL_dmean2D[(size_t)id * 3 + 1], s_acc[1][tid]);
-			atomicAdd(&dL_dconic2D[(size_t)id * 4 + 0], s_acc[2][tid]);
-			atomicAdd(&dL_dconic2D[(size_t)id * 4 + 1], s_acc[3][tid]);
-			atomicAdd(&dL_dconic2D[(size_t)id * 4 + 3], s_acc[4][tid]);
-			atomicAdd(&dL_dopacity[id], s_acc[5][tid]);
-			atomicAdd(&dL_dcolors[(size_t)id * 3 + 0], s_acc[6][tid]);
-			atomicAdd(&dL_dcolors[(size_t)id * 3 + 1], s_acc[7][tid]);
-			atomicAdd(&dL_dcolors[(size_t)id * 3 + 2], s_acc[8][tid]);
+		if (valid) {
+			float4* row = slab + (size_t)my_slot * 3;
+			row[0] = make_float4(sh.acc[0][tid], sh.acc[1][tid], sh.acc[2][tid], sh.acc[3][tid]);
+			row[1] = make_float4(sh.acc[4][tid], sh.acc[5][tid], sh.acc[6][tid], sh.acc[7][tid]);
+			row[2] = make_float4(sh.acc[8][tid], 0.f, 0.f, 0.f);
+#pragma unroll
+			for (int k = 0; k < 9; k++) sh.acc[k][tid] = 0.f;
 		}
-		s_acc[0][tid] = 0.f; s_acc[1][tid] = 0.f; s_acc[2][tid] = 0.f;
-		s_acc[3][tid] = 0.f; s_acc[4][tid] = 0.f; s_acc[5][tid] = 0.f;
-		s_acc[6][tid] = 0.f; s_acc[7][tid] = 0.f; s_acc[8][tid] = 0.f;
-		s_touched[tid] = 0;
 		__syncthreads();
+	}
+
+	// entries no pixel of the tile reached: zero rows, but they still need their map entry
+	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
+		const uint32_t slot = start + (uint32_t)pos;
+		const uint32_t id = point_list[slot];
+		const ushort4 rc = rect[id];
+		const uint32_t k = (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
+		slot_of[inst_offset[id] + k] = slot;
+		float4* row = slab + (size_t)slot * 3;
+		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		row[0] = z;
+		row[1] = z;
+		row[2] = z;
 	}
 }
 
+// inst_offset[g] = start of Gaussian g's block in slot_of; blocks are laid out in an arbitrary
+// (atomic) order of 1024-Gaussian chunks, contiguous and ascending inside a chunk.
+__global__ void __launch_bounds__(1024) k_inst_offsets(int P, const ushort4* __restrict__ rect,
+                                                       uint32_t* __restrict__ inst_offset,
+                                                       uint32_t* __restrict__ counter)
+{
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int idx = blockIdx.x * 1024 + tid;
+	uint32_t v = 0;
+	if (idx < P) {
+		const ushort4 r = rect[idx];
+		v = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
+	}
+	uint32_t incl = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(incl, d, 64);
+		if (lane >= d) incl += t;
+	}
+	if (lane == 63) s_wave[wave] = incl;
+	__syncthreads();
+	uint32_t wave_off = 0, total = 0;
+	for (int w = 0; w < 16; w++) {
+		if (w < wave) wave_off += s_wave[w];
+		total += s_wave[w];
+	}
+	if (tid == 0) s_base = atomicAdd(counter, total);
+	__syncthreads();
+	if (idx < P) inst_offset[idx] = s_base + wave_off + incl - v;
+}
+
+void launch_inst_offsets(int P, const ushort4* rect, uint32_t* inst_offset, uint32_t* counter, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_inst_offsets, dim3((P + 1023) / 1024), dim3(1024), 0, s, P, rect, inst_offset, counter);
+}
+
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                       const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                       hipStream_t s)
+                       const float4* rec, const ushort4* rect, const uint32_t* inst_offset, const float* bg,
+                       const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of,
+                       float4* slab, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
 	hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
-	                   bg, final_T, n_contrib, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+	                   rect, inst_offset, bg, final_T, n_contrib, dL_dpix, slot_of, slab);
 }
 
 }  // namespace bsr

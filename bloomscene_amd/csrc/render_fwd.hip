@@ -6,13 +6,14 @@
 // evaluated in the reference's order, so results match the CPU oracle bit for bit.
 //
 // MI355X mapping: one tile = one 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel
-// quadrant (compact footprint -> whole-wave skips of splats that miss the quadrant).  List
-// entries are staged 256 at a time: each thread gathers one 48-byte splat record (3 x 16-B loads
-// from the L2/Infinity-Cache resident record table) into LDS; waves then walk the batch with
-// broadcast LDS reads.  The reject path needs only 24 B per entry (position, conic, power cut)
-// and no exp: `power < power_cut` (precomputed -ln(255*opacity) minus a safety margin) proves
-// alpha < 1/255 without evaluating it.
-#include "common.h"
+// quadrant.  List entries are staged 256 at a time: each thread gathers one 48-byte splat record
+// (3 x 16-B loads from the L2/Infinity-Cache resident record table), runs a conservative
+// ellipse-vs-quadrant test on it and the batch is compacted with wave ballots + prefix popcounts
+// into one ordered index list per wave (tile_common.h).  A wave then walks only the entries that
+// can touch its quadrant, with broadcast LDS reads.  The per-pixel reject path needs 24 B of LDS
+// and no exp: `power < power_cut` (precomputed -ln(255*opacity) minus a margin) proves
+// alpha < 1/255 without evaluating it.  The inner loop is wave-uniform (one ballot per entry).
+#include "tile_common.h"
 
 namespace bsr {
 
@@ -26,9 +27,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
                                                           float* __restrict__ out_color,
                                                           float* __restrict__ out_depth)
 {
-	__shared__ float4 s_q0[BSR_BLOCK];
-	__shared__ float4 s_q1[BSR_BLOCK];
-	__shared__ float4 s_q2[BSR_BLOCK];
+	__shared__ TileStage st;
+	__shared__ int s_done[4];
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
 	const bool inside = px < W && py < H;
 	const float pixfx = (float)px, pixfy = (float)py;
+	const float tile_x0 = (float)(tx * BSR_TILE), tile_y0 = (float)(ty * BSR_TILE);
 
 	const uint32_t start = tile_start[tile];
 	const uint32_t end = tile_start[tile + 1];
@@ -52,42 +53,62 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	float acc = 0.000001f;
 
 	for (int base = 0; base < n; base += BSR_BLOCK) {
-		// whole tile finished?  (also the WAR barrier for the staging buffers)
-		if (__syncthreads_and(done)) break;
+		// whole tile finished?  (the barrier is also the WAR fence for the staging buffers)
+		const bool wave_done = (__ballot(!done) == 0ull);
+		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+		__syncthreads();
+		if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+
 		const int cnt = min(BSR_BLOCK, n - base);
-		if (tid < cnt) {
+		const bool valid = tid < cnt;
+		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+		if (valid) {
 			const uint32_t id = point_list[start + base + tid];
 			const float4* r = rec + (size_t)id * 3;
-			s_q0[tid] = r[0];
-			s_q1[tid] = r[1];
-			s_q2[tid] = r[2];
+			r0 = r[0];
+			r1 = r[1];
+			r2 = r[2];
 		}
-		__syncthreads();
+		const int n_mine = stage_and_compact(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
-		for (int j = 0; !done && j < cnt; j++) {
-			const float4 q0 = s_q0[j];                                              // x, y, conic a, conic b
-			const float2 ct = *reinterpret_cast<const float2*>(&s_q1[j]);            // conic c, power cut
-			const float dx = q0.x - pixfx;
-			const float dy = q0.y - pixfy;
-			const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
-			if (power > 0.0f) continue;
-			if (power < ct.y) continue;   // alpha < 1/255 for certain
-			const float2 od = *(reinterpret_cast<const float2*>(&s_q1[j]) + 1);      // opacity, depth
-			const float alpha = fminf(0.99f, od.x * bsr_expf(power));
-			if (alpha < 1.0f / 255.0f) continue;
-			const float test_T = T * (1 - alpha);
-			if (test_T < 0.0001f) {
-				done = true;
-				continue;
+		if (!wave_done) {
+			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
+			// candidate) is one ballot; the slow path is fully predicated -- no per-lane branches.
+			const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+			for (int i = 0; i < n_u; i++) {
+				const int j = __builtin_amdgcn_readfirstlane((int)st.list[wave][i]);
+				const float4 q0 = st.q0[j];                                            // x, y, conic a, conic b
+				const float2 ct = *reinterpret_cast<const float2*>(&st.q1[j]);          // conic c, power cut
+				const float dx = q0.x - pixfx;
+				const float dy = q0.y - pixfy;
+				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
+				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
+				const bool cand = !done && !(power > 0.0f) && !(power < ct.y);
+				if (__ballot(cand) == 0ull) continue;
+				const float2 od = *(reinterpret_cast<const float2*>(&st.q1[j]) + 1);      // opacity, depth
+				const float4 q2 = st.q2[j];
+				const float alpha = fminf(0.99f, od.x * bsr_expf_nonpos(power));
+				const bool c2 = cand && !(alpha < 1.0f / 255.0f);
+				const float test_T = T * (1 - alpha);
+				const bool stop = c2 && (test_T < 0.0001f);
+				const bool blend = c2 && !stop;
+				const float n0 = C0 + q2.x * alpha * T;
+				const float n1 = C1 + q2.y * alpha * T;
+				const float n2 = C2 + q2.z * alpha * T;
+				const float nd = D + od.y * alpha * T;
+				const float na = acc + alpha * T;
+				C0 = blend ? n0 : C0;
+				C1 = blend ? n1 : C1;
+				C2 = blend ? n2 : C2;
+				D = blend ? nd : D;
+				acc = blend ? na : acc;
+				T = blend ? test_T : T;
+				last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
+				done = done || stop;
+				if (__ballot(stop) != 0ull) {
+					if (__ballot(!done) == 0ull) break;
+				}
 			}
-			const float4 q2 = s_q2[j];
-			C0 += q2.x * alpha * T;
-			C1 += q2.y * alpha * T;
-			C2 += q2.z * alpha * T;
-			D += od.y * alpha * T;
-			acc += alpha * T;
-			T = test_T;
-			last_contributor = (uint32_t)(base + j + 1);
 		}
 	}
 

@@ -1,0 +1,93 @@
+// Pieces shared by the forward and backward tile renderers: the conservative quadrant test and
+// the ballot/prefix-scan compaction of a staged batch into one ordered list per wave.
+#pragma once
+#include "common.h"
+
+namespace bsr {
+
+// Can the splat reach alpha >= 1/255 at ANY point of the axis-aligned box of pixel centres
+// [bx, bx+7] x [by, by+7]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
+// d = centre - pixel.  For a positive-definite conic q is convex, so its minimum over the box is 0
+// if the centre lies inside and otherwise sits on one of the four edges, where it is a clamped 1-D
+// parabola minimum.  The splat is kept iff  -qmin >= power_cut - slack  (power_cut already carries
+// a margin; the extra slack covers the rounding of this test).  Anything not provably a miss --
+// non-PD conics, NaNs -- is kept, so the per-pixel decisions downstream stay exact.
+__device__ __forceinline__ bool quad_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
+                                             float rb_a, bool pd, float bx, float by)
+{
+	const float dx_lo = X - (bx + 7.0f), dx_hi = X - bx;
+	const float dy_lo = Y - (by + 7.0f), dy_hi = Y - by;
+	const bool in_x = (dx_lo <= 0.0f) && (dx_hi >= 0.0f);
+	const bool in_y = (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
+	float qmin = 0.0f;
+	if (!(in_x && in_y)) {
+		// edges dx = const
+		float dy0 = fminf(fmaxf(rb_c * dx_lo, dy_lo), dy_hi);
+		float q0 = 0.5f * (a * dx_lo * dx_lo + c * dy0 * dy0) + b * dx_lo * dy0;
+		float dy1 = fminf(fmaxf(rb_c * dx_hi, dy_lo), dy_hi);
+		float q1 = 0.5f * (a * dx_hi * dx_hi + c * dy1 * dy1) + b * dx_hi * dy1;
+		// edges dy = const
+		float dx2 = fminf(fmaxf(rb_a * dy_lo, dx_lo), dx_hi);
+		float q2 = 0.5f * (a * dx2 * dx2 + c * dy_lo * dy_lo) + b * dx2 * dy_lo;
+		float dx3 = fminf(fmaxf(rb_a * dy_hi, dx_lo), dx_hi);
+		float q3 = 0.5f * (a * dx3 * dx3 + c * dy_hi * dy_hi) + b * dx3 * dy_hi;
+		qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+	}
+	const float slack = 1.0e-3f + 1.0e-4f * fabsf(cut);
+	const bool miss = pd && (-qmin < cut - slack);
+	return !miss;
+}
+
+// Staged batch of up to 256 list entries + per-wave (= per 8x8 quadrant) compacted index lists.
+struct TileStage {
+	float4 q0[BSR_BLOCK];            // x, y, conic a, conic b
+	float4 q1[BSR_BLOCK];            // conic c, power cut, opacity, depth
+	float4 q2[BSR_BLOCK];            // r, g, b, -
+	unsigned short list[4][BSR_BLOCK];
+	unsigned int cnt[4][4];          // [staging wave][quadrant]
+};
+
+// Thread `tid` holds the record of batch entry `tid` (valid iff tid < cnt).  Writes the record
+// to LDS and appends tid to the list of every quadrant it may touch, preserving list order
+// (64-bit ballots + prefix popcounts inside a wave, a 4x4 count table across waves).
+// On return (after the trailing barrier) st.list[q][0 .. total[q]) is ready; returns total[wave].
+__device__ __forceinline__ int stage_and_compact(TileStage& st, int tid, bool valid, const float4 r0, const float4 r1,
+                                                 const float4 r2, float tile_x0, float tile_y0)
+{
+	const int wave = tid >> 6, lane = tid & 63;
+	bool h[4] = {false, false, false, false};
+	if (valid) {
+		st.q0[tid] = r0;
+		st.q1[tid] = r1;
+		st.q2[tid] = r2;
+		const float a = r0.z, b = r0.w, c = r1.x;
+		const bool pd = (a > 0.0f) && (c > 0.0f) && (a * c - b * b > 0.0f);
+		const float rb_c = -b / c, rb_a = -b / a;
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			h[q] = quad_may_hit(r0.x, r0.y, a, b, c, r1.y, rb_c, rb_a, pd, tile_x0 + (float)((q & 1) << 3),
+			                    tile_y0 + (float)((q >> 1) << 3));
+	}
+	unsigned long long m[4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) m[q] = __ballot(h[q]);
+	if (lane == 0) {
+#pragma unroll
+		for (int q = 0; q < 4; q++) st.cnt[wave][q] = (unsigned int)__popcll(m[q]);
+	}
+	__syncthreads();
+	const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		if (h[q]) {
+			unsigned int off = 0;
+			for (int w = 0; w < wave; w++) off += st.cnt[w][q];
+			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned short)tid;
+		}
+	}
+	const int total = (int)(st.cnt[0][wave] + st.cnt[1][wave] + st.cnt[2][wave] + st.cnt[3][wave]);
+	__syncthreads();
+	return total;
+}
+
+}  // namespace bsr
