@@ -10,8 +10,9 @@
 // global float atomics run ~17x below the contiguous rate (~20 G/s chip-wide), which would cap this
 // kernel at ~2 ms for C3.  Instead NO global atomic is issued at all:
 //   * the 9 partials are summed over the wave's 64 pixels with DPP row operations (hand
-//     interleaved so no DPP hazard nops are needed) down to four row sums,
-//   * the row sums of the tile's 4 waves are combined with native LDS float atomics,
+//     interleaved so no DPP hazard nops are needed),
+//   * each wave stores its sums in its own LDS slot (LDS float atomics cost ~16 cycles each on
+//     gfx950 whatever the exec mask); the 4 slots are added in a fixed order at the batch end,
 //   * each instance's 9 sums are written ONCE, coalesced, to a slab row [R][12] (48 B),
 //   * k_preprocess_bwd later gathers the rows of each Gaussian through an instance->slot map
 //     (written here while staging) and adds them in a fixed order.
@@ -34,17 +35,31 @@ namespace bsr {
 	"v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
 	"v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
 
-__device__ __forceinline__ void row_sums9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
-                                          float& v7, float& v8)
+// The last two steps add lane 15 of the previous row (row_bcast15, rows 1 and 3) and lane 31
+// (row_bcast31, rows 2 and 3) in place: rows masked off by row_mask keep their value.
+#define BSR_DPP9M(ctrl, rmask)                                            \
+	"v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
+	"v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:" rmask " bank_mask:0xf\n"
+
+// Sum of each of the 9 values over the 64 lanes; valid in lane 63 on return.
+__device__ __forceinline__ void wave_sums9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
+                                           float& v7, float& v8)
 {
 	asm volatile("s_nop 1\n" BSR_DPP9("quad_perm:[1,0,3,2]") BSR_DPP9("quad_perm:[2,3,0,1]") BSR_DPP9("row_half_mirror")
-	                 BSR_DPP9("row_mirror")
+	                 BSR_DPP9("row_mirror") BSR_DPP9M("row_bcast:15", "0xa") BSR_DPP9M("row_bcast:31", "0xc")
 	             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
 struct BwdShared {
 	TileStage st;
-	float acc[9][BSR_BLOCK];
+	float part[4][9][BSR_BLOCK];   // per-wave partial sums of the current batch (plain stores)
 	uint32_t max_contrib[4];
 };
 
@@ -89,8 +104,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		dpx1 = dL_dpixels[plane + pix_id];
 		dpx2 = dL_dpixels[2 * plane + pix_id];
 	}
-	float last_alpha = 0.f;
-	float last_c0 = 0.f, last_c1 = 0.f, last_c2 = 0.f;
 	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
 	const float ddelx_dx = (float)(0.5 * W);
 	const float ddely_dy = (float)(0.5 * H);
@@ -102,7 +115,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
 	if (lane == 0) sh.max_contrib[wave] = m;
 #pragma unroll
-	for (int k = 0; k < 9; k++) sh.acc[k][tid] = 0.f;
+	for (int w = 0; w < 4; w++)
+#pragma unroll
+		for (int k = 0; k < 9; k++) sh.part[w][k][tid] = 0.f;
 	__syncthreads();
 	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
 
@@ -141,67 +156,76 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 
 			// slow path: fully predicated
 			const float4 q2 = sh.st.q2[j];
-			const float G = bsr_expf_nonpos(power);
-			const float alpha = fminf(0.99f, q1.z * G);
-			const bool active = cand && !(alpha < 1.0f / 255.0f);
+			const float Graw = bsr_expf_nonpos(power);      // same pinned exp as the forward: identical decisions
+			const float alpha_raw = fminf(0.99f, q1.z * Graw);
+			const bool active = cand && !(alpha_raw < 1.0f / 255.0f);
 			if (__ballot(active) == 0ull) continue;
-
-			const float Tn = T / (1.f - alpha);
-			const float dchannel_dcolor = alpha * Tn;
-			float dL_dalpha = 0.0f;
-			const float ar0 = last_alpha * last_c0 + (1.f - last_alpha) * accum_rec0;
-			dL_dalpha += (q2.x - ar0) * dpx0;
-			const float ar1 = last_alpha * last_c1 + (1.f - last_alpha) * accum_rec1;
-			dL_dalpha += (q2.y - ar1) * dpx1;
-			const float ar2 = last_alpha * last_c2 + (1.f - last_alpha) * accum_rec2;
-			dL_dalpha += (q2.z - ar2) * dpx2;
-			dL_dalpha *= Tn;
-			dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+			// Inactive lanes take alpha = 0, G = 0: every recurrence below then leaves their state
+			// unchanged (T/(1-0) = T, 0*c + 1*acc = acc) and all nine contributions are exactly 0.
+			const float alpha = active ? alpha_raw : 0.f;
+			const float G = active ? Graw : 0.f;
+			// 1/(1-alpha) by reciprocal + one Newton step (<= 1 ulp).  The reference divides twice
+			// (:521,:557); gradients are compared with a tolerance, not bitwise, so the exact IEEE
+			// quotient (11 instructions each) is not needed here.
+			const float om = 1.f - alpha;
+			float inv = __builtin_amdgcn_rcpf(om);
+			inv = __builtin_fmaf(__builtin_fmaf(-om, inv, 1.0f), inv, inv);
+			T = T * inv;
+			const float dchannel_dcolor = alpha * T;
+			// accum_rec is folded eagerly: acc' = alpha*c + (1-alpha)*acc is exactly what the reference
+			// computes lazily at the next processed entry (:529), so no last_alpha/last_color state.
+			float dL_dalpha = (q2.x - accum_rec0) * dpx0;
+			dL_dalpha += (q2.y - accum_rec1) * dpx1;
+			dL_dalpha += (q2.z - accum_rec2) * dpx2;
+			accum_rec0 = alpha * q2.x + om * accum_rec0;
+			accum_rec1 = alpha * q2.y + om * accum_rec1;
+			accum_rec2 = alpha * q2.z + om * accum_rec2;
+			dL_dalpha *= T;
+			dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
+			dL_dalpha = active ? dL_dalpha : 0.f;
 			const float dL_dG = q1.z * dL_dalpha;
 			const float gdx = G * dx;
 			const float gdy = G * dy;
 			const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
 			const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-			float v0 = active ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-			float v1 = active ? dL_dG * dG_ddely * ddely_dy : 0.f;
-			float v2 = active ? -0.5f * gdx * dx * dL_dG : 0.f;
-			float v3 = active ? -0.5f * gdx * dy * dL_dG : 0.f;
-			float v4 = active ? -0.5f * gdy * dy * dL_dG : 0.f;
-			float v5 = active ? G * dL_dalpha : 0.f;
-			float v6 = active ? dchannel_dcolor * dpx0 : 0.f;
-			float v7 = active ? dchannel_dcolor * dpx1 : 0.f;
-			float v8 = active ? dchannel_dcolor * dpx2 : 0.f;
-			// per-pixel recurrences (reference :522-556)
-			T = active ? Tn : T;
-			accum_rec0 = active ? ar0 : accum_rec0;
-			accum_rec1 = active ? ar1 : accum_rec1;
-			accum_rec2 = active ? ar2 : accum_rec2;
-			last_c0 = active ? q2.x : last_c0;
-			last_c1 = active ? q2.y : last_c1;
-			last_c2 = active ? q2.z : last_c2;
-			last_alpha = active ? alpha : last_alpha;
+			float v0 = dL_dG * dG_ddelx * ddelx_dx;
+			float v1 = dL_dG * dG_ddely * ddely_dy;
+			float v2 = -0.5f * gdx * dx * dL_dG;
+			float v3 = -0.5f * gdx * dy * dL_dG;
+			float v4 = -0.5f * gdy * dy * dL_dG;
+			float v5 = G * dL_dalpha;
+			float v6 = dchannel_dcolor * dpx0;
+			float v7 = dchannel_dcolor * dpx1;
+			float v8 = dchannel_dcolor * dpx2;
 
-			row_sums9(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-			if ((lane & 15) == 15) {   // one lane per row of 16: 4 LDS atomics per component and wave
-				atomicAdd(&sh.acc[0][j], v0);
-				atomicAdd(&sh.acc[1][j], v1);
-				atomicAdd(&sh.acc[2][j], v2);
-				atomicAdd(&sh.acc[3][j], v3);
-				atomicAdd(&sh.acc[4][j], v4);
-				atomicAdd(&sh.acc[5][j], v5);
-				atomicAdd(&sh.acc[6][j], v6);
-				atomicAdd(&sh.acc[7][j], v7);
-				atomicAdd(&sh.acc[8][j], v8);
+			wave_sums9(v0, v1, v2, v3, v4, v5, v6, v7, v8);
+			if (lane == 63) {   // each list entry is visited once per wave: plain stores, no LDS atomics
+				sh.part[wave][0][j] = v0;
+				sh.part[wave][1][j] = v1;
+				sh.part[wave][2][j] = v2;
+				sh.part[wave][3][j] = v3;
+				sh.part[wave][4][j] = v4;
+				sh.part[wave][5][j] = v5;
+				sh.part[wave][6][j] = v6;
+				sh.part[wave][7][j] = v7;
+				sh.part[wave][8][j] = v8;
 			}
 		}
 		__syncthreads();
 		if (valid) {
-			float4* row = slab + (size_t)my_slot * 3;
-			row[0] = make_float4(sh.acc[0][tid], sh.acc[1][tid], sh.acc[2][tid], sh.acc[3][tid]);
-			row[1] = make_float4(sh.acc[4][tid], sh.acc[5][tid], sh.acc[6][tid], sh.acc[7][tid]);
-			row[2] = make_float4(sh.acc[8][tid], 0.f, 0.f, 0.f);
+			float a9[9];
 #pragma unroll
-			for (int k = 0; k < 9; k++) sh.acc[k][tid] = 0.f;
+			for (int k = 0; k < 9; k++) {   // fixed order over the 4 quadrants -> deterministic
+				a9[k] = ((sh.part[0][k][tid] + sh.part[1][k][tid]) + sh.part[2][k][tid]) + sh.part[3][k][tid];
+				sh.part[0][k][tid] = 0.f;
+				sh.part[1][k][tid] = 0.f;
+				sh.part[2][k][tid] = 0.f;
+				sh.part[3][k][tid] = 0.f;
+			}
+			float4* row = slab + (size_t)my_slot * 3;
+			row[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
+			row[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+			row[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
 		}
 		__syncthreads();
 	}

@@ -80,8 +80,8 @@ __device__ __forceinline__ int stage_and_compact(TileStage& st, int tid, bool va
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		if (h[q]) {
-			unsigned int off = 0;
-			for (int w = 0; w < wave; w++) off += st.cnt[w][q];
+			const unsigned int off = (wave > 0 ? st.cnt[0][q] : 0u) + (wave > 1 ? st.cnt[1][q] : 0u) +
+			                         (wave > 2 ? st.cnt[2][q] : 0u);
 			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned short)tid;
 		}
 	}
