@@ -136,7 +136,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    _capi.profile_enable(True)
+    _capi.profile_enable(os.environ.get("BSR_BENCH_NO_STAGE_EVENTS") != "1")
     _capi.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -134,13 +134,54 @@ static int ensure_pool_keeps_memory()
 // ---------------------------------------------------------------- stage profiler (bench only)
 struct StageRec {
 	const char* name;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;   // pending (recorded, not yet read) pairs, oldest first
+	size_t head = 0;
 	double total_ms = 0;
 	int launches = 0;
 };
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
 static std::vector<StageRec> g_stages;
+static std::vector<hipEvent_t> g_free_events;   // recycled events (creating thousands of events is slow)
+
+// Fold every pair whose end event has completed into the totals and recycle its events.
+// wait == true blocks on unfinished ones (used by bsr_profile_read).
+static void drain_stage(StageRec& r, bool wait)
+{
+	while (r.head < r.ev.size()) {
+		auto& p = r.ev[r.head];
+		if (wait) {
+			if (hipEventSynchronize(p.second) != hipSuccess) break;
+		} else if (hipEventQuery(p.second) != hipSuccess) {
+			(void)hipGetLastError();   // hipErrorNotReady is not an error
+			break;
+		}
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+			r.total_ms += ms;
+			r.launches++;
+		}
+		g_free_events.push_back(p.first);
+		g_free_events.push_back(p.second);
+		r.head++;
+	}
+	if (r.head == r.ev.size()) {
+		r.ev.clear();
+		r.head = 0;
+	}
+}
+
+static hipEvent_t take_event()
+{
+	if (!g_free_events.empty()) {
+		hipEvent_t e = g_free_events.back();
+		g_free_events.pop_back();
+		return e;
+	}
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
 
 struct StageTimer {
 	hipStream_t s;
@@ -158,7 +199,10 @@ struct StageTimer {
 			g_stages.push_back(StageRec{name});
 			rec = &g_stages.back();
 		}
-		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rec = nullptr; return; }
+		if (rec->ev.size() - rec->head >= 8) drain_stage(*rec, false);
+		e0 = take_event();
+		e1 = take_event();
+		if (!e0 || !e1) { rec = nullptr; return; }
 		(void)hipEventRecord(e0, s);
 	}
 	~StageTimer()
@@ -193,8 +237,7 @@ int bsr_profile_reset(void)
 {
 	std::lock_guard<std::mutex> lk(g_prof_mu);
 	for (auto& r : g_stages) {
-		for (auto& p : r.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-		r.ev.clear();
+		drain_stage(r, true);
 		r.total_ms = 0;
 		r.launches = 0;
 	}
@@ -206,16 +249,7 @@ int bsr_profile_read(bsr_stage_profile* out, int max_stages)
 	std::lock_guard<std::mutex> lk(g_prof_mu);
 	int n = 0;
 	for (auto& r : g_stages) {
-		for (auto& p : r.ev) {
-			float ms = 0;
-			if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
-				r.total_ms += ms;
-				r.launches++;
-			}
-			(void)hipEventDestroy(p.first);
-			(void)hipEventDestroy(p.second);
-		}
-		r.ev.clear();
+		drain_stage(r, true);
 		if (n < max_stages) {
 			out[n].name = r.name;
 			out[n].total_ms = r.total_ms;

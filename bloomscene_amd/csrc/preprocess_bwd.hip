@@ -14,23 +14,41 @@
 namespace bsr {
 
 
-__device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, const float* v, int n_valid)
+// Store the N = 3*(DEG+1)^2 computed coefficient gradients of one Gaussian (compile-time register
+// indices, so the array never goes to scratch memory) and zero the remaining 3*M - N floats.
+template <int N>
+__device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, const float* v)
 {
-	// dst: 3*M floats of this Gaussian; v holds n_valid floats, the rest are zero.
+	const int total = M * 3;
+	if ((M & 3) == 0) {   // 12*M bytes: the block is 16-B aligned and a whole number of float4
+		float4* d4 = reinterpret_cast<float4*>(dst);
+		constexpr int NV = (N + 3) / 4;
+#pragma unroll
+		for (int i = 0; i < NV; i++) {
+			float4 o;
+			o.x = (i * 4 + 0 < N) ? v[i * 4 + 0] : 0.f;
+			o.y = (i * 4 + 1 < N) ? v[i * 4 + 1] : 0.f;
+			o.z = (i * 4 + 2 < N) ? v[i * 4 + 2] : 0.f;
+			o.w = (i * 4 + 3 < N) ? v[i * 4 + 3] : 0.f;
+			if (i * 4 < total) d4[i] = o;
+		}
+		for (int i = NV; i < (total >> 2); i++) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	} else {
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			if (i < total) dst[i] = v[i];
+		for (int i = N; i < total; i++) dst[i] = 0.f;
+	}
+}
+
+__device__ __forceinline__ void zero_sh_grad(float* __restrict__ dst, int M)
+{
+	const int total = M * 3;
 	if ((M & 3) == 0) {
 		float4* d4 = reinterpret_cast<float4*>(dst);
-		const int nv = (M * 3) >> 2;
-#pragma unroll 12
-		for (int i = 0; i < nv; i++) {
-			float4 o;
-			o.x = (i * 4 + 0 < n_valid) ? v[i * 4 + 0] : 0.f;
-			o.y = (i * 4 + 1 < n_valid) ? v[i * 4 + 1] : 0.f;
-			o.z = (i * 4 + 2 < n_valid) ? v[i * 4 + 2] : 0.f;
-			o.w = (i * 4 + 3 < n_valid) ? v[i * 4 + 3] : 0.f;
-			d4[i] = o;
-		}
+		for (int i = 0; i < (total >> 2); i++) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 	} else {
-		for (int i = 0; i < M * 3; i++) dst[i] = (i < n_valid) ? v[i] : 0.f;
+		for (int i = 0; i < total; i++) dst[i] = 0.f;
 	}
 }
 
@@ -38,8 +56,6 @@ template <int DEG>
 __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const float3 m, const float* dcolor, float* dmean)
 {
 	constexpr int NC = (DEG + 1) * (DEG + 1);
-	float c[NC * 3];
-	load_sh<NC>(a.shs + (size_t)idx * a.M * 3, a.M, c);
 	const float ox = m.x - a.campos[0], oy = m.y - a.campos[1], oz = m.z - a.campos[2];
 	const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
 	const float x = ox / len, y = oy / len, z = oz / len;
@@ -48,10 +64,18 @@ __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const floa
 	dL_dRGB[0] *= (cl & 1) ? 0.f : 1.f;
 	dL_dRGB[1] *= (cl & 2) ? 0.f : 1.f;
 	dL_dRGB[2] *= (cl & 4) ? 0.f : 1.f;
-	float dsh[NC * 3];
+	{   // phase 1: coefficient gradients out to HBM before the coefficients come in
+		float dsh[NC * 3];
+		sh_coef_grad<DEG>(x, y, z, dL_dRGB, dsh);
+		store_sh_grad<NC * 3>(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh);
+	}
+	__builtin_amdgcn_sched_barrier(0);
 	float dL_ddir[3];
-	sh_backward<DEG>(c, x, y, z, dL_dRGB, dsh, dL_ddir);
-	store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, NC * 3);
+	{   // phase 2: view-direction gradient needs the coefficients
+		float c[NC * 3];
+		load_sh<NC>(a.shs + (size_t)idx * a.M * 3, a.M, c);
+		sh_dir_grad<DEG>(c, x, y, z, dL_dRGB, dL_ddir);
+	}
 	// dnormvdv(dir_orig, dL_ddir), reference auxiliary.h:107-117
 	const float sum2 = ox * ox + oy * oy + oz * oz;
 	const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
@@ -60,7 +84,7 @@ __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const floa
 	dmean[2] += (-ox * oz * dL_ddir[0] - oy * oz * dL_ddir[1] + (sum2 - oz * oz) * dL_ddir[2]) * invsum32;
 }
 
-__global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
+__global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= a.P) return;
@@ -234,8 +258,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(const BwdArgs a)
 			drot[3] = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
 		}
 	} else if (a.shs && a.dL_dsh) {
-		const float zero = 0.f;
-		store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, &zero, 0);
+		zero_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M);
 	}
 
 	a.dL_dmean3D[3 * idx] = dmean[0];

@@ -99,14 +99,13 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float3 pos, cons
 	}
 }
 
-// backward (reference backward.cu:20-139): writes dL_dsh[0..(DEG+1)^2) (remaining coefficients,
-// if M is larger, are zeroed by the caller) and returns dL_ddir = (dRGBdx.dL, dRGBdy.dL, dRGBdz.dL).
+// backward (reference backward.cu:20-139), split in two so that the 3*(DEG+1)^2 coefficient
+// gradients and the 3*(DEG+1)^2 coefficients are never live in registers at the same time:
+//  sh_coef_grad: dL_dsh[k] = basis_k(dir) * dL_dRGB   (needs no coefficients)
+//  sh_dir_grad : dL_ddir = (dRGBdx.dL_dRGB, dRGBdy.dL_dRGB, dRGBdz.dL_dRGB)
 template <int DEG>
-__device__ __forceinline__ void sh_backward(const float* c, float x, float y, float z, const float* dL_dRGB,
-                                            float* dsh /* [(DEG+1)^2*3] */, float* dL_ddir)
+__device__ __forceinline__ void sh_coef_grad(float x, float y, float z, const float* dL_dRGB, float* dsh)
 {
-	float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
-#define SH(k) c[(k) * 3 + ch]
 #define DSH(k, v)                                                    \
 	do {                                                             \
 		const float _v = (v);                                        \
@@ -117,6 +116,35 @@ __device__ __forceinline__ void sh_backward(const float* c, float x, float y, fl
 		DSH(1, -SH_C1 * y);
 		DSH(2, SH_C1 * z);
 		DSH(3, -SH_C1 * x);
+		if (DEG > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			DSH(4, SH_C2[0] * xy);
+			DSH(5, SH_C2[1] * yz);
+			DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
+			DSH(7, SH_C2[3] * xz);
+			DSH(8, SH_C2[4] * (xx - yy));
+			if (DEG > 2) {
+				DSH(9, SH_C3[0] * y * (3.f * xx - yy));
+				DSH(10, SH_C3[1] * xy * z);
+				DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
+				DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+				DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
+				DSH(14, SH_C3[5] * z * (xx - yy));
+				DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
+			}
+		}
+	}
+#undef DSH
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_dir_grad(const float* c, float x, float y, float z, const float* dL_dRGB,
+                                            float* dL_ddir)
+{
+	float dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+#define SH(k) c[(k) * 3 + ch]
+	if (DEG > 0) {
 #pragma unroll
 		for (int ch = 0; ch < 3; ch++) {
 			dRGBdx[ch] = -SH_C1 * SH(3);
@@ -126,11 +154,6 @@ __device__ __forceinline__ void sh_backward(const float* c, float x, float y, fl
 		if (DEG > 1) {
 			const float xx = x * x, yy = y * y, zz = z * z;
 			const float xy = x * y, yz = y * z, xz = x * z;
-			DSH(4, SH_C2[0] * xy);
-			DSH(5, SH_C2[1] * yz);
-			DSH(6, SH_C2[2] * (2.f * zz - xx - yy));
-			DSH(7, SH_C2[3] * xz);
-			DSH(8, SH_C2[4] * (xx - yy));
 #pragma unroll
 			for (int ch = 0; ch < 3; ch++) {
 				dRGBdx[ch] += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
@@ -138,13 +161,6 @@ __device__ __forceinline__ void sh_backward(const float* c, float x, float y, fl
 				dRGBdz[ch] += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
 			}
 			if (DEG > 2) {
-				DSH(9, SH_C3[0] * y * (3.f * xx - yy));
-				DSH(10, SH_C3[1] * xy * z);
-				DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy));
-				DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-				DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy));
-				DSH(14, SH_C3[5] * z * (xx - yy));
-				DSH(15, SH_C3[6] * x * (xx - 3.f * yy));
 #pragma unroll
 				for (int ch = 0; ch < 3; ch++) {
 					dRGBdx[ch] += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz +
@@ -163,7 +179,6 @@ __device__ __forceinline__ void sh_backward(const float* c, float x, float y, fl
 		}
 	}
 #undef SH
-#undef DSH
 	dL_ddir[0] = (dRGBdx[0] * dL_dRGB[0] + dRGBdx[1] * dL_dRGB[1]) + dRGBdx[2] * dL_dRGB[2];
 	dL_ddir[1] = (dRGBdy[0] * dL_dRGB[0] + dRGBdy[1] * dL_dRGB[1]) + dRGBdy[2] * dL_dRGB[2];
 	dL_ddir[2] = (dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1]) + dRGBdz[2] * dL_dRGB[2];
