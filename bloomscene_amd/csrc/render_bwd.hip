@@ -57,6 +57,47 @@ __device__ __forceinline__ void wave_sums9(float& v0, float& v1, float& v2, floa
 	             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
 }
 
+// ---- butterfly reduction of 9 values over the 64 lanes -------------------------------------
+// Instead of nine independent 6-step reductions (54 cross-lane adds) the values are split between
+// partner lanes at every step, halving the live set: 8 -> 4 -> 2 -> 1 value per lane over the steps
+// lane^1, lane^2, lane+-4, while the ninth value rides on the lanes that step 4 (lane+-8) frees up.
+// After two row swaps every lane holds the 64-lane total of component comp(lane):
+//   lane&8 == 0 :  4*(lane&1) + 2*((lane>>1)&1) + ((lane>>2)&1)      (components 0..7)
+//   lane&8 != 0 :  8
+// 33 VALU instructions instead of 54; one 9-lane LDS store instead of nine 1-lane stores.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float x2, float x3, float x4, float x5,
+                                                      float x6, float x7, float x8, int lane)
+{
+	const bool b1 = (lane & 1) != 0, b2 = (lane & 2) != 0, b4 = (lane & 4) != 0, b8 = (lane & 8) != 0;
+	// step lane^1 (quad_perm [1,0,3,2]): even lanes keep 0..3, odd lanes keep 4..7
+	const float a0 = (b1 ? x4 : x0) + dpp_mov<0xB1>(b1 ? x0 : x4);
+	const float a1 = (b1 ? x5 : x1) + dpp_mov<0xB1>(b1 ? x1 : x5);
+	const float a2 = (b1 ? x6 : x2) + dpp_mov<0xB1>(b1 ? x2 : x6);
+	const float a3 = (b1 ? x7 : x3) + dpp_mov<0xB1>(b1 ? x3 : x7);
+	float y = x8 + dpp_mov<0xB1>(x8);
+	// step lane^2 (quad_perm [2,3,0,1])
+	const float c0 = (b2 ? a2 : a0) + dpp_mov<0x4E>(b2 ? a0 : a2);
+	const float c1 = (b2 ? a3 : a1) + dpp_mov<0x4E>(b2 ? a1 : a3);
+	y = y + dpp_mov<0x4E>(y);
+	// step lane+-4 (row_ror:4: the source lane has the opposite bit 2 and the same low bits)
+	float d = (b4 ? c1 : c0) + dpp_mov<0x124>(b4 ? c0 : c1);
+	y = y + dpp_mov<0x124>(y);
+	// step lane+-8 (row_ror:8): lanes 0..7 of a row take the row total of their component,
+	// lanes 8..15 the row total of the ninth value
+	d = (b8 ? y : d) + dpp_mov<0x128>(b8 ? d : y);
+	// rows 0+1 / 2+3, then halves
+	auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+	d = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+	auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 struct BwdShared {
 	TileStage st;
 	float part[4][9][BSR_BLOCK];   // per-wave partial sums of the current batch (plain stores)
@@ -105,6 +146,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		dpx2 = dL_dpixels[2 * plane + pix_id];
 	}
 	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
+	const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;
+	// component whose wave total lands in this lane after wave_sums9_butterfly (lanes 0..8 store)
+	const int comp_of_lane = (lane & 8) ? 8 : (((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1));
+	float* const part_mine = &sh.part[wave][comp_of_lane][0];
 	const float ddelx_dx = (float)(0.5 * W);
 	const float ddely_dy = (float)(0.5 * H);
 
@@ -161,55 +206,49 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const bool active = cand && !(alpha_raw < 1.0f / 255.0f);
 			if (__ballot(active) == 0ull) continue;
 			// Inactive lanes take alpha = 0, G = 0: every recurrence below then leaves their state
-			// unchanged (T/(1-0) = T, 0*c + 1*acc = acc) and all nine contributions are exactly 0.
+			// unchanged (T*1 = T, acc + 0*(c-acc) = acc) and all nine contributions are exactly 0.
 			const float alpha = active ? alpha_raw : 0.f;
 			const float G = active ? Graw : 0.f;
-			// 1/(1-alpha) by reciprocal + one Newton step (<= 1 ulp).  The reference divides twice
-			// (:521,:557); gradients are compared with a tolerance, not bitwise, so the exact IEEE
-			// quotient (11 instructions each) is not needed here.
-			const float om = 1.f - alpha;
-			float inv = __builtin_amdgcn_rcpf(om);
-			inv = __builtin_fmaf(__builtin_fmaf(-om, inv, 1.0f), inv, inv);
-			T = T * inv;
-			const float dchannel_dcolor = alpha * T;
-			// accum_rec is folded eagerly: acc' = alpha*c + (1-alpha)*acc is exactly what the reference
-			// computes lazily at the next processed entry (:529), so no last_alpha/last_color state.
-			float dL_dalpha = (q2.x - accum_rec0) * dpx0;
-			dL_dalpha += (q2.y - accum_rec1) * dpx1;
-			dL_dalpha += (q2.z - accum_rec2) * dpx2;
-			accum_rec0 = alpha * q2.x + om * accum_rec0;
-			accum_rec1 = alpha * q2.y + om * accum_rec1;
-			accum_rec2 = alpha * q2.z + om * accum_rec2;
-			dL_dalpha *= T;
-			dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-			dL_dalpha = active ? dL_dalpha : 0.f;
-			const float dL_dG = q1.z * dL_dalpha;
-			const float gdx = G * dx;
-			const float gdy = G * dy;
-			const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-			const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-			float v0 = dL_dG * dG_ddelx * ddelx_dx;
-			float v1 = dL_dG * dG_ddely * ddely_dy;
-			float v2 = -0.5f * gdx * dx * dL_dG;
-			float v3 = -0.5f * gdx * dy * dL_dG;
-			float v4 = -0.5f * gdy * dy * dL_dG;
-			float v5 = G * dL_dalpha;
-			float v6 = dchannel_dcolor * dpx0;
-			float v7 = dchannel_dcolor * dpx1;
-			float v8 = dchannel_dcolor * dpx2;
-
-			wave_sums9(v0, v1, v2, v3, v4, v5, v6, v7, v8);
-			if (lane == 63) {   // each list entry is visited once per wave: plain stores, no LDS atomics
-				sh.part[wave][0][j] = v0;
-				sh.part[wave][1][j] = v1;
-				sh.part[wave][2][j] = v2;
-				sh.part[wave][3][j] = v3;
-				sh.part[wave][4][j] = v4;
-				sh.part[wave][5][j] = v5;
-				sh.part[wave][6][j] = v6;
-				sh.part[wave][7][j] = v7;
-				sh.part[wave][8][j] = v8;
+			float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+			{
+				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
+				// unordered), so this block may fuse multiply-adds and use a refined reciprocal
+				// instead of the reference's two IEEE divisions (:521,:557).
+#pragma clang fp contract(fast)
+				const float om = 1.f - alpha;
+				float inv = __builtin_amdgcn_rcpf(om);
+				inv = __builtin_fmaf(__builtin_fmaf(-om, inv, 1.0f), inv, inv);
+				// T/(1-alpha): quotient estimate + one residual correction = the correctly rounded quotient
+				// in all but rare cases, so the T chain (hundreds of steps in dense tiles) does not drift.
+				const float qT = T * inv;
+				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);
+				// accum_rec folded eagerly: acc' = alpha*c + (1-alpha)*acc is what the reference computes
+				// lazily at the next processed entry (:529); no last_alpha/last_color state is needed.
+				const float e0 = q2.x - accum_rec0, e1 = q2.y - accum_rec1, e2 = q2.z - accum_rec2;
+				const float S = e0 * dpx0 + e1 * dpx1 + e2 * dpx2;
+				accum_rec0 = accum_rec0 + alpha * e0;
+				accum_rec1 = accum_rec1 + alpha * e1;
+				accum_rec2 = accum_rec2 + alpha * e2;
+				float dL_dalpha = T * S + neg_Tfinal_bg * inv;
+				dL_dalpha = active ? dL_dalpha : 0.f;
+				const float gd = G * dL_dalpha;          // dL/dopacity term
+				const float w = q1.z * gd;               // G * dL_dG
+				const float h = -0.5f * w;
+				const float hx = h * dx, hy = h * dy;
+				const float wnx = -w * ddelx_dx, wny = -w * ddely_dy;
+				v0 = wnx * (q0.z * dx + q0.w * dy);
+				v1 = wny * (q1.x * dy + q0.w * dx);
+				v2 = hx * dx;
+				v3 = hx * dy;
+				v4 = hy * dy;
+				v5 = gd;
+				const float aT = alpha * T;
+				v6 = aT * dpx0;
+				v7 = aT * dpx1;
+				v8 = aT * dpx2;
 			}
+			const float tot = wave_sums9_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
+			if (lane < 9) part_mine[j] = tot;   // lane l holds component comp(l): one 9-lane store
 		}
 		__syncthreads();
 		if (valid) {
