@@ -5,7 +5,7 @@
 //   memset(tile_count) -> k_preprocess (project, cull, SH, count instances per tile)
 //   -> k_scan_tiles (tile ranges) -> 4-byte D2H read of R -> binning alloc
 //   -> k_scatter -> k_sort_tiles (per-tile LDS sort) -> k_render_fwd.
-// Backward (rasterizer_impl.cu:403-504): k_inst_offsets -> k_render_bwd (per-instance partial sums
+// Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums
 // to a slab, no global atomics) -> k_preprocess_bwd (gathers them per Gaussian, then the chain).
 #include "../../include/bloomscene_rast.h"
 #include "common.h"
@@ -22,7 +22,8 @@ namespace bsr {
 size_t GeomState::bytes(size_t P)
 {
 	size_t s = 0;
-	s += align_up(P * 3 * sizeof(float4), 256);
+	s += align_up(P * BSR_REC * sizeof(float4), 256);
+	s += align_up(P * sizeof(uint32_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * 6 * sizeof(float), 256);
 	s += align_up(P * sizeof(uint8_t), 256);
@@ -32,7 +33,8 @@ GeomState GeomState::carve(char* p, size_t P)
 {
 	GeomState g;
 	p = (char*)align_up((size_t)p, 256);
-	g.rec = (float4*)p;      p += align_up(P * 3 * sizeof(float4), 256);
+	g.rec = (float4*)p;      p += align_up(P * BSR_REC * sizeof(float4), 256);
+	g.inst_offset = (uint32_t*)p; p += align_up(P * sizeof(uint32_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
 	g.clamped = (uint8_t*)p;
@@ -78,11 +80,9 @@ void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uin
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
-void launch_inst_offsets(int P, const ushort4* rect, uint32_t* inst_offset, uint32_t* counter, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const ushort4* rect, const uint32_t* inst_offset, const float* bg,
-                       const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of,
-                       float4* slab, hipStream_t s);
+                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                       const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- errors
@@ -462,18 +462,14 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0));
 
 	// Backward-only scratch (stream-ordered, from the device's default memory pool):
-	//   inst_offset[P] u32 | counter | slot_of[R] u32 | slab[R][12] f32
+	//   slot_of[R] u32 | slab[R][12] f32
 	const size_t Rn = (size_t)(R > 0 ? R : 0);
-	const size_t off_counter = align_up((size_t)P * 4, 256);
-	const size_t off_slot = off_counter + 256;
-	const size_t off_slab = off_slot + align_up(Rn * 4, 256);
-	const size_t scratch_bytes = off_slab + align_up(Rn * 48, 256);
+	const size_t off_slab = align_up(Rn * 4, 256);
+	const size_t scratch_bytes = off_slab + align_up(Rn * 48, 256) + 256;
 	if (ensure_pool_keeps_memory()) return 1;
 	char* scratch = nullptr;
 	HIP_TRY(hipMallocAsync((void**)&scratch, scratch_bytes, s));
-	uint32_t* inst_offset = (uint32_t*)scratch;
-	uint32_t* counter = (uint32_t*)(scratch + off_counter);
-	uint32_t* slot_of = (uint32_t*)(scratch + off_slot);
+	uint32_t* slot_of = (uint32_t*)scratch;
 	float4* slab = (float4*)(scratch + off_slab);
 	struct ScratchFree {
 		char* p; hipStream_t s;
@@ -482,15 +478,9 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 
 	if (R > 0) {
 		{
-			StageTimer t("inst_offsets", s);
-			HIP_TRY(hipMemsetAsync(counter, 0, 4, s));
-			launch_inst_offsets(P, geom.rect, inst_offset, counter, s);
-		}
-		STAGE_CHECK("inst_offsets", debug, s);
-		{
 			StageTimer t("render_bwd", s);
-			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.rect, inst_offset,
-			                  background, img.final_T, img.n_contrib, dL_dpix, slot_of, slab, s);
+			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
+			                  img.n_contrib, dL_dpix, slot_of, slab, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}
@@ -503,7 +493,7 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	a.focal_y = height / (2.0f * tan_fovy);
 	a.focal_x = width / (2.0f * tan_fovx);
 	a.geom = geom;
-	a.inst_offset = inst_offset; a.slot_of = slot_of; a.slab = slab;
+	a.slot_of = slot_of; a.slab = slab;
 	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
 	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
 	{

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_scatter(int P, int gx, const ushort4* _
 	if (idx >= P) return;
 	const ushort4 r = rect[idx];
 	if (r.z <= r.x || r.w <= r.y) return;
-	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * 3 + 1].w);
+	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
 	const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++) {

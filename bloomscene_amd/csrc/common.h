@@ -12,10 +12,14 @@
 namespace bsr {
 
 // Private layout of the three scratch buffers (opaque to callers).
-// Per-Gaussian "splat record": everything the tile kernels gather per list entry, 48 B:
+// Per-Gaussian "splat record": everything the tile kernels gather per list entry, exactly one
+// 64-byte cache line:
 //   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, power_cut, opacity, depth)   q2 = (r, g, b, 0)
+//   q3 = bits(inst_offset, xmin | ymin << 16, xmax | ymax << 16, 0)     (backward only)
+#define BSR_REC 4
 struct GeomState {
-	float4* rec;        // [P][3]
+	float4* rec;        // [P][BSR_REC]
+	uint32_t* inst_offset;  // [P] start of the Gaussian's block of tile instances (Gaussian-major order)
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
 	float* cov3D;       // [P][6]
 	uint8_t* clamped;   // [P] bit ch = SH colour channel ch was clamped at 0
@@ -60,7 +64,7 @@ struct PreArgs {
 	int* radii;          // may be NULL
 	GeomState geom;
 	uint32_t* tile_count;
-	int* flags;
+	int* flags;            // [0] prefiltered violation, [1] running total of tile instances
 };
 
 struct BwdArgs {
@@ -77,7 +81,6 @@ struct BwdArgs {
 	const float* campos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	GeomState geom;
-	const uint32_t* inst_offset;   // [P]  start of the Gaussian's block in slot_of
 	const uint32_t* slot_of;       // [R]  list slot of the k-th tile instance of each Gaussian
 	const float4* slab;            // [R][3] per-instance partial sums written by k_render_bwd
 	float* dL_dmean2D;         // [P,3]  (outputs; fully written)

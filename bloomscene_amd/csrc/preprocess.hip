@@ -96,17 +96,19 @@ template <bool FILTER_ONLY>
 __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= a.P) return;
+	const bool in_range = idx < a.P;
+	if (FILTER_ONLY && !in_range) return;   // the full kernel keeps every thread for the workgroup scan below
 
 	int radius_out = 0;
 	ushort4 rect_out = make_ushort4(0, 0, 0, 0);
 
-	const float3 p = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+	const int ld = in_range ? idx : 0;
+	const float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
 	const float* vm = a.viewmatrix;
 	const float* pm = a.projmatrix;
 	const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
-	bool alive = !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
-	if (!alive && a.prefiltered) a.flags[0] = 1;
+	bool alive = in_range && !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
+	if (in_range && !alive && a.prefiltered) a.flags[0] = 1;
 
 	if (alive) {
 		const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					// alpha = min(0.99, o*exp(power)) < 1/255  <=>  power < -ln(255*o); keep a margin far
 					// above the rounding of logf/expf so the cut only skips pairs the exact test rejects.
 					const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
-					float4* rec = a.geom.rec + (size_t)idx * 3;
+					float4* rec = a.geom.rec + (size_t)idx * BSR_REC;
 					rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
 					rec[1] = make_float4(conic_c, power_cut, opacity, pvz);
 					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
@@ -174,8 +176,36 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			}
 		}
 	}
-	if (a.radii) a.radii[idx] = radius_out;
-	if (!FILTER_ONLY) a.geom.rect[idx] = rect_out;
+	if (in_range && a.radii) a.radii[idx] = radius_out;
+	if (!FILTER_ONLY) {
+		// Gaussian-major instance blocks for the backward's gather: exclusive scan of the per-Gaussian
+		// tile counts inside the workgroup + one atomic per workgroup on a running total.  Blocks of
+		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
+		__shared__ uint32_t s_wave[4];
+		__shared__ uint32_t s_base;
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		const uint32_t n_inst = (uint32_t)(rect_out.z - rect_out.x) * (uint32_t)(rect_out.w - rect_out.y);
+		uint32_t incl = n_inst;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+		if (threadIdx.x == 0) s_base = atomicAdd((uint32_t*)&a.flags[1], w0 + w1 + w2 + w3);
+		__syncthreads();
+		if (in_range) {
+			const uint32_t off = s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
+			a.geom.rect[idx] = rect_out;
+			a.geom.inst_offset[idx] = off;
+			if (n_inst)
+				a.geom.rec[(size_t)idx * BSR_REC + 3] =
+				    make_float4(__uint_as_float(off), __uint_as_float((uint32_t)rect_out.x | ((uint32_t)rect_out.y << 16)),
+				                __uint_as_float((uint32_t)rect_out.z | ((uint32_t)rect_out.w << 16)), 0.0f);
+		}
+	}
 }
 
 __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __restrict__ means3D,

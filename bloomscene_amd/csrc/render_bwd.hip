@@ -98,6 +98,15 @@ __device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float 
 	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
+// Index of this tile's instance of a Gaussian in the Gaussian-major instance order (its block
+// starts at inst_offset and enumerates its tile rectangle row-major), from q3 of the splat record.
+__device__ __forceinline__ uint32_t instance_index(const float4 q3, int tx, int ty)
+{
+	const uint32_t off = __float_as_uint(q3.x), lo = __float_as_uint(q3.y), hi = __float_as_uint(q3.z);
+	const uint32_t xmin = lo & 0xffffu, ymin = lo >> 16, xmax = hi & 0xffffu;
+	return off + ((uint32_t)ty - ymin) * (xmax - xmin) + ((uint32_t)tx - xmin);
+}
+
 struct BwdShared {
 	TileStage st;
 	float part[4][9][BSR_BLOCK];   // per-wave partial sums of the current batch (plain stores)
@@ -108,8 +117,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ rec,
-                                                          const ushort4* __restrict__ rect,
-                                                          const uint32_t* __restrict__ inst_offset,
                                                           const float* __restrict__ bg_color,
                                                           const float* __restrict__ final_Ts,
                                                           const uint32_t* __restrict__ n_contrib,
@@ -176,13 +183,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		if (valid) {
 			my_slot = start + (uint32_t)(top - tid);
 			const uint32_t id = point_list[my_slot];
-			const float4* r = rec + (size_t)id * 3;
+			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
-			const ushort4 rc = rect[id];
-			const uint32_t k = (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
-			slot_of[inst_offset[id] + k] = my_slot;
+			slot_of[instance_index(r[3], tx, ty)] = my_slot;
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -273,9 +278,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
 		const uint32_t id = point_list[slot];
-		const ushort4 rc = rect[id];
-		const uint32_t k = (uint32_t)(ty - rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - rc.x);
-		slot_of[inst_offset[id] + k] = slot;
+		slot_of[instance_index(rec[(size_t)id * BSR_REC + 3], tx, ty)] = slot;
 		float4* row = slab + (size_t)slot * 3;
 		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 		row[0] = z;
@@ -284,53 +287,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	}
 }
 
-// inst_offset[g] = start of Gaussian g's block in slot_of; blocks are laid out in an arbitrary
-// (atomic) order of 1024-Gaussian chunks, contiguous and ascending inside a chunk.
-__global__ void __launch_bounds__(1024) k_inst_offsets(int P, const ushort4* __restrict__ rect,
-                                                       uint32_t* __restrict__ inst_offset,
-                                                       uint32_t* __restrict__ counter)
-{
-	__shared__ uint32_t s_wave[16];
-	__shared__ uint32_t s_base;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int idx = blockIdx.x * 1024 + tid;
-	uint32_t v = 0;
-	if (idx < P) {
-		const ushort4 r = rect[idx];
-		v = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
-	}
-	uint32_t incl = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += t;
-	}
-	if (lane == 63) s_wave[wave] = incl;
-	__syncthreads();
-	uint32_t wave_off = 0, total = 0;
-	for (int w = 0; w < 16; w++) {
-		if (w < wave) wave_off += s_wave[w];
-		total += s_wave[w];
-	}
-	if (tid == 0) s_base = atomicAdd(counter, total);
-	__syncthreads();
-	if (idx < P) inst_offset[idx] = s_base + wave_off + incl - v;
-}
-
-void launch_inst_offsets(int P, const ushort4* rect, uint32_t* inst_offset, uint32_t* counter, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_inst_offsets, dim3((P + 1023) / 1024), dim3(1024), 0, s, P, rect, inst_offset, counter);
-}
-
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const ushort4* rect, const uint32_t* inst_offset, const float* bg,
-                       const float* final_T, const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of,
-                       float4* slab, hipStream_t s)
+                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
+                       const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
 	hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
-	                   rect, inst_offset, bg, final_T, n_contrib, dL_dpix, slot_of, slab);
+	                   bg, final_T, n_contrib, dL_dpix, slot_of, slab);
 }
 
 }  // namespace bsr

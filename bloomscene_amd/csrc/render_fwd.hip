@@ -7,7 +7,7 @@
 //
 // MI355X mapping: one tile = one 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel
 // quadrant.  List entries are staged 256 at a time: each thread gathers one 48-byte splat record
-// (3 x 16-B loads from the L2/Infinity-Cache resident record table), runs a conservative
+// (3 x 16-B loads out of its one 64-B line in the L2/Infinity-Cache resident record table), runs a conservative
 // ellipse-vs-quadrant test on it and the batch is compacted with wave ballots + prefix popcounts
 // into one ordered index list per wave (tile_common.h).  A wave then walks only the entries that
 // can touch its quadrant, with broadcast LDS reads.  The per-pixel reject path needs 24 B of LDS
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		if (valid) {
 			const uint32_t id = point_list[start + base + tid];
-			const float4* r = rec + (size_t)id * 3;
+			const float4* r = rec + (size_t)id * BSR_REC;
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];

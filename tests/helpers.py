@@ -164,7 +164,8 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     img = img_t.cpu().numpy()
     out = SimpleNamespace()
     off = 0
-    out.rec = geom[off:off + P * 48].view(np.float32).reshape(P, 12); off += _al(P * 48)
+    out.rec = geom[off:off + P * 64].view(np.float32).reshape(P, 16); off += _al(P * 64)
+    out.inst_offset = geom[off:off + P * 4].view(np.uint32); off += _al(P * 4)
     out.rect = geom[off:off + P * 8].view(np.uint16).reshape(P, 4); off += _al(P * 8)
     out.cov3D = geom[off:off + P * 24].view(np.float32).reshape(P, 6); off += _al(P * 24)
     out.clamped = geom[off:off + P].copy()
