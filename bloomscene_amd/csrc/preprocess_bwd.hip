@@ -84,12 +84,86 @@ __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const floa
 	dmean[2] += (-ox * oz * dL_ddir[0] - oy * oz * dL_ddir[1] + (sum2 - oz * oz) * dL_ddir[2]) * invsum32;
 }
 
-__global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
+// Wave-cooperative variant of sh_bwd_deg for M = 4 / 16 (ROW_F4 = 3 / 12): every lane of the wave
+// takes part; dL_dsh rows (zeros for culled Gaussians) leave through the LDS tile as contiguous
+// 1-KiB stores, and the coefficients come in the same way unless most of the wave is culled.
+template <int DEG, int ROW_F4>
+__device__ __forceinline__ void sh_bwd_coop(const BwdArgs& a, int idx, bool visible, const float3 m, const float* dcolor,
+                                            float* dmean, ShTile<ROW_F4>& tile, int lane, int g0, int n_valid)
+{
+	constexpr int NC = (DEG + 1) * (DEG + 1);
+	constexpr int N = NC * 3;
+	constexpr int STRIDE = ShTile<ROW_F4>::STRIDE;
+	const float ox = m.x - a.campos[0], oy = m.y - a.campos[1], oz = m.z - a.campos[2];
+	const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
+	// culled lanes use direction 0 and gradient 0: their row is exactly zero
+	const float x = visible ? ox / len : 0.f, y = visible ? oy / len : 0.f, z = visible ? oz / len : 0.f;
+	const uint8_t cl = visible ? a.geom.clamped[idx] : (uint8_t)7;
+	float dL_dRGB[3];
+	dL_dRGB[0] = (visible && !(cl & 1)) ? dcolor[0] : 0.f;
+	dL_dRGB[1] = (visible && !(cl & 2)) ? dcolor[1] : 0.f;
+	dL_dRGB[2] = (visible && !(cl & 4)) ? dcolor[2] : 0.f;
+	if (visible) {   // same product as the reference's dL_dRGB *= clamped ? 0 : 1 (backward.cu:32-34)
+		dL_dRGB[0] = dcolor[0] * ((cl & 1) ? 0.f : 1.f);
+		dL_dRGB[1] = dcolor[1] * ((cl & 2) ? 0.f : 1.f);
+		dL_dRGB[2] = dcolor[2] * ((cl & 4) ? 0.f : 1.f);
+	}
+	{   // phase 1: coefficient gradients -> own LDS row -> contiguous global stores
+		float dsh[N];
+		sh_coef_grad<DEG>(x, y, z, dL_dRGB, dsh);
+		float4* row = &tile.rows[lane * STRIDE];
+#pragma unroll
+		for (int i = 0; i < ROW_F4; i++) {
+			float4 o;
+			o.x = (i * 4 + 0 < N) ? dsh[(i * 4 + 0 < N) ? i * 4 + 0 : 0] : 0.f;
+			o.y = (i * 4 + 1 < N) ? dsh[(i * 4 + 1 < N) ? i * 4 + 1 : 0] : 0.f;
+			o.z = (i * 4 + 2 < N) ? dsh[(i * 4 + 2 < N) ? i * 4 + 2 : 0] : 0.f;
+			o.w = (i * 4 + 3 < N) ? dsh[(i * 4 + 3 < N) ? i * 4 + 3 : 0] : 0.f;
+			row[i] = o;
+		}
+		__builtin_amdgcn_wave_barrier();
+		sh_tile_store<ROW_F4>(tile, a.dL_dsh, g0, n_valid, lane);
+		__builtin_amdgcn_wave_barrier();
+	}
+	// phase 2: coefficients in, view-direction gradient
+	const int n_vis = __popcll(__ballot(visible));
+	if (n_vis == 0) return;
+	float c[N];
+	if (n_vis >= 24) {
+		sh_tile_load<ROW_F4>(tile, a.shs, g0, n_valid, lane);
+		__builtin_amdgcn_wave_barrier();
+		const float4* row = &tile.rows[lane * STRIDE];
+#pragma unroll
+		for (int i = 0; i < (N + 3) / 4; i++) {
+			const float4 v = row[i];
+			if (i * 4 + 0 < N) c[i * 4 + 0] = v.x;
+			if (i * 4 + 1 < N) c[i * 4 + 1] = v.y;
+			if (i * 4 + 2 < N) c[i * 4 + 2] = v.z;
+			if (i * 4 + 3 < N) c[i * 4 + 3] = v.w;
+		}
+	} else if (visible) {
+		load_sh<NC>(a.shs + (size_t)idx * a.M * 3, a.M, c);
+	}
+	if (visible) {
+		float dL_ddir[3];
+		sh_dir_grad<DEG>(c, x, y, z, dL_dRGB, dL_ddir);
+		const float sum2 = ox * ox + oy * oy + oz * oz;
+		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+		dmean[0] += ((+sum2 - ox * ox) * dL_ddir[0] - oy * ox * dL_ddir[1] - oz * ox * dL_ddir[2]) * invsum32;
+		dmean[1] += (-ox * oy * dL_ddir[0] + (sum2 - oy * oy) * dL_ddir[1] - oz * oy * dL_ddir[2]) * invsum32;
+		dmean[2] += (-ox * oz * dL_ddir[0] - oy * oz * dL_ddir[1] + (sum2 - oz * oz) * dL_ddir[2]) * invsum32;
+	}
+}
+
+// ROW_F4 = 0: per-thread SH access (any M); 3 / 12: wave-cooperative LDS-transposed access (M = 4 / 16)
+template <int ROW_F4>
+__global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(const BwdArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= a.P) return;
-	const ushort4 rc = a.geom.rect[idx];
-	const bool visible = a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y);
+	const bool in_range = idx < a.P;
+	if (ROW_F4 == 0 && !in_range) return;   // the cooperative variants keep whole waves alive
+	const ushort4 rc = in_range ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
+	const bool visible = in_range && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
 
 	// ---- gather: add the per-instance partial sums of this Gaussian in tile (row-major) order.
 	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
@@ -106,23 +180,26 @@ __global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
 			g[8] += s2.x;
 		}
 	}
-	a.dL_dmean2D[3 * idx] = g[0];
-	a.dL_dmean2D[3 * idx + 1] = g[1];
-	a.dL_dmean2D[3 * idx + 2] = 0.f;
-	reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g[2], g[3], 0.f, g[4]);
-	a.dL_dopacity[idx] = g[5];
-	a.dL_dcolor[3 * idx] = g[6];
-	a.dL_dcolor[3 * idx + 1] = g[7];
-	a.dL_dcolor[3 * idx + 2] = g[8];
+	if (in_range) {
+		a.dL_dmean2D[3 * idx] = g[0];
+		a.dL_dmean2D[3 * idx + 1] = g[1];
+		a.dL_dmean2D[3 * idx + 2] = 0.f;
+		reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g[2], g[3], 0.f, g[4]);
+		a.dL_dopacity[idx] = g[5];
+		a.dL_dcolor[3 * idx] = g[6];
+		a.dL_dcolor[3 * idx + 1] = g[7];
+		a.dL_dcolor[3 * idx + 2] = g[8];
+	}
 
 	float dmean[3] = {0.f, 0.f, 0.f};
 	float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float dscale[3] = {0.f, 0.f, 0.f};
 	float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
+	const int li = in_range ? idx : 0;
+	const float3 m = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
 	if (visible) {
 		const float* vm = a.viewmatrix;
-		const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
 
 		// ------------------------------------------------ computeCov2DCUDA, backward.cu:144-274
 		float V[6];
@@ -213,7 +290,7 @@ __global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
 		dmean[1] += pdy;
 		dmean[2] += pdz;
 
-		if (a.shs) {
+		if (ROW_F4 == 0 && a.shs) {
 			if (a.D <= 0) sh_bwd_deg<0>(a, idx, m, &g[6], dmean);
 			else if (a.D == 1) sh_bwd_deg<1>(a, idx, m, &g[6], dmean);
 			else if (a.D == 2) sh_bwd_deg<2>(a, idx, m, &g[6], dmean);
@@ -257,9 +334,25 @@ __global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
 			drot[2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
 			drot[3] = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
 		}
-	} else if (a.shs && a.dL_dsh) {
+	} else if (ROW_F4 == 0 && a.shs && a.dL_dsh) {
 		zero_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M);
 	}
+
+	if (ROW_F4 != 0) {
+		// SH part for the whole wave at once (the reference adds it to dL_dmean after the projection
+		// part, backward.cu:387-391; the cov3D part above does not touch dL_dmean, so the order holds)
+		__shared__ ShTile<(ROW_F4 ? ROW_F4 : 1)> s_tile[4];
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		const int g0 = blockIdx.x * 256 + wave * 64;
+		const int n_valid = min(64, max(0, a.P - g0));
+		ShTile<(ROW_F4 ? ROW_F4 : 1)>& tile = s_tile[wave];
+		if (a.D <= 0) sh_bwd_coop<0, (ROW_F4 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		else if (a.D == 1) sh_bwd_coop<1, (ROW_F4 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		else if (ROW_F4 < 12) { /* degree > 1 needs M >= 9: not reachable with M = 4 (checked by the host) */ }
+		else if (a.D == 2) sh_bwd_coop<2, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
+		else sh_bwd_coop<3, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
+	}
+	if (!in_range) return;
 
 	a.dL_dmean3D[3 * idx] = dmean[0];
 	a.dL_dmean3D[3 * idx + 1] = dmean[1];
@@ -276,7 +369,13 @@ __global__ void __launch_bounds__(256, 4) k_preprocess_bwd(const BwdArgs a)
 
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_preprocess_bwd, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+	const dim3 grid((a.P + 255) / 256), block(256);
+	if (a.shs && a.M == 16)
+		hipLaunchKernelGGL(k_preprocess_bwd<12>, grid, block, 0, s, a);
+	else if (a.shs && a.M == 4)
+		hipLaunchKernelGGL(k_preprocess_bwd<3>, grid, block, 0, s, a);
+	else
+		hipLaunchKernelGGL(k_preprocess_bwd<0>, grid, block, 0, s, a);
 }
 
 }  // namespace bsr

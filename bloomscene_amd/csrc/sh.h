@@ -184,4 +184,50 @@ __device__ __forceinline__ void sh_dir_grad(const float* c, float x, float y, fl
 	dL_ddir[2] = (dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1]) + dRGBdz[2] * dL_dRGB[2];
 }
 
+// ---- wave-cooperative, LDS-transposed access to the [P][M][3] coefficient arrays ---------------
+// A lane reading or writing its own 12*M-byte block touches 64 different cache lines per wave
+// instruction with 16 B each.  Instead the wave's 64 blocks (contiguous in memory, 12 KiB at M = 16)
+// move with full 1-KiB wave instructions and are transposed through a padded LDS tile, one row
+// per Gaussian.  ROW_F4 = 3*M/4 float4 per Gaussian (3 for M = 4, 12 for M = 16); the row stride is
+// ROW_F4 + 1 float4 (52 dwords at M = 16: conflict-free for ds_read/write_b128).
+template <int ROW_F4>
+struct ShTile {
+	static constexpr int STRIDE = ROW_F4 + 1;
+	float4 rows[64 * STRIDE];
+};
+
+// global -> LDS rows of the wave's Gaussians [g0, g0 + n_valid)
+template <int ROW_F4>
+__device__ __forceinline__ void sh_tile_load(ShTile<ROW_F4>& t, const float* __restrict__ base, int g0, int n_valid,
+                                             int lane)
+{
+	const float4* src = reinterpret_cast<const float4*>(base) + (size_t)g0 * ROW_F4;
+	const int n_f4 = n_valid * ROW_F4;
+#pragma unroll
+	for (int i = 0; i < ROW_F4; i++) {
+		const int n = i * 64 + lane;
+		if (n < n_f4) {
+			const int g = n / ROW_F4, part = n - g * ROW_F4;
+			t.rows[g * ShTile<ROW_F4>::STRIDE + part] = src[n];
+		}
+	}
+}
+
+// LDS rows -> global
+template <int ROW_F4>
+__device__ __forceinline__ void sh_tile_store(const ShTile<ROW_F4>& t, float* __restrict__ base, int g0, int n_valid,
+                                              int lane)
+{
+	float4* dst = reinterpret_cast<float4*>(base) + (size_t)g0 * ROW_F4;
+	const int n_f4 = n_valid * ROW_F4;
+#pragma unroll
+	for (int i = 0; i < ROW_F4; i++) {
+		const int n = i * 64 + lane;
+		if (n < n_f4) {
+			const int g = n / ROW_F4, part = n - g * ROW_F4;
+			dst[n] = t.rows[g * ShTile<ROW_F4>::STRIDE + part];
+		}
+	}
+}
+
 }  // namespace bsr
