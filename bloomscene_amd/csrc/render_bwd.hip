@@ -107,9 +107,10 @@ __device__ __forceinline__ uint32_t instance_index(const float4 q3, int tx, int 
 	return off + ((uint32_t)ty - ymin) * (xmax - xmin) + ((uint32_t)tx - xmin);
 }
 
+#define BSR_BWD_BATCH 128
 struct BwdShared {
-	TileStage st;
-	float part[4][9][BSR_BLOCK];   // per-wave partial sums of the current batch (plain stores)
+	TileStageT<BSR_BWD_BATCH> st;
+	float part[4][9][BSR_BWD_BATCH];   // per-wave partial sums of the current batch (plain stores)
 	uint32_t max_contrib[4];
 };
 
@@ -166,16 +167,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
 	if (lane == 0) sh.max_contrib[wave] = m;
+	if (tid < BSR_BWD_BATCH) {
 #pragma unroll
-	for (int w = 0; w < 4; w++)
+		for (int w = 0; w < 4; w++)
 #pragma unroll
-		for (int k = 0; k < 9; k++) sh.part[w][k][tid] = 0.f;
+			for (int k = 0; k < 9; k++) sh.part[w][k][tid] = 0.f;
+	}
 	__syncthreads();
 	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
 
 	// LDS byte address of acc[0][0] for the native ds_add_f32 path
-	for (int base = 0; base < n_walk; base += BSR_BLOCK) {
-		const int cnt = min(BSR_BLOCK, n_walk - base);
+	for (int base = 0; base < n_walk; base += BSR_BWD_BATCH) {
+		const int cnt = min(BSR_BWD_BATCH, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
 		const bool valid = tid < cnt;
 		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;

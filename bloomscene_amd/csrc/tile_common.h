@@ -38,21 +38,26 @@ __device__ __forceinline__ bool quad_may_hit(float X, float Y, float a, float b,
 	return !miss;
 }
 
-// Staged batch of up to 256 list entries + per-wave (= per 8x8 quadrant) compacted index lists.
-struct TileStage {
-	float4 q0[BSR_BLOCK];            // x, y, conic a, conic b
-	float4 q1[BSR_BLOCK];            // conic c, power cut, opacity, depth
-	float4 q2[BSR_BLOCK];            // r, g, b, -
-	unsigned short list[4][BSR_BLOCK];
+// Staged batch of up to BATCH (<= 256) list entries + per-wave (= per 8x8 quadrant) compacted
+// index lists.  The forward stages 256 entries at a time; the backward 128, which with its
+// per-wave partial-sum slots keeps LDS at 25 KB per workgroup (6 workgroups per CU).
+template <int BATCH>
+struct TileStageT {
+	float4 q0[BATCH];                // x, y, conic a, conic b
+	float4 q1[BATCH];                // conic c, power cut, opacity, depth
+	float4 q2[BATCH];                // r, g, b, -
+	unsigned short list[4][BATCH];
 	unsigned int cnt[4][4];          // [staging wave][quadrant]
 };
+using TileStage = TileStageT<BSR_BLOCK>;
 
 // Thread `tid` holds the record of batch entry `tid` (valid iff tid < cnt).  Writes the record
 // to LDS and appends tid to the list of every quadrant it may touch, preserving list order
 // (64-bit ballots + prefix popcounts inside a wave, a 4x4 count table across waves).
 // On return (after the trailing barrier) st.list[q][0 .. total[q]) is ready; returns total[wave].
-__device__ __forceinline__ int stage_and_compact(TileStage& st, int tid, bool valid, const float4 r0, const float4 r1,
-                                                 const float4 r2, float tile_x0, float tile_y0)
+template <int BATCH>
+__device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid, bool valid, const float4 r0,
+                                                 const float4 r1, const float4 r2, float tile_x0, float tile_y0)
 {
 	const int wave = tid >> 6, lane = tid & 63;
 	bool h[4] = {false, false, false, false};
