@@ -24,6 +24,7 @@ size_t GeomState::bytes(size_t P)
 	size_t s = 0;
 	s += align_up(P * BSR_REC * sizeof(float4), 256);
 	s += align_up(P * sizeof(uint32_t), 256);
+	s += align_up(P * sizeof(uint64_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * 6 * sizeof(float), 256);
 	s += align_up(P * sizeof(uint8_t), 256);
@@ -35,6 +36,7 @@ GeomState GeomState::carve(char* p, size_t P)
 	p = (char*)align_up((size_t)p, 256);
 	g.rec = (float4*)p;      p += align_up(P * BSR_REC * sizeof(float4), 256);
 	g.inst_offset = (uint32_t*)p; p += align_up(P * sizeof(uint32_t), 256);
+	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
 	g.clamped = (uint8_t*)p;
@@ -73,7 +75,7 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, hipStream_t s);
-void launch_scatter(int P, int gx, const ushort4* rect, const float4* rec, const uint32_t* tile_start,
+void launch_scatter(int P, int gx, const ushort4* rect, const uint64_t* kept_mask, const float4* rec, const uint32_t* tile_start,
                     uint32_t* tile_cursor, uint64_t* keys, hipStream_t s);
 void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
                        hipStream_t s);
@@ -400,7 +402,9 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	// num_rendered (and the prefiltered flag) -> host; the one blocking read of the forward pass
 	uint32_t h_R = 0;
 	int h_flag = 0;
-	HIP_TRY(hipMemcpyAsync(&h_R, img.tile_start + T, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	// The reference's num_rendered = sum of rect areas (rasterizer_impl.cu:278-282); it sizes the scratch.
+	// The number of instances actually kept after exact tile culling stays on the device (tile_start[T]).
+	HIP_TRY(hipMemcpyAsync(&h_R, img.flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	if (prefiltered) HIP_TRY(hipMemcpyAsync(&h_flag, img.flags, sizeof(int), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
@@ -415,7 +419,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	if (R > 0) {
 		{
 			StageTimer t("scatter", s);
-			launch_scatter(P, gx, geom.rect, geom.rec, img.tile_start, img.tile_cursor, bin.keys, s);
+			launch_scatter(P, gx, geom.rect, geom.kept_mask, geom.rec, img.tile_start, img.tile_cursor, bin.keys, s);
 		}
 		STAGE_CHECK("scatter", debug, s);
 		{

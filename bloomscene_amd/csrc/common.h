@@ -15,11 +15,14 @@ namespace bsr {
 // Per-Gaussian "splat record": everything the tile kernels gather per list entry, exactly one
 // 64-byte cache line:
 //   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, power_cut, opacity, depth)   q2 = (r, g, b, 0)
-//   q3 = bits(inst_offset, xmin | ymin << 16, xmax | ymax << 16, 0)     (backward only)
+//   q3 = bits(inst_offset, xmin | ymin << 16, width | height << 16, kept_mask_lo), q2.w = bits(kept_mask_hi)
+//        (backward only).  kept_mask bit k = the k-th tile (row-major) of the rect is kept; rects of
+//        more than 64 tiles keep every tile and ignore the mask.
 #define BSR_REC 4
 struct GeomState {
 	float4* rec;        // [P][BSR_REC]
-	uint32_t* inst_offset;  // [P] start of the Gaussian's block of tile instances (Gaussian-major order)
+	uint32_t* inst_offset;  // [P] start of the Gaussian's block of kept tile instances (Gaussian-major order)
+	uint64_t* kept_mask;    // [P] see q3 above
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
 	float* cov3D;       // [P][6]
 	uint8_t* clamped;   // [P] bit ch = SH colour channel ch was clamped at 0
@@ -38,7 +41,7 @@ struct ImgState {
 	uint32_t* tile_start;  // [T + 1] exclusive scan of tile_count; ranges[t] = [start[t], start[t+1])
 	uint32_t* tile_count;  // [T]
 	uint32_t* tile_cursor; // [T]
-	int* flags;            // [4]: 0 = prefiltered violation
+	int* flags;            // [4]: prefiltered violation | kept instances | rect tiles (= reference num_rendered)
 	static size_t bytes(size_t N, size_t T);
 	static ImgState carve(char* p, size_t N, size_t T);
 };
@@ -64,7 +67,7 @@ struct PreArgs {
 	int* radii;          // may be NULL
 	GeomState geom;
 	uint32_t* tile_count;
-	int* flags;            // [0] prefiltered violation, [1] running total of tile instances
+	int* flags;            // [0] prefiltered violation, [1] running total of kept instances, [2] of rect tiles
 };
 
 struct BwdArgs {
@@ -133,6 +136,20 @@ __device__ __forceinline__ float bsr_expf_nonpos(float x)
 	p = __builtin_fmaf(p, r, 1.0f);
 	const float v = __builtin_ldexpf(p, (int)k);
 	return (x < -104.0f) ? 0.0f : v;
+}
+
+// Dense index of rect tile k (row-major) among the Gaussian's kept tiles.
+__device__ __forceinline__ uint32_t kept_rank(uint32_t area, uint64_t mask, uint32_t k)
+{
+	return area > 64u ? k : (uint32_t)__popcll(mask & ((1ull << k) - 1ull));
+}
+__device__ __forceinline__ bool tile_kept(uint32_t area, uint64_t mask, uint32_t k)
+{
+	return area > 64u || ((mask >> k) & 1ull);
+}
+__device__ __forceinline__ uint32_t kept_count(uint32_t area, uint64_t mask)
+{
+	return area > 64u ? area : (uint32_t)__popcll(mask);
 }
 
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a

@@ -7,6 +7,7 @@
 // are written out with their zero terms dropped, keeping the order of the remaining operations.
 #include "common.h"
 #include "sh.h"
+#include "tile_common.h"
 
 namespace bsr {
 
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 
 	int radius_out = 0;
 	ushort4 rect_out = make_ushort4(0, 0, 0, 0);
+	uint64_t kept_mask = 0;
 
 	const int ld = in_range ? idx : 0;
 	const float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
@@ -168,10 +170,26 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					float4* rec = a.geom.rec + (size_t)idx * BSR_REC;
 					rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
 					rec[1] = make_float4(conic_c, power_cut, opacity, pvz);
-					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], 0.0f);
 					a.geom.clamped[idx] = clamp_bits;
+					// Count one instance per tile of the rect the splat can actually reach: the reference
+					// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
+					// alpha < 1/255 everywhere only ever `continue` in its render loops, so dropping them
+					// changes no pixel.  Rects of more than 64 tiles are kept whole (mask too short).
+					const uint32_t area = (uint32_t)(rmax[0] - rmin[0]) * (uint32_t)(rmax[1] - rmin[1]);
+					const bool pd = (conic_a > 0.0f) && (conic_c > 0.0f) && (conic_a * conic_c - conic_b * conic_b > 0.0f);
+					const float rb_c = -conic_b / conic_c, rb_a = -conic_b / conic_a;
+					uint32_t k = 0;
 					for (int y = rmin[1]; y < rmax[1]; y++)
-						for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+						for (int x = rmin[0]; x < rmax[0]; x++, k++) {
+							const bool keep = area > 64u || box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut,
+							                                                rb_c, rb_a, pd, (float)(x * BSR_TILE),
+							                                                (float)(y * BSR_TILE));
+							if (keep) {
+								atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+								if (area <= 64u) kept_mask |= (1ull << k);
+							}
+						}
+					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
 				}
 			}
 		}
@@ -184,7 +202,13 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		__shared__ uint32_t s_wave[4];
 		__shared__ uint32_t s_base;
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-		const uint32_t n_inst = (uint32_t)(rect_out.z - rect_out.x) * (uint32_t)(rect_out.w - rect_out.y);
+		const uint32_t area_all = (uint32_t)(rect_out.z - rect_out.x) * (uint32_t)(rect_out.w - rect_out.y);
+		const uint32_t n_inst = area_all ? kept_count(area_all, kept_mask) : 0u;
+		// reference num_rendered = sum of rect areas: wave-reduce, one atomic per wave
+		uint32_t area_sum = area_all;
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) area_sum += __shfl_xor(area_sum, d, 64);
+		if ((threadIdx.x & 63) == 0 && area_sum) atomicAdd((uint32_t*)&a.flags[2], area_sum);
 		uint32_t incl = n_inst;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -200,10 +224,12 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			const uint32_t off = s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
 			a.geom.rect[idx] = rect_out;
 			a.geom.inst_offset[idx] = off;
+			a.geom.kept_mask[idx] = kept_mask;
 			if (n_inst)
-				a.geom.rec[(size_t)idx * BSR_REC + 3] =
-				    make_float4(__uint_as_float(off), __uint_as_float((uint32_t)rect_out.x | ((uint32_t)rect_out.y << 16)),
-				                __uint_as_float((uint32_t)rect_out.z | ((uint32_t)rect_out.w << 16)), 0.0f);
+				a.geom.rec[(size_t)idx * BSR_REC + 3] = make_float4(
+				    __uint_as_float(off), __uint_as_float((uint32_t)rect_out.x | ((uint32_t)rect_out.y << 16)),
+				    __uint_as_float((uint32_t)(rect_out.z - rect_out.x) | ((uint32_t)(rect_out.w - rect_out.y) << 16)),
+				    __uint_as_float((uint32_t)kept_mask));
 		}
 	}
 }

@@ -98,13 +98,16 @@ __device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float 
 	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
-// Index of this tile's instance of a Gaussian in the Gaussian-major instance order (its block
-// starts at inst_offset and enumerates its tile rectangle row-major), from q3 of the splat record.
-__device__ __forceinline__ uint32_t instance_index(const float4 q3, int tx, int ty)
+// Index of this tile's instance of a Gaussian in the Gaussian-major order of KEPT instances (its
+// block starts at inst_offset and enumerates the kept tiles of its rect row-major), from q3 / q2.w of
+// the splat record.
+__device__ __forceinline__ uint32_t instance_index(const float4 q2, const float4 q3, int tx, int ty)
 {
-	const uint32_t off = __float_as_uint(q3.x), lo = __float_as_uint(q3.y), hi = __float_as_uint(q3.z);
-	const uint32_t xmin = lo & 0xffffu, ymin = lo >> 16, xmax = hi & 0xffffu;
-	return off + ((uint32_t)ty - ymin) * (xmax - xmin) + ((uint32_t)tx - xmin);
+	const uint32_t off = __float_as_uint(q3.x), lo = __float_as_uint(q3.y), wh = __float_as_uint(q3.z);
+	const uint32_t xmin = lo & 0xffffu, ymin = lo >> 16, w = wh & 0xffffu, h = wh >> 16;
+	const uint64_t mask = ((uint64_t)__float_as_uint(q2.w) << 32) | (uint64_t)__float_as_uint(q3.w);
+	const uint32_t k = ((uint32_t)ty - ymin) * w + ((uint32_t)tx - xmin);
+	return off + kept_rank(w * h, mask, k);
 }
 
 #define BSR_BWD_BATCH 128
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
-			slot_of[instance_index(r[3], tx, ty)] = my_slot;
+			slot_of[instance_index(r2, r[3], tx, ty)] = my_slot;
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
 		const uint32_t id = point_list[slot];
-		slot_of[instance_index(rec[(size_t)id * BSR_REC + 3], tx, ty)] = slot;
+		slot_of[instance_index(rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3], tx, ty)] = slot;
 		float4* row = slab + (size_t)slot * 3;
 		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 		row[0] = z;

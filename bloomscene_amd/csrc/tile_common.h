@@ -5,18 +5,19 @@
 
 namespace bsr {
 
-// Can the splat reach alpha >= 1/255 at ANY point of the axis-aligned box of pixel centres
-// [bx, bx+7] x [by, by+7]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
+// Can the splat reach alpha >= 1/255 at ANY point of an axis-aligned box of pixel centres
+// [bx, bx+EXT] x [by, by+EXT]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
 // d = centre - pixel.  For a positive-definite conic q is convex, so its minimum over the box is 0
 // if the centre lies inside and otherwise sits on one of the four edges, where it is a clamped 1-D
 // parabola minimum.  The splat is kept iff  -qmin >= power_cut - slack  (power_cut already carries
 // a margin; the extra slack covers the rounding of this test).  Anything not provably a miss --
 // non-PD conics, NaNs -- is kept, so the per-pixel decisions downstream stay exact.
-__device__ __forceinline__ bool quad_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
-                                             float rb_a, bool pd, float bx, float by)
+template <int EXT>   // box of pixel centres [bx, bx+EXT] x [by, by+EXT]: EXT = 7 (quadrant) or 15 (tile)
+__device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
+                                            float rb_a, bool pd, float bx, float by)
 {
-	const float dx_lo = X - (bx + 7.0f), dx_hi = X - bx;
-	const float dy_lo = Y - (by + 7.0f), dy_hi = Y - by;
+	const float dx_lo = X - (bx + (float)EXT), dx_hi = X - bx;
+	const float dy_lo = Y - (by + (float)EXT), dy_hi = Y - by;
 	const bool in_x = (dx_lo <= 0.0f) && (dx_hi >= 0.0f);
 	const bool in_y = (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
 	float qmin = 0.0f;
@@ -70,7 +71,7 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 		const float rb_c = -b / c, rb_a = -b / a;
 #pragma unroll
 		for (int q = 0; q < 4; q++)
-			h[q] = quad_may_hit(r0.x, r0.y, a, b, c, r1.y, rb_c, rb_a, pd, tile_x0 + (float)((q & 1) << 3),
+			h[q] = box_may_hit<7>(r0.x, r0.y, a, b, c, r1.y, rb_c, rb_a, pd, tile_x0 + (float)((q & 1) << 3),
 			                    tile_y0 + (float)((q >> 1) << 3));
 	}
 	unsigned long long m[4];

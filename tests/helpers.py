@@ -166,6 +166,7 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     off = 0
     out.rec = geom[off:off + P * 64].view(np.float32).reshape(P, 16); off += _al(P * 64)
     out.inst_offset = geom[off:off + P * 4].view(np.uint32); off += _al(P * 4)
+    out.kept_mask = geom[off:off + P * 8].view(np.uint64); off += _al(P * 8)
     out.rect = geom[off:off + P * 8].view(np.uint16).reshape(P, 4); off += _al(P * 8)
     out.cov3D = geom[off:off + P * 24].view(np.float32).reshape(P, 6); off += _al(P * 24)
     out.clamped = geom[off:off + P].copy()
@@ -175,10 +176,62 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     out.final_T = img[off:off + N * 4].view(np.float32); off += _al(N * 4)
     out.n_contrib = img[off:off + N * 4].view(np.uint32); off += _al(N * 4)
     out.tile_start = img[off:off + (T + 1) * 4].view(np.uint32)
+    # R = the reference's num_rendered (sum of rect areas) sizes the buffer; the instances actually
+    # kept after exact tile culling are the first tile_start[T] entries of point_list
+    out.kept = int(out.tile_start[T]) if R > 0 else 0
     if R > 0:
         b = bin_t.cpu().numpy()
         off = _al(R * 8)
-        out.point_list = b[off:off + R * 4].view(np.uint32)
+        out.point_list = b[off:off + out.kept * 4].view(np.uint32)
     else:
         out.point_list = np.zeros(0, dtype=np.uint32)
     return out
+
+
+def check_lists_against_oracle(c, st, b):
+    """The HIP per-tile lists must be order-preserving sub-sequences of the oracle's (= the
+    reference's (tile, depth, id) order); every instance dropped by the tile-level cull must be inert
+    (alpha < 1/255 or power > 0 at EVERY pixel of its tile, evaluated per pixel in float64); and each
+    pixel's n_contrib must point at the same Gaussian in both lists.  Returns the kept fraction."""
+    W, H = c.W, c.H
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    ts = b.tile_start.astype(np.int64)
+    assert ts[0] == 0 and (np.diff(ts[:T + 1]) >= 0).all()
+    n_h = b.n_contrib.reshape(H, W).astype(np.int64)
+    n_o = st.n_contrib.reshape(H, W).astype(np.int64)
+    xy = st.means2D.astype(np.float64)
+    con = st.conic_opacity.astype(np.float64)
+    dropped_total = 0
+    for t in range(T):
+        o0, o1 = int(st.ranges[t, 0]), int(st.ranges[t, 1])
+        ol = st.point_list[o0:o1].astype(np.int64)
+        hl = b.point_list[ts[t]:ts[t + 1]].astype(np.int64)
+        assert len(hl) <= len(ol)
+        # subsequence: positions of hl's ids inside ol must be strictly increasing (ids are unique per tile)
+        pos = {int(g): i for i, g in enumerate(ol)}
+        idx = np.array([pos[int(g)] for g in hl], dtype=np.int64) if len(hl) else np.zeros(0, np.int64)
+        assert (np.diff(idx) > 0).all(), f"tile {t}: not an order-preserving sub-sequence"
+        keep = np.zeros(len(ol), dtype=bool)
+        keep[idx] = True
+        drop = ol[~keep]
+        ty, tx = divmod(t, gx)
+        if len(drop):
+            dropped_total += len(drop)
+            px = tx * 16 + np.arange(16, dtype=np.float64)[None, :, None]
+            py = ty * 16 + np.arange(16, dtype=np.float64)[None, None, :]
+            dx = xy[drop, 0, None, None] - px
+            dy = xy[drop, 1, None, None] - py
+            power = -0.5 * (con[drop, 0, None, None] * dx * dx + con[drop, 2, None, None] * dy * dy) \
+                - con[drop, 1, None, None] * dx * dy
+            alpha = np.minimum(0.99, con[drop, 3, None, None] * np.exp(np.minimum(power, 0.0)))
+            live = (power <= 0) & (alpha >= (1.0 / 255.0) * (1 - 1e-5))
+            assert not live.any(), f"tile {t}: a culled instance could have contributed"
+        # n_contrib: same Gaussian is the last contributor of every pixel of the tile
+        blk = (slice(ty * 16, min(H, ty * 16 + 16)), slice(tx * 16, min(W, tx * 16 + 16)))
+        nh, no = n_h[blk].reshape(-1), n_o[blk].reshape(-1)
+        assert ((nh == 0) == (no == 0)).all()
+        m = no > 0
+        if m.any():
+            assert (hl[nh[m] - 1] == ol[no[m] - 1]).all(), f"tile {t}: n_contrib points at different Gaussians"
+    return 1.0 - dropped_total / max(1, st.num_rendered)
