@@ -404,7 +404,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	int h_flag = 0;
 	// The reference's num_rendered = sum of rect areas (rasterizer_impl.cu:278-282); it sizes the scratch.
 	// The number of instances actually kept after exact tile culling stays on the device (tile_start[T]).
-	HIP_TRY(hipMemcpyAsync(&h_R, img.flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(&h_R, img.flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	if (prefiltered) HIP_TRY(hipMemcpyAsync(&h_flag, img.flags, sizeof(int), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");

@@ -41,7 +41,7 @@ struct ImgState {
 	uint32_t* tile_start;  // [T + 1] exclusive scan of tile_count; ranges[t] = [start[t], start[t+1])
 	uint32_t* tile_count;  // [T]
 	uint32_t* tile_cursor; // [T]
-	int* flags;            // [4]: prefiltered violation | kept instances | rect tiles (= reference num_rendered)
+	int* flags;            // [4]: prefiltered violation | - | kept instances | rect tiles (= reference num_rendered)
 	static size_t bytes(size_t N, size_t T);
 	static ImgState carve(char* p, size_t N, size_t T);
 };
@@ -67,7 +67,7 @@ struct PreArgs {
 	int* radii;          // may be NULL
 	GeomState geom;
 	uint32_t* tile_count;
-	int* flags;            // [0] prefiltered violation, [1] running total of kept instances, [2] of rect tiles
+	int* flags;            // [0] prefiltered violation, [2] running total of kept instances, [3] of rect tiles (one u64)
 };
 
 struct BwdArgs {

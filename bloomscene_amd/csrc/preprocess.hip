@@ -178,17 +178,41 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					const uint32_t area = (uint32_t)(rmax[0] - rmin[0]) * (uint32_t)(rmax[1] - rmin[1]);
 					const bool pd = (conic_a > 0.0f) && (conic_c > 0.0f) && (conic_a * conic_c - conic_b * conic_b > 0.0f);
 					const float rb_c = -conic_b / conic_c, rb_a = -conic_b / conic_a;
-					uint32_t k = 0;
-					for (int y = rmin[1]; y < rmax[1]; y++)
-						for (int x = rmin[0]; x < rmax[0]; x++, k++) {
-							const bool keep = area > 64u || box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut,
-							                                                rb_c, rb_a, pd, (float)(x * BSR_TILE),
-							                                                (float)(y * BSR_TILE));
-							if (keep) {
-								atomicAdd(&a.tile_count[y * a.gx + x], 1u);
-								if (area <= 64u) kept_mask |= (1ull << k);
+					if (area > 64u) {
+						for (int y = rmin[1]; y < rmax[1]; y++)
+							for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+					} else {
+						// Axis-aligned bounding box of the region {alpha >= 1/255} = {q(d) <= t}, t = -(cut - slack):
+						// |dx| <= sqrt(2 t c / det), |dy| <= sqrt(2 t a / det).  Tiles outside it are dropped
+						// without the edge test; NaN / non-PD conics fall back to the whole rect.
+						int x0 = rmin[0], x1 = rmax[0], y0 = rmin[1], y1 = rmax[1];
+						const float tq = -(power_cut - (1.0e-3f + 1.0e-4f * fabsf(power_cut)));
+						const float cdet = conic_a * conic_c - conic_b * conic_b;
+						if (pd) {
+							if (tq < 0.0f) {
+								x1 = x0;   // opacity below 1/255: nothing is ever blended
+							} else {
+								const float hx = sqrtf(2.0f * tq * conic_c / cdet) * 1.0001f + 0.01f;
+								const float hy = sqrtf(2.0f * tq * conic_a / cdet) * 1.0001f + 0.01f;
+								if (hx == hx && hy == hy) {
+									// tile x holds pixel centres [16x, 16x+15]
+									x0 = max(x0, (int)ceilf((pix_x - hx - 15.0f) * (1.0f / BSR_TILE)));
+									x1 = min(x1, (int)floorf((pix_x + hx) * (1.0f / BSR_TILE)) + 1);
+									y0 = max(y0, (int)ceilf((pix_y - hy - 15.0f) * (1.0f / BSR_TILE)));
+									y1 = min(y1, (int)floorf((pix_y + hy) * (1.0f / BSR_TILE)) + 1);
+								}
 							}
 						}
+						const int w = rmax[0] - rmin[0];
+						for (int y = y0; y < y1; y++)
+							for (int x = x0; x < x1; x++) {
+								if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
+								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
+									atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
+								}
+							}
+					}
 					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
 				}
 			}
@@ -200,25 +224,34 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		// tile counts inside the workgroup + one atomic per workgroup on a running total.  Blocks of
 		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
 		__shared__ uint32_t s_wave[4];
+		__shared__ uint32_t s_area[4];
 		__shared__ uint32_t s_base;
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const uint32_t area_all = (uint32_t)(rect_out.z - rect_out.x) * (uint32_t)(rect_out.w - rect_out.y);
 		const uint32_t n_inst = area_all ? kept_count(area_all, kept_mask) : 0u;
-		// reference num_rendered = sum of rect areas: wave-reduce, one atomic per wave
-		uint32_t area_sum = area_all;
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) area_sum += __shfl_xor(area_sum, d, 64);
-		if ((threadIdx.x & 63) == 0 && area_sum) atomicAdd((uint32_t*)&a.flags[2], area_sum);
+		// inclusive wave scans of the kept-instance counts (-> instance blocks) and wave sums of the
+		// rect areas (-> the reference's num_rendered); ONE 64-bit atomic per workgroup carries both
+		// running totals (same-address atomics serialise at ~90 per microsecond).
 		uint32_t incl = n_inst;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t t = __shfl_up(incl, d, 64);
 			if (lane >= d) incl += t;
 		}
-		if (lane == 63) s_wave[wave] = incl;
+		uint32_t area_sum = area_all;
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) area_sum += __shfl_xor(area_sum, d, 64);
+		if (lane == 63) {
+			s_wave[wave] = incl;
+			s_area[wave] = area_sum;
+		}
 		__syncthreads();
 		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-		if (threadIdx.x == 0) s_base = atomicAdd((uint32_t*)&a.flags[1], w0 + w1 + w2 + w3);
+		if (threadIdx.x == 0) {
+			const unsigned long long add = (unsigned long long)(w0 + w1 + w2 + w3) |
+			                               ((unsigned long long)(s_area[0] + s_area[1] + s_area[2] + s_area[3]) << 32);
+			s_base = (uint32_t)atomicAdd((unsigned long long*)&a.flags[2], add);
+		}
 		__syncthreads();
 		if (in_range) {
 			const uint32_t off = s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
