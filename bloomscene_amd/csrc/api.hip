@@ -24,6 +24,7 @@ size_t GeomState::bytes(size_t P)
 	size_t s = 0;
 	s += align_up(P * BSR_REC * sizeof(float4), 256);
 	s += align_up(P * sizeof(uint32_t), 256);
+	s += 2 * align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
 	s += align_up(P * sizeof(uint64_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * 6 * sizeof(float), 256);
@@ -36,6 +37,8 @@ GeomState GeomState::carve(char* p, size_t P)
 	p = (char*)align_up((size_t)p, 256);
 	g.rec = (float4*)p;      p += align_up(P * BSR_REC * sizeof(float4), 256);
 	g.inst_offset = (uint32_t*)p; p += align_up(P * sizeof(uint32_t), 256);
+	g.wg_kept = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
+	g.wg_area = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
 	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
@@ -74,7 +77,8 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 // ---------------------------------------------------------------- kernels (other translation units)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
-void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, hipStream_t s);
+void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, int n_wg,
+                       uint32_t* wg_kept, const uint32_t* wg_area, int* flags, hipStream_t s);
 void launch_scatter(int P, int gx, const ushort4* rect, const uint64_t* kept_mask, const float4* rec, const uint32_t* tile_start,
                     uint32_t* tile_cursor, uint64_t* keys, hipStream_t s);
 void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
@@ -83,8 +87,8 @@ void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                       const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s);
+                       const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
+                       const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- errors
@@ -395,7 +399,8 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	}
 	{
 		StageTimer t("scan_tiles", s);
-		launch_scan_tiles(T, img.tile_count, img.tile_start, img.tile_cursor, s);
+		launch_scan_tiles(T, img.tile_count, img.tile_start, img.tile_cursor, (P + 255) / 256, geom.wg_kept, geom.wg_area,
+		                  img.flags, s);
 	}
 	STAGE_CHECK("scan_tiles", debug, s);
 
@@ -483,7 +488,7 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	if (R > 0) {
 		{
 			StageTimer t("render_bwd", s);
-			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
+			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
 			                  img.n_contrib, dL_dpix, slot_of, slab, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);

@@ -20,10 +20,50 @@
 namespace bsr {
 
 // ---- exclusive scan of tile_count -> tile_start[0..T], total in tile_start[T]; zero cursors ----
+// Exclusive scan of n values in place (dst may alias src), one 1024-thread workgroup; returns the total.
+__device__ __forceinline__ uint32_t block_exclusive_scan(int n, const uint32_t* src, uint32_t* dst, uint32_t* s_wave,
+                                                         uint32_t* s_carry, bool write)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	if (tid == 0) *s_carry = 0;
+	__syncthreads();
+	for (int base = 0; base < n; base += 1024) {
+		const int i = base + tid;
+		const uint32_t v = (i < n) ? src[i] : 0u;
+		uint32_t incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		uint32_t wave_off = 0;
+		for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+		const uint32_t carry = *s_carry;
+		if (write && i < n) dst[i] = carry + wave_off + incl - v;
+		__syncthreads();
+		if (tid == 1023) *s_carry = carry + wave_off + incl;
+		__syncthreads();
+	}
+	return *s_carry;
+}
+
 __global__ void __launch_bounds__(1024) k_scan_tiles(int T, const uint32_t* __restrict__ tile_count,
                                                      uint32_t* __restrict__ tile_start,
-                                                     uint32_t* __restrict__ tile_cursor)
+                                                     uint32_t* __restrict__ tile_cursor, int n_wg,
+                                                     uint32_t* __restrict__ wg_kept,
+                                                     const uint32_t* __restrict__ wg_area, int* __restrict__ flags)
 {
+	{   // per-preprocess-workgroup totals: kept instances -> bases (in place), rect tiles -> num_rendered
+		__shared__ uint32_t s_w[16];
+		__shared__ uint32_t s_c;
+		block_exclusive_scan(n_wg, wg_kept, wg_kept, s_w, &s_c, true);
+		__syncthreads();
+		const uint32_t total_area = block_exclusive_scan(n_wg, wg_area, nullptr, s_w, &s_c, false);
+		if (threadIdx.x == 0) flags[3] = (int)total_area;
+		__syncthreads();
+	}
 	__shared__ uint32_t s_wave[16];
 	__shared__ uint32_t s_carry;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -147,9 +187,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles_global(int T, int min_
 	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)keys[start + i];
 }
 
-void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, hipStream_t s)
+void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, int n_wg,
+                       uint32_t* wg_kept, const uint32_t* wg_area, int* flags, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, tile_cursor);
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, tile_cursor, n_wg, wg_kept,
+	                   wg_area, flags);
 }
 
 void launch_scatter(int P, int gx, const ushort4* rect, const uint64_t* kept_mask, const float4* rec,

@@ -15,13 +15,16 @@ namespace bsr {
 // Per-Gaussian "splat record": everything the tile kernels gather per list entry, exactly one
 // 64-byte cache line:
 //   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, power_cut, opacity, depth)   q2 = (r, g, b, 0)
-//   q3 = bits(inst_offset, xmin | ymin << 16, width | height << 16, kept_mask_lo), q2.w = bits(kept_mask_hi)
+//   q3 = bits(inst_offset (relative to its workgroup's base), xmin | ymin << 16, width | height << 16, kept_mask_lo), q2.w = bits(kept_mask_hi)
 //        (backward only).  kept_mask bit k = the k-th tile (row-major) of the rect is kept; rects of
 //        more than 64 tiles keep every tile and ignore the mask.
 #define BSR_REC 4
 struct GeomState {
 	float4* rec;        // [P][BSR_REC]
-	uint32_t* inst_offset;  // [P] start of the Gaussian's block of kept tile instances (Gaussian-major order)
+	uint32_t* inst_offset;  // [P] start of the Gaussian's block of kept tile instances, relative to wg_base[id / 256]
+	uint32_t* wg_kept;      // [ceil(P/256)] kept instances per preprocess workgroup; exclusive-scanned in place
+	                        //               into the workgroup's base by k_scan_tiles (-> "wg_base")
+	uint32_t* wg_area;      // [ceil(P/256)] rect tiles per preprocess workgroup (sum = reference num_rendered)
 	uint64_t* kept_mask;    // [P] see q3 above
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
 	float* cov3D;       // [P][6]

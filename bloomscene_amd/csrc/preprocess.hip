@@ -225,13 +225,11 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
 		__shared__ uint32_t s_wave[4];
 		__shared__ uint32_t s_area[4];
-		__shared__ uint32_t s_base;
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const uint32_t area_all = (uint32_t)(rect_out.z - rect_out.x) * (uint32_t)(rect_out.w - rect_out.y);
 		const uint32_t n_inst = area_all ? kept_count(area_all, kept_mask) : 0u;
-		// inclusive wave scans of the kept-instance counts (-> instance blocks) and wave sums of the
-		// rect areas (-> the reference's num_rendered); ONE 64-bit atomic per workgroup carries both
-		// running totals (same-address atomics serialise at ~90 per microsecond).
+		// inclusive wave scans of the kept-instance counts (-> instance blocks, relative to the
+		// workgroup) and wave sums of the rect areas (-> the reference's num_rendered)
 		uint32_t incl = n_inst;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -247,14 +245,12 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		}
 		__syncthreads();
 		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-		if (threadIdx.x == 0) {
-			const unsigned long long add = (unsigned long long)(w0 + w1 + w2 + w3) |
-			                               ((unsigned long long)(s_area[0] + s_area[1] + s_area[2] + s_area[3]) << 32);
-			s_base = (uint32_t)atomicAdd((unsigned long long*)&a.flags[2], add);
+		if (threadIdx.x == 0) {   // no atomics: k_scan_tiles prefix-sums these per-workgroup totals
+			a.geom.wg_kept[blockIdx.x] = w0 + w1 + w2 + w3;
+			a.geom.wg_area[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 		}
-		__syncthreads();
 		if (in_range) {
-			const uint32_t off = s_base + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
+			const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
 			a.geom.rect[idx] = rect_out;
 			a.geom.inst_offset[idx] = off;
 			a.geom.kept_mask[idx] = kept_mask;

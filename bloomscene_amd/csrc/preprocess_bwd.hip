@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	{
 		const uint32_t area = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
-		const uint32_t off = n_inst ? a.geom.inst_offset[idx] : 0u;
+		const uint32_t off = n_inst ? a.geom.wg_kept[idx >> 8] + a.geom.inst_offset[idx] : 0u;
 		for (uint32_t k = 0; k < n_inst; k++) {
 			const float4* row = a.slab + (size_t)a.slot_of[off + k] * 3;
 			const float4 s0 = row[0], s1 = row[1], s2 = row[2];

@@ -101,9 +101,10 @@ __device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float 
 // Index of this tile's instance of a Gaussian in the Gaussian-major order of KEPT instances (its
 // block starts at inst_offset and enumerates the kept tiles of its rect row-major), from q3 / q2.w of
 // the splat record.
-__device__ __forceinline__ uint32_t instance_index(const float4 q2, const float4 q3, int tx, int ty)
+__device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ wg_base, uint32_t id, const float4 q2,
+                                                   const float4 q3, int tx, int ty)
 {
-	const uint32_t off = __float_as_uint(q3.x), lo = __float_as_uint(q3.y), wh = __float_as_uint(q3.z);
+	const uint32_t off = wg_base[id >> 8] + __float_as_uint(q3.x), lo = __float_as_uint(q3.y), wh = __float_as_uint(q3.z);
 	const uint32_t xmin = lo & 0xffffu, ymin = lo >> 16, w = wh & 0xffffu, h = wh >> 16;
 	const uint64_t mask = ((uint64_t)__float_as_uint(q2.w) << 32) | (uint64_t)__float_as_uint(q3.w);
 	const uint32_t k = ((uint32_t)ty - ymin) * w + ((uint32_t)tx - xmin);
@@ -121,6 +122,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ rec,
+                                                          const uint32_t* __restrict__ wg_base,
                                                           const float* __restrict__ bg_color,
                                                           const float* __restrict__ final_Ts,
                                                           const uint32_t* __restrict__ n_contrib,
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
-			slot_of[instance_index(r2, r[3], tx, ty)] = my_slot;
+			slot_of[instance_index(wg_base, id, r2, r[3], tx, ty)] = my_slot;
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
 		const uint32_t id = point_list[slot];
-		slot_of[instance_index(rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3], tx, ty)] = slot;
+		slot_of[instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3], tx, ty)] = slot;
 		float4* row = slab + (size_t)slot * 3;
 		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 		row[0] = z;
@@ -294,13 +296,13 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 }
 
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
-                       const float4* rec, const float* bg, const float* final_T, const uint32_t* n_contrib,
-                       const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s)
+                       const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
+                       const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
 	hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
-	                   bg, final_T, n_contrib, dL_dpix, slot_of, slab);
+	                   wg_base, bg, final_T, n_contrib, dL_dpix, slot_of, slab);
 }
 
 }  // namespace bsr
