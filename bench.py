@@ -43,11 +43,10 @@ def algorithmic_bytes(P, M, R, N):
     """Per-stage ALGORITHMIC bytes of one launch (SURVEY.md §8d derivation)."""
     return {
         "preprocess": (44 + 12 * M + 75) * P,
-        "scan_tiles": 8 * (N // 256 + 1),
-        "scatter": 20 * P + 12 * R,
+        "scan_wg": 8 * (P // 256 + 1),
+        "binning": 20 * P + 12 * R,
         "sort_tiles": 24 * R,
         "render_fwd": 4 * R + 40 * P + 24 * N,
-        "inst_offsets": 12 * P,
         "render_bwd": 4 * R + 40 * P + 20 * N + 36 * P,
         "preprocess_bwd": (56 + 36 + 107 + 12 * M + 40 + 12 * M) * P,
     }

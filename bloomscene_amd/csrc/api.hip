@@ -2,9 +2,10 @@
 //
 // Stage order of one forward call (cf. the reference's CudaRasterizer::Rasterizer::forward,
 // cuda_rasterizer/rasterizer_impl.cu:198-339):
-//   memset(tile_count) -> k_preprocess (project, cull, SH, count instances per tile)
-//   -> k_scan_tiles (tile ranges) -> 4-byte D2H read of R -> binning alloc
-//   -> k_scatter -> k_sort_tiles (per-tile LDS sort) -> k_render_fwd.
+//   k_preprocess (project, cull, SH, exact tile cull, Gaussian-major instance numbering)
+//   -> k_scan_wg (workgroup bases, totals) -> 8-byte D2H read (kept, num_rendered) -> binning alloc
+//   -> k_emit -> radix passes on the tile id -> k_tile_ranges -> k_sort_tiles (per-tile LDS sort)
+//   -> k_render_fwd.  No atomics.
 // Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums
 // to a slab, no global atomics) -> k_preprocess_bwd (gathers them per Gaussian, then the chain).
 #include "../../include/bloomscene_rast.h"
@@ -17,6 +18,8 @@
 #include <vector>
 
 namespace bsr {
+
+static constexpr size_t BSR_RADIX_BINS_ = 256;
 
 // ---------------------------------------------------------------- scratch layouts
 size_t GeomState::bytes(size_t P)
@@ -47,19 +50,24 @@ GeomState GeomState::carve(char* p, size_t P)
 }
 size_t BinState::bytes(size_t R)
 {
-	return align_up(R * sizeof(uint64_t), 256) + align_up(R * sizeof(uint32_t), 256) + 256;
+	return 3 * align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(uint64_t), 256) +
+	       align_up((size_t)BSR_RADIX_BINS_ * (BSR_HIST_BLOCKS_MAX + 1) * sizeof(uint32_t), 256) + 256;
 }
 BinState BinState::carve(char* p, size_t R)
 {
 	BinState b;
 	p = (char*)align_up((size_t)p, 256);
-	b.keys = (uint64_t*)p;   p += align_up(R * sizeof(uint64_t), 256);
-	b.point_list = (uint32_t*)p;
+	b.point_list = (uint32_t*)p; p += align_up(R * sizeof(uint32_t), 256);
+	b.keys_a = (uint64_t*)p;     p += align_up(R * sizeof(uint64_t), 256);
+	b.keys_b = (uint64_t*)p;     p += align_up(R * sizeof(uint64_t), 256);
+	b.tiles_a = (uint32_t*)p;    p += align_up(R * sizeof(uint32_t), 256);
+	b.tiles_b = (uint32_t*)p;    p += align_up(R * sizeof(uint32_t), 256);
+	b.hist = (uint32_t*)p;
 	return b;
 }
 size_t ImgState::bytes(size_t N, size_t T)
 {
-	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 2 * align_up(T * 4, 256) + 256 + 256;
+	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + 256;
 }
 ImgState ImgState::carve(char* p, size_t N, size_t T)
 {
@@ -68,8 +76,6 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 	i.final_T = (float*)p;        p += align_up(N * 4, 256);
 	i.n_contrib = (uint32_t*)p;   p += align_up(N * 4, 256);
 	i.tile_start = (uint32_t*)p;  p += align_up((T + 1) * 4, 256);
-	i.tile_count = (uint32_t*)p;  p += align_up(T * 4, 256);
-	i.tile_cursor = (uint32_t*)p; p += align_up(T * 4, 256);
 	i.flags = (int*)p;
 	return i;
 }
@@ -77,12 +83,11 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 // ---------------------------------------------------------------- kernels (other translation units)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
-void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, int n_wg,
-                       uint32_t* wg_kept, const uint32_t* wg_area, int* flags, hipStream_t s);
-void launch_scatter(int P, int gx, const ushort4* rect, const uint64_t* kept_mask, const float4* rec, const uint32_t* tile_start,
-                    uint32_t* tile_cursor, uint64_t* keys, hipStream_t s);
-void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
-                       hipStream_t s);
+void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
+void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint32_t* tiles_a, uint32_t* tiles_b,
+                    uint64_t* keys_a, uint64_t* keys_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start,
+                    uint64_t** keys_sorted, hipStream_t s);
+void launch_sort_tiles(int T, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
@@ -376,10 +381,9 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	GeomState geom = GeomState::carve(geom_p, (size_t)P);
 	ImgState img = ImgState::carve(img_p, N, (size_t)T);
 
-	// tile_count, tile_cursor and flags are contiguous: clear them in one go
-	HIP_TRY(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)img.flags - (char*)img.tile_count) + 4 * sizeof(int), s));
+	HIP_TRY(hipMemsetAsync(img.flags, 0, 4 * sizeof(int), s));
 
-	if (P > 0) {
+	{
 		PreArgs a;
 		memset(&a, 0, sizeof(a));
 		a.P = P; a.D = D; a.M = M;
@@ -390,7 +394,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 		a.focal_y = height / (2.0f * tan_fovy);   // reference rasterizer_impl.cu:223-224
 		a.focal_x = width / (2.0f * tan_fovx);
 		a.gx = gx; a.gy = gy; a.prefiltered = prefiltered; a.radii = radii; a.geom = geom;
-		a.tile_count = img.tile_count; a.flags = img.flags;
+		a.flags = img.flags;
 		{
 			StageTimer t("preprocess", s);
 			launch_preprocess(a, false, s);
@@ -398,41 +402,41 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 		STAGE_CHECK("preprocess", debug, s);
 	}
 	{
-		StageTimer t("scan_tiles", s);
-		launch_scan_tiles(T, img.tile_count, img.tile_start, img.tile_cursor, (P + 255) / 256, geom.wg_kept, geom.wg_area,
-		                  img.flags, s);
+		StageTimer t("scan_wg", s);
+		launch_scan_wg((P + 255) / 256, geom.wg_kept, geom.wg_area, img.flags, s);
 	}
-	STAGE_CHECK("scan_tiles", debug, s);
+	STAGE_CHECK("scan_wg", debug, s);
 
-	// num_rendered (and the prefiltered flag) -> host; the one blocking read of the forward pass
-	uint32_t h_R = 0;
+	// flags[2] = instances kept after the exact tile cull, flags[3] = the reference's num_rendered
+	// (sum of rect areas, rasterizer_impl.cu:278-282) which sizes the scratch -> host; the one
+	// blocking read of the forward pass.
+	uint32_t h_cnt[2] = {0, 0};
 	int h_flag = 0;
-	// The reference's num_rendered = sum of rect areas (rasterizer_impl.cu:278-282); it sizes the scratch.
-	// The number of instances actually kept after exact tile culling stays on the device (tile_start[T]).
-	HIP_TRY(hipMemcpyAsync(&h_R, img.flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipMemcpyAsync(h_cnt, img.flags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	if (prefiltered) HIP_TRY(hipMemcpyAsync(&h_flag, img.flags, sizeof(int), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipStreamSynchronize(s));
 	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
-	const int R = (int)h_R;
+	if (h_cnt[1] > 0x7fffffffu) return fail("too many tile instances (%u)", h_cnt[1]);
+	const int R = (int)h_cnt[1];
+	const int n_kept = (int)h_cnt[0];
 	if (num_rendered) *num_rendered = R;
 
 	char* bin_p = binningBuffer(binning_user, BinState::bytes((size_t)R));
 	if (!bin_p) return fail("scratch allocation callback returned null");
 	BinState bin = BinState::carve(bin_p, (size_t)R);
 
-	if (R > 0) {
-		{
-			StageTimer t("scatter", s);
-			launch_scatter(P, gx, geom.rect, geom.kept_mask, geom.rec, img.tile_start, img.tile_cursor, bin.keys, s);
-		}
-		STAGE_CHECK("scatter", debug, s);
-		{
-			StageTimer t("sort_tiles", s);
-			launch_sort_tiles(T, 0, img.tile_start, bin.keys, bin.point_list, s);
-		}
-		STAGE_CHECK("sort_tiles", debug, s);
+	uint64_t* keys_sorted = bin.keys_a;
+	{
+		StageTimer t("binning", s);
+		launch_binning(P, T, gx, n_kept, geom, bin.tiles_a, bin.tiles_b, bin.keys_a, bin.keys_b, bin.hist,
+		               BSR_HIST_BLOCKS_MAX, img.tile_start, &keys_sorted, s);
 	}
+	STAGE_CHECK("binning", debug, s);
+	if (n_kept > 0) {
+		StageTimer t("sort_tiles", s);
+		launch_sort_tiles(T, img.tile_start, keys_sorted, bin.point_list, s);
+	}
+	STAGE_CHECK("sort_tiles", debug, s);
 	{
 		StageTimer t("render_fwd", s);
 		launch_render_fwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,

@@ -1,36 +1,47 @@
-// Per-tile binning and depth sort.
+// Per-tile binning and depth sort -- no atomics anywhere.
 //
 // The reference emits one 64-bit (tile | depth) key per (Gaussian, tile) instance in Gaussian order
-// and runs a global stable radix sort over all R instances (rasterizer_impl.cu:70-111,304-309 under
+// and runs a global stable radix sort over all R instances on 32+bit key bits, six 8-bit passes at
+// 1080p (rasterizer_impl.cu:70-111,304-309 under
 // /root/reference/submodules/depth-diff-gaussian-rasterization), then finds tile ranges
-// (:116-138).  The resulting order is (tile, depth bit pattern, Gaussian id).  Here the same
-// order is produced without a global sort:
-//   1. k_preprocess counted the instances of every tile (tile_count), dropping (Gaussian, tile)
-//      pairs whose tile the splat provably cannot reach with alpha >= 1/255 (exact, conservative
-//      ellipse-vs-tile test; ~1/3 of the reference's instances on the synthetic scenes): the
-//      lists are order-preserving sub-sequences of the reference's and every pixel is unchanged,
-//   2. k_scan_tiles turns the counts into tile ranges (one workgroup; <= a few 10k tiles),
-//   3. k_scatter appends each instance's (depth_bits << 32 | id) key to its tile's segment
-//      (atomic cursor -> arbitrary order inside the segment),
-//   4. k_sort_tiles sorts each segment by that 64-bit key in LDS (bitonic network), which
-//      restores exactly the stable-sort order because ids are unique within a tile.
-// Traffic: 8 B written + 8 B read + 4 B written per instance instead of six 24-B radix passes.
+// (:116-138).  The resulting order is (tile, depth bit pattern, Gaussian id).  Here:
+//   1. k_preprocess decided per (Gaussian, tile) whether the splat can reach the tile at all
+//      (exact conservative ellipse-vs-tile test; ~1/3 of the reference's instances are dropped on the
+//      synthetic scenes, no pixel changes) and numbered the kept instances Gaussian-major inside
+//      its workgroup; k_scan_wg prefix-sums the workgroup totals (one workgroup, <= 20k values),
+//   2. k_emit writes every kept instance's tile id and (depth_bits << 32 | id) key at its
+//      Gaussian-major position (coalesced, one thread per Gaussian),
+//   3. ceil(bits(T)/8) stable LSD radix passes on the TILE ID only (1080p: 2 passes over 12-byte
+//      elements instead of the reference's 6 over 12-byte elements): per-workgroup digit histogram
+//      -> 256 parallel row scans -> stable scatter (wave ballots for the in-round rank, stamped
+//      per-wave counters across the 4 waves),
+//   4. k_tile_ranges finds each tile's segment by binary search in the sorted tile ids,
+//   5. k_sort_tiles sorts each segment by its 64-bit key in LDS (bitonic network), which yields
+//      exactly the reference's stable-sort order because ids are unique within a tile.
+// The earlier version counted and appended instances with global integer atomics (~20 G/s when
+// lane-scattered on MI355X: 0.2 ms at C3, 1.4 ms at C5); this one is also fully deterministic.
 #include "common.h"
 
 namespace bsr {
 
-// ---- exclusive scan of tile_count -> tile_start[0..T], total in tile_start[T]; zero cursors ----
-// Exclusive scan of n values in place (dst may alias src), one 1024-thread workgroup; returns the total.
-__device__ __forceinline__ uint32_t block_exclusive_scan(int n, const uint32_t* src, uint32_t* dst, uint32_t* s_wave,
-                                                         uint32_t* s_carry, bool write)
+#define BSR_RADIX_BITS 8
+#define BSR_RADIX_BINS 256
+
+// Exclusive scan of n uint32 in place by ONE 1024-thread workgroup, 4 values per thread and step.
+// Returns the total to every thread.
+__device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, uint32_t* s_wave, uint32_t* s_carry,
+                                                         bool write)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if (tid == 0) *s_carry = 0;
 	__syncthreads();
-	for (int base = 0; base < n; base += 1024) {
-		const int i = base + tid;
-		const uint32_t v = (i < n) ? src[i] : 0u;
-		uint32_t incl = v;
+	for (int base = 0; base < n; base += 4096) {
+		const int i = base + tid * 4;
+		uint32_t v[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) v[k] = (i + k < n) ? data[i + k] : 0u;
+		const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+		uint32_t incl = mine;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t t = __shfl_up(incl, d, 64);
@@ -41,7 +52,14 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int n, const uint32_t* 
 		uint32_t wave_off = 0;
 		for (int w = 0; w < wave; w++) wave_off += s_wave[w];
 		const uint32_t carry = *s_carry;
-		if (write && i < n) dst[i] = carry + wave_off + incl - v;
+		uint32_t run = carry + wave_off + incl - mine;
+		if (write) {
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				if (i + k < n) data[i + k] = run;
+				run += v[k];
+			}
+		}
 		__syncthreads();
 		if (tid == 1023) *s_carry = carry + wave_off + incl;
 		__syncthreads();
@@ -49,74 +67,177 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int n, const uint32_t* 
 	return *s_carry;
 }
 
-__global__ void __launch_bounds__(1024) k_scan_tiles(int T, const uint32_t* __restrict__ tile_count,
-                                                     uint32_t* __restrict__ tile_start,
-                                                     uint32_t* __restrict__ tile_cursor, int n_wg,
-                                                     uint32_t* __restrict__ wg_kept,
-                                                     const uint32_t* __restrict__ wg_area, int* __restrict__ flags)
+// Per-preprocess-workgroup totals: kept instances -> workgroup bases (in place) and flags[2] = total
+// kept; rect tiles -> flags[3] = the reference's num_rendered.
+__global__ void __launch_bounds__(1024) k_scan_wg(int n_wg, uint32_t* __restrict__ wg_kept,
+                                                  uint32_t* __restrict__ wg_area, int* __restrict__ flags)
 {
-	{   // per-preprocess-workgroup totals: kept instances -> bases (in place), rect tiles -> num_rendered
-		__shared__ uint32_t s_w[16];
-		__shared__ uint32_t s_c;
-		block_exclusive_scan(n_wg, wg_kept, wg_kept, s_w, &s_c, true);
-		__syncthreads();
-		const uint32_t total_area = block_exclusive_scan(n_wg, wg_area, nullptr, s_w, &s_c, false);
-		if (threadIdx.x == 0) flags[3] = (int)total_area;
-		__syncthreads();
+	__shared__ uint32_t s_w[16];
+	__shared__ uint32_t s_c;
+	const uint32_t kept = block_exclusive_scan(n_wg, wg_kept, s_w, &s_c, true);
+	__syncthreads();
+	const uint32_t area = block_exclusive_scan(n_wg, wg_area, s_w, &s_c, false);
+	if (threadIdx.x == 0) {
+		flags[2] = (int)kept;
+		flags[3] = (int)area;
 	}
-	__shared__ uint32_t s_wave[16];
+}
+
+// One workgroup per digit d: exclusive scan of row d of the digit-major histogram (in place) and the
+// row total.  256 short, independent scans instead of one long latency-bound one.
+__global__ void __launch_bounds__(256) k_radix_rowscan(int n_blocks, uint32_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ digit_total)
+{
+	__shared__ uint32_t s_wave[4];
 	__shared__ uint32_t s_carry;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint32_t* row = hist + (size_t)blockIdx.x * n_blocks;
 	if (tid == 0) s_carry = 0;
 	__syncthreads();
-	for (int base = 0; base < T; base += 1024) {
+	for (int base = 0; base < n_blocks; base += 256) {
 		const int i = base + tid;
-		const uint32_t v = (i < T) ? tile_count[i] : 0u;
-		uint32_t incl = v;   // inclusive wave scan
+		const uint32_t v = (i < n_blocks) ? row[i] : 0u;
+		uint32_t incl = v;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t n = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += n;
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
 		}
 		if (lane == 63) s_wave[wave] = incl;
 		__syncthreads();
-		uint32_t wave_off = 0;
-		for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
 		const uint32_t carry = s_carry;
-		if (i < T) {
-			tile_start[i] = carry + wave_off + incl - v;
-			tile_cursor[i] = 0;
-		}
+		if (i < n_blocks) row[i] = carry + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - v;
 		__syncthreads();
-		if (tid == 1023) s_carry = carry + wave_off + incl;
+		if (tid == 0) s_carry = carry + w0 + w1 + w2 + w3;
 		__syncthreads();
 	}
-	if (tid == 0) tile_start[T] = s_carry;
+	if (tid == 0) digit_total[blockIdx.x] = s_carry;
 }
 
-// ---- append every instance to its tile's segment ----
-__global__ void __launch_bounds__(256) k_scatter(int P, int gx, const ushort4* __restrict__ rect,
-                                                 const uint64_t* __restrict__ kept_mask,
-                                                 const float4* __restrict__ rec,
-                                                 const uint32_t* __restrict__ tile_start,
-                                                 uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys)
+// ---- every kept instance at its Gaussian-major position ----
+__global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __restrict__ rect,
+                                              const uint64_t* __restrict__ kept_mask,
+                                              const uint32_t* __restrict__ inst_offset,
+                                              const uint32_t* __restrict__ wg_base, const float4* __restrict__ rec,
+                                              uint32_t* __restrict__ tiles, uint64_t* __restrict__ keys)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
 	const ushort4 r = rect[idx];
 	if (r.z <= r.x || r.w <= r.y) return;
-	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
-	const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
 	const uint32_t area = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
 	const uint64_t mask = kept_mask[idx];
+	if (kept_count(area, mask) == 0) return;
+	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
+	const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
+	uint32_t pos = wg_base[idx >> 8] + inst_offset[idx];
 	uint32_t k = 0;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
-			if (!tile_kept(area, mask, k)) continue;   // same decision as the count in k_preprocess
-			const int t = y * gx + x;
-			const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+			if (!tile_kept(area, mask, k)) continue;
+			tiles[pos] = (uint32_t)(y * gx + x);
 			keys[pos] = key;
+			pos++;
 		}
+}
+
+// ---- stable LSD radix pass on bits [shift, shift+8) of the tile id ----
+// Workgroup b owns elements [b*chunk, (b+1)*chunk).  hist is digit-major: hist[d * n_blocks + b].
+__global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift, const uint32_t* __restrict__ tiles,
+                                                    uint32_t* __restrict__ hist, int n_blocks)
+{
+	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
+	const int tid = threadIdx.x;
+	s_hist[tid] = 0;
+	__syncthreads();
+	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
+	for (int i = beg + tid; i < end; i += 256) atomicAdd(&s_hist[(tiles[i] >> shift) & (BSR_RADIX_BINS - 1)], 1u);
+	__syncthreads();
+	hist[(size_t)tid * n_blocks + blockIdx.x] = s_hist[tid];
+}
+
+__global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shift,
+                                                       const uint32_t* __restrict__ tiles_in,
+                                                       const uint64_t* __restrict__ keys_in,
+                                                       uint32_t* __restrict__ tiles_out,
+                                                       uint64_t* __restrict__ keys_out,
+                                                       const uint32_t* __restrict__ hist,
+                                                       const uint32_t* __restrict__ digit_total, int n_blocks)
+{
+	__shared__ uint32_t s_off[BSR_RADIX_BINS];        // next output position per digit for this workgroup
+	__shared__ uint32_t s_wcnt[4][BSR_RADIX_BINS];    // (round << 8 | count) per wave and digit, stamped
+	__shared__ uint32_t s_scan[4];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this block's row prefix
+		const uint32_t v = digit_total[tid];
+		uint32_t incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		if (lane == 63) s_scan[wave] = incl;
+		__syncthreads();
+		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
+		s_off[tid] = base + hist[(size_t)tid * n_blocks + blockIdx.x];
+	}
+#pragma unroll
+	for (int w = 0; w < 4; w++) s_wcnt[w][tid] = 0;
+	__syncthreads();
+	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	uint32_t round = 1;
+	for (int base = beg; base < end; base += 256, round++) {
+		const int i = base + tid;
+		const bool valid = i < end;
+		uint32_t tile = 0;
+		uint64_t key = 0;
+		if (valid) {
+			tile = tiles_in[i];
+			key = keys_in[i];
+		}
+		const uint32_t d = (tile >> shift) & (BSR_RADIX_BINS - 1);
+		// lanes of this wave with the same digit (invalid lanes match nobody)
+		unsigned long long peers = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < BSR_RADIX_BITS; b++) {
+			const bool bit = (d >> b) & 1u;
+			const unsigned long long m = __ballot(bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t rank_w = (uint32_t)__popcll(peers & lt);
+		const uint32_t cnt_w = (uint32_t)__popcll(peers);
+		if (valid && rank_w == 0) s_wcnt[wave][d] = (round << 8) | cnt_w;
+		__syncthreads();
+		uint32_t lower = 0;
+		if (valid) {
+#pragma unroll
+			for (int w = 0; w < 4; w++) {
+				const uint32_t c = s_wcnt[w][d];
+				if (w < wave && (c >> 8) == round) lower += c & 0xffu;
+			}
+			const uint32_t pos = s_off[d] + lower + rank_w;
+			tiles_out[pos] = tile;
+			keys_out[pos] = key;
+		}
+		__syncthreads();
+		if (valid && rank_w == 0) atomicAdd(&s_off[d], cnt_w);   // LDS; order irrelevant, positions are taken
+	}
+}
+
+// ---- tile ranges: tile_start[t] = first sorted position whose tile id is >= t ----
+__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint32_t* __restrict__ tiles_sorted,
+                                                     uint32_t* __restrict__ tile_start)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	if (t > T) return;
+	int lo = 0, hi = n;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (tiles_sorted[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+	}
+	tile_start[t] = (uint32_t)lo;
 }
 
 // ---- per-tile bitonic sort of 64-bit keys ----
@@ -187,25 +308,43 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles_global(int T, int min_
 	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)keys[start + i];
 }
 
-void launch_scan_tiles(int T, const uint32_t* tile_count, uint32_t* tile_start, uint32_t* tile_cursor, int n_wg,
-                       uint32_t* wg_kept, const uint32_t* wg_area, int* flags, hipStream_t s)
+void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_count, tile_start, tile_cursor, n_wg, wg_kept,
-	                   wg_area, flags);
+	hipLaunchKernelGGL(k_scan_wg, dim3(1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags);
 }
 
-void launch_scatter(int P, int gx, const ushort4* rect, const uint64_t* kept_mask, const float4* rec,
-                    const uint32_t* tile_start, uint32_t* tile_cursor, uint64_t* keys, hipStream_t s)
+// Bins n kept instances: emit -> radix passes on the tile id -> tile ranges.  keys_a/tiles_a and
+// keys_b/tiles_b ping-pong; returns (through *keys_sorted) the buffer holding the final keys.
+void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint32_t* tiles_a, uint32_t* tiles_b,
+                    uint64_t* keys_a, uint64_t* keys_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start,
+                    uint64_t** keys_sorted, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, rect, kept_mask, rec, tile_start,
-	                   tile_cursor, keys);
+	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, geom.rect, geom.kept_mask,
+	                   geom.inst_offset, geom.wg_kept, geom.rec, tiles_a, keys_a);
+	int bits = 0;
+	while ((1 << bits) < T) bits++;
+	// chunk: multiple of 256, at least 1024 elements, at most hist_blocks_max workgroups
+	int chunk = ((n + hist_blocks_max - 1) / hist_blocks_max + 255) / 256 * 256;
+	if (chunk < 1024) chunk = 1024;
+	const int n_blocks = (n + chunk - 1) / chunk;
+	uint32_t* digit_total = hist + (size_t)BSR_RADIX_BINS * hist_blocks_max;
+	uint32_t* ti = tiles_a; uint32_t* to = tiles_b;
+	uint64_t* ki = keys_a; uint64_t* ko = keys_b;
+	for (int shift = 0; shift < bits; shift += BSR_RADIX_BITS) {
+		hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ti, hist, n_blocks);
+		hipLaunchKernelGGL(k_radix_rowscan, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_blocks, hist, digit_total);
+		hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ti, ki, to, ko, hist,
+		                   digit_total, n_blocks);
+		uint32_t* tt = ti; ti = to; to = tt;
+		uint64_t* kk = ki; ki = ko; ko = kk;
+	}
+	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ti, tile_start);
+	*keys_sorted = ki;
 }
 
 // Size classes: (0, 1024] -> 8 KB LDS, (1024, 8192] -> 64 KB LDS, > 8192 -> global memory.
-void launch_sort_tiles(int T, int max_tile_hint, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list,
-                       hipStream_t s)
+void launch_sort_tiles(int T, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list, hipStream_t s)
 {
-	(void)max_tile_hint;
 	hipLaunchKernelGGL(k_sort_tiles<1024>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 0, tile_start, keys, point_list);
 	hipLaunchKernelGGL(k_sort_tiles<8192>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 1024, tile_start, keys, point_list);
 	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_BLOCK), 0, s, T, 8192, tile_start, keys, point_list);

@@ -32,18 +32,21 @@ struct GeomState {
 	static size_t bytes(size_t P);
 	static GeomState carve(char* p, size_t P);
 };
+#define BSR_HIST_BLOCKS_MAX 2048
 struct BinState {
-	uint64_t* keys;       // [R] (depth_bits << 32 | gaussian id), tile-major, unsorted then sorted
-	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted
+	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
+	uint64_t* keys_a;     // [R] (depth_bits << 32 | gaussian id); ping-pong buffers of the radix passes
+	uint64_t* keys_b;     // [R]
+	uint32_t* tiles_a;    // [R] tile id of every instance
+	uint32_t* tiles_b;    // [R]
+	uint32_t* hist;       // [256 * BSR_HIST_BLOCKS_MAX] digit-major workgroup histograms, then [256] digit totals
 	static size_t bytes(size_t R);
 	static BinState carve(char* p, size_t R);
 };
 struct ImgState {
 	float* final_T;        // [N]
 	uint32_t* n_contrib;   // [N]
-	uint32_t* tile_start;  // [T + 1] exclusive scan of tile_count; ranges[t] = [start[t], start[t+1])
-	uint32_t* tile_count;  // [T]
-	uint32_t* tile_cursor; // [T]
+	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
 	int* flags;            // [4]: prefiltered violation | - | kept instances | rect tiles (= reference num_rendered)
 	static size_t bytes(size_t N, size_t T);
 	static ImgState carve(char* p, size_t N, size_t T);
@@ -69,8 +72,7 @@ struct PreArgs {
 	int prefiltered;
 	int* radii;          // may be NULL
 	GeomState geom;
-	uint32_t* tile_count;
-	int* flags;            // [0] prefiltered violation, [2] running total of kept instances, [3] of rect tiles (one u64)
+	int* flags;            // [0] prefiltered violation, [2] kept instances, [3] rect tiles (both set by k_scan_wg)
 };
 
 struct BwdArgs {

@@ -171,17 +171,14 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
 					rec[1] = make_float4(conic_c, power_cut, opacity, pvz);
 					a.geom.clamped[idx] = clamp_bits;
-					// Count one instance per tile of the rect the splat can actually reach: the reference
+					// Keep one instance per tile of the rect the splat can actually reach: the reference
 					// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
 					// alpha < 1/255 everywhere only ever `continue` in its render loops, so dropping them
 					// changes no pixel.  Rects of more than 64 tiles are kept whole (mask too short).
 					const uint32_t area = (uint32_t)(rmax[0] - rmin[0]) * (uint32_t)(rmax[1] - rmin[1]);
 					const bool pd = (conic_a > 0.0f) && (conic_c > 0.0f) && (conic_a * conic_c - conic_b * conic_b > 0.0f);
 					const float rb_c = -conic_b / conic_c, rb_a = -conic_b / conic_a;
-					if (area > 64u) {
-						for (int y = rmin[1]; y < rmax[1]; y++)
-							for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
-					} else {
+					if (area <= 64u) {
 						// Axis-aligned bounding box of the region {alpha >= 1/255} = {q(d) <= t}, t = -(cut - slack):
 						// |dx| <= sqrt(2 t c / det), |dy| <= sqrt(2 t a / det).  Tiles outside it are dropped
 						// without the edge test; NaN / non-PD conics fall back to the whole rect.
@@ -207,10 +204,8 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 						for (int y = y0; y < y1; y++)
 							for (int x = x0; x < x1; x++) {
 								if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
-								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
-									atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE)))
 									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
-								}
 							}
 					}
 					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));

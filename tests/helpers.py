@@ -182,8 +182,7 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     out.kept = int(out.tile_start[T]) if R > 0 else 0
     if R > 0:
         b = bin_t.cpu().numpy()
-        off = _al(R * 8)
-        out.point_list = b[off:off + out.kept * 4].view(np.uint32)
+        out.point_list = b[0:out.kept * 4].view(np.uint32)   # point_list is the first section
     else:
         out.point_list = np.zeros(0, dtype=np.uint32)
     return out

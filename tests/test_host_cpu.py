@@ -31,8 +31,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
     assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)
     assert lib.bsr_geometry_bytes(1000) >= 1000 * (64 + 4 + 8 + 24 + 1)
-    assert lib.bsr_binning_bytes(1000) >= 1000 * 12
-    assert lib.bsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 12
+    assert lib.bsr_binning_bytes(1000) >= 1000 * 28
+    assert lib.bsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 4
 
 
 def test_every_entry_point_cites_the_reference_interface_it_replaces():
@@ -172,7 +172,7 @@ def test_algorithmic_byte_model_is_consistent():
     import bench
     P, M, R, N = 1_000_000, 16, 4_380_000, 1920 * 1080
     a = bench.algorithmic_bytes(P, M, R, N)
-    fwd = a["preprocess"] + 8 * P + a["scatter"] + a["sort_tiles"] + 8 * R + a["render_fwd"]
+    fwd = a["preprocess"] + 8 * P + a["binning"] + a["sort_tiles"] + 8 * R + a["render_fwd"]
     assert abs(fwd - bench.step_bytes(P, M, R, N, False)) / fwd < 0.01
     total = fwd + a["render_bwd"] + a["preprocess_bwd"]
     assert abs(total - bench.step_bytes(P, M, R, N, True)) / total < 0.01
