@@ -50,7 +50,7 @@ GeomState GeomState::carve(char* p, size_t P)
 }
 size_t BinState::bytes(size_t R)
 {
-	return 3 * align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(uint64_t), 256) +
+	return align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(uint4), 256) +
 	       align_up((size_t)BSR_RADIX_BINS_ * (BSR_HIST_BLOCKS_MAX + 1) * sizeof(uint32_t), 256) + 256;
 }
 BinState BinState::carve(char* p, size_t R)
@@ -58,10 +58,8 @@ BinState BinState::carve(char* p, size_t R)
 	BinState b;
 	p = (char*)align_up((size_t)p, 256);
 	b.point_list = (uint32_t*)p; p += align_up(R * sizeof(uint32_t), 256);
-	b.keys_a = (uint64_t*)p;     p += align_up(R * sizeof(uint64_t), 256);
-	b.keys_b = (uint64_t*)p;     p += align_up(R * sizeof(uint64_t), 256);
-	b.tiles_a = (uint32_t*)p;    p += align_up(R * sizeof(uint32_t), 256);
-	b.tiles_b = (uint32_t*)p;    p += align_up(R * sizeof(uint32_t), 256);
+	b.elems_a = (uint4*)p;       p += align_up(R * sizeof(uint4), 256);
+	b.elems_b = (uint4*)p;       p += align_up(R * sizeof(uint4), 256);
 	b.hist = (uint32_t*)p;
 	return b;
 }
@@ -84,10 +82,10 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
-void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint32_t* tiles_a, uint32_t* tiles_b,
-                    uint64_t* keys_a, uint64_t* keys_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start,
-                    uint64_t** keys_sorted, hipStream_t s);
-void launch_sort_tiles(int T, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list, hipStream_t s);
+void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
+                    int hist_blocks_max, uint32_t* tile_start, uint4** elems_sorted, uint4** elems_free, hipStream_t s);
+void launch_sort_tiles(int T, const uint32_t* tile_start, const uint4* elems, uint4* elems_free, uint32_t* point_list,
+                       hipStream_t s);
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
@@ -425,16 +423,17 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	if (!bin_p) return fail("scratch allocation callback returned null");
 	BinState bin = BinState::carve(bin_p, (size_t)R);
 
-	uint64_t* keys_sorted = bin.keys_a;
+	uint4* elems_sorted = bin.elems_a;
+	uint4* elems_free = bin.elems_b;
 	{
 		StageTimer t("binning", s);
-		launch_binning(P, T, gx, n_kept, geom, bin.tiles_a, bin.tiles_b, bin.keys_a, bin.keys_b, bin.hist,
-		               BSR_HIST_BLOCKS_MAX, img.tile_start, &keys_sorted, s);
+		launch_binning(P, T, gx, n_kept, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX, img.tile_start,
+		               &elems_sorted, &elems_free, s);
 	}
 	STAGE_CHECK("binning", debug, s);
 	if (n_kept > 0) {
 		StageTimer t("sort_tiles", s);
-		launch_sort_tiles(T, img.tile_start, keys_sorted, bin.point_list, s);
+		launch_sort_tiles(T, img.tile_start, elems_sorted, elems_free, bin.point_list, s);
 	}
 	STAGE_CHECK("sort_tiles", debug, s);
 	{

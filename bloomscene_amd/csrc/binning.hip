@@ -9,10 +9,10 @@
 //      (exact conservative ellipse-vs-tile test; ~1/3 of the reference's instances are dropped on the
 //      synthetic scenes, no pixel changes) and numbered the kept instances Gaussian-major inside
 //      its workgroup; k_scan_wg prefix-sums the workgroup totals (one workgroup, <= 20k values),
-//   2. k_emit writes every kept instance's tile id and (depth_bits << 32 | id) key at its
-//      Gaussian-major position (coalesced, one thread per Gaussian),
-//   3. ceil(bits(T)/8) stable LSD radix passes on the TILE ID only (1080p: 2 passes over 12-byte
-//      elements instead of the reference's 6 over 12-byte elements): per-workgroup digit histogram
+//   2. k_emit writes every kept instance as one 16-byte element (tile id, Gaussian id, depth bits)
+//      at its Gaussian-major position (coalesced, one thread per Gaussian),
+//   3. ceil(bits(T)/8) stable LSD radix passes on the TILE ID only (1080p: 2 passes instead of the
+//      reference's 6; elements move as single 16-byte loads/stores): per-workgroup digit histogram
 //      -> 256 parallel row scans -> stable scatter (wave ballots for the in-round rank, stamped
 //      per-wave counters across the 4 waves),
 //   4. k_tile_ranges finds each tile's segment by binary search in the sorted tile ids,
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __re
                                               const uint64_t* __restrict__ kept_mask,
                                               const uint32_t* __restrict__ inst_offset,
                                               const uint32_t* __restrict__ wg_base, const float4* __restrict__ rec,
-                                              uint32_t* __restrict__ tiles, uint64_t* __restrict__ keys)
+                                              uint4* __restrict__ elems)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
@@ -130,21 +130,19 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __re
 	const uint64_t mask = kept_mask[idx];
 	if (kept_count(area, mask) == 0) return;
 	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
-	const uint64_t key = ((uint64_t)depth_bits << 32) | (uint32_t)idx;
 	uint32_t pos = wg_base[idx >> 8] + inst_offset[idx];
 	uint32_t k = 0;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
 			if (!tile_kept(area, mask, k)) continue;
-			tiles[pos] = (uint32_t)(y * gx + x);
-			keys[pos] = key;
+			elems[pos] = make_uint4((uint32_t)(y * gx + x), (uint32_t)idx, depth_bits, 0u);   // one 16-B store
 			pos++;
 		}
 }
 
 // ---- stable LSD radix pass on bits [shift, shift+8) of the tile id ----
 // Workgroup b owns elements [b*chunk, (b+1)*chunk).  hist is digit-major: hist[d * n_blocks + b].
-__global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift, const uint32_t* __restrict__ tiles,
+__global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift, const uint4* __restrict__ elems,
                                                     uint32_t* __restrict__ hist, int n_blocks)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
@@ -152,16 +150,14 @@ __global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift,
 	s_hist[tid] = 0;
 	__syncthreads();
 	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
-	for (int i = beg + tid; i < end; i += 256) atomicAdd(&s_hist[(tiles[i] >> shift) & (BSR_RADIX_BINS - 1)], 1u);
+	for (int i = beg + tid; i < end; i += 256) atomicAdd(&s_hist[(elems[i].x >> shift) & (BSR_RADIX_BINS - 1)], 1u);
 	__syncthreads();
 	hist[(size_t)tid * n_blocks + blockIdx.x] = s_hist[tid];
 }
 
 __global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shift,
-                                                       const uint32_t* __restrict__ tiles_in,
-                                                       const uint64_t* __restrict__ keys_in,
-                                                       uint32_t* __restrict__ tiles_out,
-                                                       uint64_t* __restrict__ keys_out,
+                                                       const uint4* __restrict__ elems_in,
+                                                       uint4* __restrict__ elems_out,
                                                        const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ digit_total, int n_blocks)
 {
@@ -191,13 +187,9 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shi
 	for (int base = beg; base < end; base += 256, round++) {
 		const int i = base + tid;
 		const bool valid = i < end;
-		uint32_t tile = 0;
-		uint64_t key = 0;
-		if (valid) {
-			tile = tiles_in[i];
-			key = keys_in[i];
-		}
-		const uint32_t d = (tile >> shift) & (BSR_RADIX_BINS - 1);
+		uint4 e = make_uint4(0u, 0u, 0u, 0u);
+		if (valid) e = elems_in[i];
+		const uint32_t d = (e.x >> shift) & (BSR_RADIX_BINS - 1);
 		// lanes of this wave with the same digit (invalid lanes match nobody)
 		unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -218,8 +210,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shi
 				if (w < wave && (c >> 8) == round) lower += c & 0xffu;
 			}
 			const uint32_t pos = s_off[d] + lower + rank_w;
-			tiles_out[pos] = tile;
-			keys_out[pos] = key;
+			elems_out[pos] = e;
 		}
 		__syncthreads();
 		if (valid && rank_w == 0) atomicAdd(&s_off[d], cnt_w);   // LDS; order irrelevant, positions are taken
@@ -227,7 +218,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shi
 }
 
 // ---- tile ranges: tile_start[t] = first sorted position whose tile id is >= t ----
-__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint32_t* __restrict__ tiles_sorted,
+__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint4* __restrict__ elems_sorted,
                                                      uint32_t* __restrict__ tile_start)
 {
 	const int t = blockIdx.x * 256 + threadIdx.x;
@@ -235,7 +226,7 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint32_
 	int lo = 0, hi = n;
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
-		if (tiles_sorted[mid] < (uint32_t)t) lo = mid + 1; else hi = mid;
+		if (elems_sorted[mid].x < (uint32_t)t) lo = mid + 1; else hi = mid;
 	}
 	tile_start[t] = (uint32_t)lo;
 }
@@ -278,9 +269,11 @@ __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 	__syncthreads();
 }
 
+__device__ __forceinline__ uint64_t elem_key(const uint4 e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
+
 template <int CAP>
 __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles(int T, int min_n, const uint32_t* __restrict__ tile_start,
-                                                           const uint64_t* __restrict__ keys,
+                                                           const uint4* __restrict__ elems,
                                                            uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[CAP];
@@ -290,13 +283,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles(int T, int min_n, cons
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n <= min_n || n > CAP) return;   // handled by another size class
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += BSR_BLOCK) s_keys[i] = keys[start + i];
+	for (int i = tid; i < n; i += BSR_BLOCK) s_keys[i] = elem_key(elems[start + i]);
 	bitonic_sort_asc(s_keys, n, tid);
 	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)s_keys[i];
 }
 
+// keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
 __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles_global(int T, int min_n, const uint32_t* __restrict__ tile_start,
-                                                                  uint64_t* keys, uint32_t* __restrict__ point_list)
+                                                                  const uint4* __restrict__ elems, uint64_t* keys,
+                                                                  uint32_t* __restrict__ point_list)
 {
 	const int tile = blockIdx.x;
 	if (tile >= T) return;
@@ -304,6 +299,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles_global(int T, int min_
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n <= min_n) return;
 	const int tid = threadIdx.x;
+	for (int i = tid; i < n; i += BSR_BLOCK) keys[start + i] = elem_key(elems[start + i]);
 	bitonic_sort_asc(keys + start, n, tid);
 	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)keys[start + i];
 }
@@ -315,12 +311,11 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 
 // Bins n kept instances: emit -> radix passes on the tile id -> tile ranges.  keys_a/tiles_a and
 // keys_b/tiles_b ping-pong; returns (through *keys_sorted) the buffer holding the final keys.
-void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint32_t* tiles_a, uint32_t* tiles_b,
-                    uint64_t* keys_a, uint64_t* keys_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start,
-                    uint64_t** keys_sorted, hipStream_t s)
+void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
+                    int hist_blocks_max, uint32_t* tile_start, uint4** elems_sorted, uint4** elems_free, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, geom.rect, geom.kept_mask,
-	                   geom.inst_offset, geom.wg_kept, geom.rec, tiles_a, keys_a);
+	                   geom.inst_offset, geom.wg_kept, geom.rec, elems_a);
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
 	// chunk: multiple of 256, at least 1024 elements, at most hist_blocks_max workgroups
@@ -328,26 +323,27 @@ void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint32_t
 	if (chunk < 1024) chunk = 1024;
 	const int n_blocks = (n + chunk - 1) / chunk;
 	uint32_t* digit_total = hist + (size_t)BSR_RADIX_BINS * hist_blocks_max;
-	uint32_t* ti = tiles_a; uint32_t* to = tiles_b;
-	uint64_t* ki = keys_a; uint64_t* ko = keys_b;
+	uint4* ei = elems_a; uint4* eo = elems_b;
 	for (int shift = 0; shift < bits; shift += BSR_RADIX_BITS) {
-		hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ti, hist, n_blocks);
+		hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ei, hist, n_blocks);
 		hipLaunchKernelGGL(k_radix_rowscan, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_blocks, hist, digit_total);
-		hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ti, ki, to, ko, hist,
-		                   digit_total, n_blocks);
-		uint32_t* tt = ti; ti = to; to = tt;
-		uint64_t* kk = ki; ki = ko; ko = kk;
+		hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ei, eo, hist, digit_total,
+		                   n_blocks);
+		uint4* tt = ei; ei = eo; eo = tt;
 	}
-	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ti, tile_start);
-	*keys_sorted = ki;
+	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ei, tile_start);
+	*elems_sorted = ei;
+	*elems_free = eo;
 }
 
 // Size classes: (0, 1024] -> 8 KB LDS, (1024, 8192] -> 64 KB LDS, > 8192 -> global memory.
-void launch_sort_tiles(int T, const uint32_t* tile_start, uint64_t* keys, uint32_t* point_list, hipStream_t s)
+void launch_sort_tiles(int T, const uint32_t* tile_start, const uint4* elems, uint4* elems_free, uint32_t* point_list,
+                       hipStream_t s)
 {
-	hipLaunchKernelGGL(k_sort_tiles<1024>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 0, tile_start, keys, point_list);
-	hipLaunchKernelGGL(k_sort_tiles<8192>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 1024, tile_start, keys, point_list);
-	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_BLOCK), 0, s, T, 8192, tile_start, keys, point_list);
+	hipLaunchKernelGGL(k_sort_tiles<1024>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 0, tile_start, elems, point_list);
+	hipLaunchKernelGGL(k_sort_tiles<8192>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 1024, tile_start, elems, point_list);
+	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_BLOCK), 0, s, T, 8192, tile_start, elems,
+	                   reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 
 }  // namespace bsr

@@ -35,10 +35,8 @@ struct GeomState {
 #define BSR_HIST_BLOCKS_MAX 2048
 struct BinState {
 	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
-	uint64_t* keys_a;     // [R] (depth_bits << 32 | gaussian id); ping-pong buffers of the radix passes
-	uint64_t* keys_b;     // [R]
-	uint32_t* tiles_a;    // [R] tile id of every instance
-	uint32_t* tiles_b;    // [R]
+	uint4* elems_a;       // [R] (tile id, gaussian id, depth bits, -): ping-pong buffers of the radix passes
+	uint4* elems_b;       // [R]
 	uint32_t* hist;       // [256 * BSR_HIST_BLOCKS_MAX] digit-major workgroup histograms, then [256] digit totals
 	static size_t bytes(size_t R);
 	static BinState carve(char* p, size_t R);
