@@ -53,7 +53,10 @@ int bsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * cov3D_precomp must be non-NULL.  background, viewmatrix, projmatrix, cam_pos are DEVICE
  * float[3]/[16]/[16]/[3].  debug != 0: synchronise and check after every stage.  prefiltered != 0:
  * a culled Gaussian is an error (the reference printf+__trap()s, auxiliary.h:156-160).
- * Performs one blocking 4-byte device->host read, like rasterizer_impl.cu:282.
+ * Performs one blocking 8-byte device->host read (the reference reads 4 bytes, rasterizer_impl.cu:282).
+ * *num_rendered is the reference's value (sum over Gaussians of the tiles of their bounding rect,
+ * rasterizer_impl.cu:278-282); it sizes the binning scratch.  Instances whose tile the splat provably
+ * cannot reach with alpha >= 1/255 are not listed internally (no output depends on them).
  * Replaces CudaRasterizer::Rasterizer::forward, cuda_rasterizer/rasterizer.h:31-54
  * (= rasterizer_impl.cu:198-339); bound by `_C.rasterize_gaussians`, ext.cpp:16 /
  * rasterize_points.cu:35-117. */

@@ -238,6 +238,34 @@ def test_autograd_end_to_end(name):
         assert frac < 5e-3, (k, frac)   # elements losing > 1e-4 to cancellation in the unordered sums
 
 
+def test_gradients_and_outputs_are_bit_reproducible():
+    """No atomics and fixed summation orders everywhere: two runs give identical bits, gradients
+    included (the reference's float atomicAdd sums vary from run to run, backward.cu:537-583)."""
+    c = Hh.make_case(P=60000, W=400, H=300, deg=2, seed=77, scale_mul=3.0)
+    a = Hh.run_hip(c)
+    b = Hh.run_hip(c)
+    np.testing.assert_array_equal(a.color.view(np.uint32), b.color.view(np.uint32))
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        np.testing.assert_array_equal(getattr(a.grads, k).view(np.uint32), getattr(b.grads, k).view(np.uint32), err_msg=k)
+
+
+def test_debug_snapshot_on_failure(tmp_path, monkeypatch):
+    """debug=True: a failing forward leaves snapshot_fw.dump behind and re-raises
+    (depth_diff_gaussian_rasterization/__init__.py:83-90)."""
+    from bloomscene_amd import GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    dev = _dev()
+    c = Hh.make_case(P=200, W=32, H=32, deg=0, seed=3, near_fraction=0.5)
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev, debug=True, prefiltered=True))
+    m = c.means3D.to(dev)
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        rast(m, torch.zeros_like(m), c.opacities.to(dev), shs=c.shs.to(dev), scales=c.scales.to(dev),
+             rotations=c.rotations.to(dev))
+    assert (tmp_path / "snapshot_fw.dump").exists()
+    args = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert len(args) == 19 and args[1].shape == (200, 3) and args[1].device.type == "cpu"
+
+
 def test_visible_filter_and_mark_visible():
     from bloomscene_amd import GaussianRasterizer
     c = Hh.make_case(P=50000, W=320, H=200, deg=1, seed=31, near_fraction=0.3, scene="b", view=5, scale_mul=3.0)
