@@ -314,6 +314,12 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
                     int hist_blocks_max, uint32_t* tile_start, uint4** elems_sorted, uint4** elems_free, hipStream_t s)
 {
+	*elems_sorted = elems_a;
+	*elems_free = elems_b;
+	if (n <= 0) {   // nothing survived the culls: every tile range is empty
+		hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, 0, elems_a, tile_start);
+		return;
+	}
 	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, geom.rect, geom.kept_mask,
 	                   geom.inst_offset, geom.wg_kept, geom.rec, elems_a);
 	int bits = 0;

@@ -294,6 +294,14 @@ def test_empty_inputs_errors_debug_and_streams():
     color, radii, depth = rast(z3, z3, torch.zeros(0, 1, device=dev), shs=torch.zeros(0, 4, 3, device=dev),
                                scales=z3, rotations=torch.zeros(0, 4, device=dev))
     assert radii.numel() == 0 and not color.any() and not depth.any()
+    # every Gaussian behind the near plane: background image, zero depth, zero gradients
+    behind = Hh.make_case(P=300, W=50, H=34, deg=1, seed=42)
+    behind.means3D[:, 2] = -1.0
+    ob, _ = Hh.run_oracle(behind, backward=False)
+    hb = Hh.run_hip(behind)
+    assert ob.num_rendered == 0 and not hb.radii.any()
+    np.testing.assert_array_equal(hb.color.view(np.uint32), ob.color.view(np.uint32))
+    assert not hb.depth.any() and not hb.grads.means3D.any() and not hb.grads.shs.any()
     # prefiltered=True with culled points is an error (auxiliary.h:156-160)
     rast_p = GaussianRasterizer(Hh.hip_settings(c, dev, prefiltered=True))
     m = c.means3D.to(dev)
