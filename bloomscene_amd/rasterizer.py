@@ -203,6 +203,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 class _RasterizeGaussians(torch.autograd.Function):
+    last_final_T = None   # final_T view of the most recent forward call (see GaussianRasterizer.forward)
+
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
@@ -227,6 +229,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
                 _rasterize_gaussians_native(*args)
 
+        # accumulated opacity of the call (extension; final_T is the first H*W floats of the image buffer)
+        n_pix = raster_settings.image_height * raster_settings.image_width
+        if imgBuffer.numel() >= 4 * n_pix:
+            final_T = imgBuffer[:4 * n_pix].view(torch.float32).view(1, raster_settings.image_height,
+                                                                     raster_settings.image_width)
+            _RasterizeGaussians.last_final_T = final_T   # a view: nothing is computed unless asked for
+        else:   # P == 0: nothing was rendered
+            _RasterizeGaussians.last_final_T = None
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
@@ -295,7 +305,10 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
         return visible
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, return_alpha=False):
+        """Same call as the reference (PYW:188-221) -> (color, radii, depth).  Extension, off by default:
+        ``return_alpha=True`` appends ``alpha = 1 - final_T`` [1,H,W] (accumulated opacity; the reference
+        keeps final_T only inside its opaque image buffer, forward.cu:459).  It carries no gradient."""
         raster_settings = self.raster_settings
 
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -316,8 +329,14 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
         if cov3D_precomp is None:
             cov3D_precomp = torch.Tensor([])
 
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3D_precomp, raster_settings)
+        if not return_alpha:
+            return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                       cov3D_precomp, raster_settings)
+        color, radii, depth = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                                  rotations, cov3D_precomp, raster_settings)
+        final_T = _RasterizeGaussians.last_final_T
+        alpha = torch.zeros_like(depth) if final_T is None else (1.0 - final_T)
+        return color, radii, depth, alpha.detach()
 
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         raster_settings = self.raster_settings

@@ -238,6 +238,25 @@ def test_autograd_end_to_end(name):
         assert frac < 5e-3, (k, frac)   # elements losing > 1e-4 to cancellation in the unordered sums
 
 
+def test_alpha_target_extension():
+    """return_alpha=True appends alpha = 1 - final_T (the reference has no alpha output; north_star
+    asks for the extra depth/alpha targets).  Default call shape and results are unchanged."""
+    from bloomscene_amd import GaussianRasterizer
+    dev = _dev()
+    c = Hh.make_case(P=4000, W=120, H=70, deg=1, seed=61, scale_mul=3.0)
+    st, _ = Hh.run_oracle(c, backward=False)
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev))
+    m = c.means3D.to(dev)
+    args = dict(means3D=m, means2D=torch.zeros_like(m), opacities=c.opacities.to(dev), shs=c.shs.to(dev),
+                scales=c.scales.to(dev), rotations=c.rotations.to(dev))
+    out3 = rast(**args)
+    assert len(out3) == 3
+    color, radii, depth, alpha = rast(return_alpha=True, **args)
+    assert alpha.shape == (1, 70, 120) and not alpha.requires_grad
+    np.testing.assert_array_equal(alpha.cpu().numpy().reshape(-1), (np.float32(1.0) - st.final_T))
+    np.testing.assert_array_equal(color.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
+
+
 def test_gradients_and_outputs_are_bit_reproducible():
     """No atomics and fixed summation orders everywhere: two runs give identical bits, gradients
     included (the reference's float atomicAdd sums vary from run to run, backward.cu:537-583)."""
