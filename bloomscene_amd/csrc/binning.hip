@@ -232,38 +232,53 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint4* 
 }
 
 // ---- per-tile bitonic sort of 64-bit keys ----
-// One workgroup per tile.  Segments of up to CAP keys are sorted in LDS; longer ones (rare: a
-// tile overlapped by > CAP splats) are sorted in place in global memory by the same network.
+// One workgroup per tile.  Segments of up to CAP keys are sorted in LDS.  Longer ones (rare: a
+// tile overlapped by > 8192 splats) run the same network hybrid: every 8192-key chunk is sorted in
+// LDS, then each merge does only its steps with partner distance >= 8192 in global memory and
+// finishes chunk by chunk in LDS.
 // The network is the all-ascending form of bitonic sort (first step of every merge compares
 // mirrored partners), so keys beyond n behave as +infinity pads without ever being stored:
 // a compare-exchange whose upper index is >= n is a no-op.
 template <typename KeyPtr>
+__device__ __forceinline__ void cmp_exchange(KeyPtr k, int lo, int hi)
+{
+	const uint64_t a = k[lo], b = k[hi];
+	if (a > b) { k[lo] = b; k[hi] = a; }
+}
+
+// mirrored first step of the merge that builds sorted runs of `size`
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void merge_mirror_step(KeyPtr k, int n, int n2, int size, int tid)
+{
+	const int half = size >> 1;
+	for (int i = tid; i < (n2 >> 1); i += NT) {
+		const int blk = i / half, off = i - blk * half;
+		const int hi = blk * size + size - 1 - off;
+		if (hi < n) cmp_exchange(k, blk * size + off, hi);
+	}
+}
+
+template <int NT, typename KeyPtr>
+__device__ __forceinline__ void merge_stride_step(KeyPtr k, int n, int n2, int stride, int tid)
+{
+	for (int i = tid; i < (n2 >> 1); i += NT) {
+		const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
+		const int hi = lo | stride;
+		if (hi < n) cmp_exchange(k, lo, hi);
+	}
+}
+
+template <int NT, typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 {
 	int n2 = 1;
 	while (n2 < n) n2 <<= 1;
 	for (int size = 2; size <= n2; size <<= 1) {
-		const int half = size >> 1;
 		__syncthreads();
-		for (int i = tid; i < (n2 >> 1); i += BSR_BLOCK) {
-			const int blk = i / half, off = i - blk * half;
-			const int lo = blk * size + off;
-			const int hi = blk * size + size - 1 - off;
-			if (hi < n) {
-				const uint64_t a = k[lo], b = k[hi];
-				if (a > b) { k[lo] = b; k[hi] = a; }
-			}
-		}
-		for (int stride = half >> 1; stride > 0; stride >>= 1) {
+		merge_mirror_step<NT>(k, n, n2, size, tid);
+		for (int stride = size >> 2; stride > 0; stride >>= 1) {
 			__syncthreads();
-			for (int i = tid; i < (n2 >> 1); i += BSR_BLOCK) {
-				const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
-				const int hi = lo | stride;
-				if (hi < n) {
-					const uint64_t a = k[lo], b = k[hi];
-					if (a > b) { k[lo] = b; k[hi] = a; }
-				}
-			}
+			merge_stride_step<NT>(k, n, n2, stride, tid);
 		}
 	}
 	__syncthreads();
@@ -271,10 +286,10 @@ __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 
 __device__ __forceinline__ uint64_t elem_key(const uint4 e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
 
-template <int CAP>
-__global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles(int T, int min_n, const uint32_t* __restrict__ tile_start,
-                                                           const uint4* __restrict__ elems,
-                                                           uint32_t* __restrict__ point_list)
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) k_sort_tiles(int T, int min_n, const uint32_t* __restrict__ tile_start,
+                                                    const uint4* __restrict__ elems,
+                                                    uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[CAP];
 	const int tile = blockIdx.x;
@@ -283,25 +298,60 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles(int T, int min_n, cons
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n <= min_n || n > CAP) return;   // handled by another size class
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += BSR_BLOCK) s_keys[i] = elem_key(elems[start + i]);
-	bitonic_sort_asc(s_keys, n, tid);
-	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)s_keys[i];
+	for (int i = tid; i < n; i += NT) s_keys[i] = elem_key(elems[start + i]);
+	bitonic_sort_asc<NT>(s_keys, n, tid);
+	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)s_keys[i];
 }
 
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
-__global__ void __launch_bounds__(BSR_BLOCK) k_sort_tiles_global(int T, int min_n, const uint32_t* __restrict__ tile_start,
-                                                                  const uint4* __restrict__ elems, uint64_t* keys,
-                                                                  uint32_t* __restrict__ point_list)
+#define BSR_SORT_CHUNK 8192
+#define BSR_SORT_NT 1024
+__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_global(int T, int min_n,
+                                                                   const uint32_t* __restrict__ tile_start,
+                                                                   const uint4* __restrict__ elems, uint64_t* keys,
+                                                                   uint32_t* __restrict__ point_list)
 {
+	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
+	__shared__ uint64_t s_keys[CH];
 	const int tile = blockIdx.x;
 	if (tile >= T) return;
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n <= min_n) return;
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += BSR_BLOCK) keys[start + i] = elem_key(elems[start + i]);
-	bitonic_sort_asc(keys + start, n, tid);
-	for (int i = tid; i < n; i += BSR_BLOCK) point_list[start + i] = (uint32_t)keys[start + i];
+	uint64_t* k = keys + start;
+	int n2 = 1;
+	while (n2 < n) n2 <<= 1;
+	// runs of CH: every chunk sorted on its own in LDS
+	for (int base = 0; base < n; base += CH) {
+		const int m = min(CH, n - base);
+		__syncthreads();
+		for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(elems[start + base + i]);
+		bitonic_sort_asc<NT>(s_keys, m, tid);
+		for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
+	}
+	// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
+	for (int size = 2 * CH; size <= n2; size <<= 1) {
+		__syncthreads();
+		merge_mirror_step<NT>(k, n, n2, size, tid);
+		for (int stride = size >> 2; stride >= CH; stride >>= 1) {
+			__syncthreads();
+			merge_stride_step<NT>(k, n, n2, stride, tid);
+		}
+		for (int base = 0; base < n; base += CH) {
+			const int m = min(CH, n - base);
+			__syncthreads();
+			for (int i = tid; i < m; i += NT) s_keys[i] = k[base + i];
+			for (int stride = CH >> 1; stride > 0; stride >>= 1) {
+				__syncthreads();
+				merge_stride_step<NT>(s_keys, m, CH, stride, tid);
+			}
+			__syncthreads();
+			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
 }
 
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s)
@@ -342,13 +392,14 @@ void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* e
 	*elems_free = eo;
 }
 
-// Size classes: (0, 1024] -> 8 KB LDS, (1024, 8192] -> 64 KB LDS, > 8192 -> global memory.
+// Size classes: (0, 1024] -> 8 KB LDS, (1024, 4096] -> 32 KB, (4096, 8192] -> 64 KB, > 8192 -> hybrid.
 void launch_sort_tiles(int T, const uint32_t* tile_start, const uint4* elems, uint4* elems_free, uint32_t* point_list,
                        hipStream_t s)
 {
-	hipLaunchKernelGGL(k_sort_tiles<1024>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 0, tile_start, elems, point_list);
-	hipLaunchKernelGGL(k_sort_tiles<8192>, dim3(T), dim3(BSR_BLOCK), 0, s, T, 1024, tile_start, elems, point_list);
-	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_BLOCK), 0, s, T, 8192, tile_start, elems,
+	hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(T), dim3(256), 0, s, T, 0, tile_start, elems, point_list);
+	hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(T), dim3(512), 0, s, T, 1024, tile_start, elems, point_list);
+	hipLaunchKernelGGL((k_sort_tiles<8192, 1024>), dim3(T), dim3(1024), 0, s, T, 4096, tile_start, elems, point_list);
+	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_SORT_NT), 0, s, T, BSR_SORT_CHUNK, tile_start, elems,
 	                   reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 

@@ -158,6 +158,47 @@ def _bitonic_asc(keys):
     return k
 
 
+def _bitonic_hybrid(keys, ch):
+    """Python model of k_sort_tiles_global: chunks of `ch` sorted on their own, then every merge
+    runs its far steps (partner distance >= ch) over the whole array and the near ones per chunk."""
+    k = list(keys)
+    n = len(k)
+    n2 = 1
+    while n2 < n:
+        n2 <<= 1
+    for base in range(0, n, ch):
+        k[base:base + ch] = _bitonic_asc(k[base:base + ch])
+
+    def stride_step(arr, m, pairs, stride):
+        for i in range(pairs):
+            lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1))
+            hi = lo | stride
+            if hi < m and arr[lo] > arr[hi]:
+                arr[lo], arr[hi] = arr[hi], arr[lo]
+
+    size = 2 * ch
+    while size <= n2:
+        half = size >> 1
+        for i in range(n2 >> 1):
+            blk, off = divmod(i, half)
+            lo, hi = blk * size + off, blk * size + size - 1 - off
+            if hi < n and k[lo] > k[hi]:
+                k[lo], k[hi] = k[hi], k[lo]
+        stride = size >> 2
+        while stride >= ch:
+            stride_step(k, n, n2 >> 1, stride)
+            stride >>= 1
+        for base in range(0, n, ch):
+            part = k[base:base + ch]
+            stride = ch >> 1
+            while stride > 0:
+                stride_step(part, len(part), ch >> 1, stride)
+                stride >>= 1
+            k[base:base + ch] = part
+        size <<= 1
+    return k
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 8, 17, 100, 255, 256, 257, 1000, 1025])
 def test_sort_network_sorts_any_length(n):
     rng = np.random.default_rng(n)
@@ -165,6 +206,9 @@ def test_sort_network_sorts_any_length(n):
     keys = [(d << 32) | i for i, d in enumerate(keys)]       # (depth, id) keys are unique
     rng.shuffle(keys)
     assert _bitonic_asc(keys) == sorted(keys)
+    for ch in (8, 64):
+        if n > ch:
+            assert _bitonic_hybrid(keys, ch) == sorted(keys)
 
 
 def test_algorithmic_byte_model_is_consistent():
