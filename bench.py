@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--gaussians", type=int, default=0, help="override P (experiments only)")
+    ap.add_argument("--colors", default="sh", choices=["sh", "precomp"],
+                    help="precomp: colors_precomp[P,3] instead of SHs, the call shape of the reference's render() "
+                         "(gaussian_renderer/__init__.py:254-262); experiments only, the metric is quoted on sh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -93,16 +96,22 @@ def main():
     P, W, H, deg, do_bwd = CONFIGS[args.config]
     if args.gaussians:
         P = args.gaussians
-    M = (deg + 1) ** 2
+    precomp = args.colors == "precomp"
+    if precomp:
+        deg = 1   # the reference passes sh_degree=1 with shs=None (gaussian_renderer/__init__.py:244,257)
+    M = 0 if precomp else (deg + 1) ** 2
     N = W * H
 
     # ---- inputs: generated on rank 0's host, broadcast over RCCL/xGMI, resident in HBM ----
     names = ("means3D", "scales", "rotations", "opacities", "shs")
     if rank == 0:
-        sc = scene_a(P, W, H, deg, seed=0)
+        sc = scene_a(P, W, H, 0 if precomp else deg, seed=0)
+        if precomp:
+            sc.shs = torch.rand(P, 3, generator=torch.Generator().manual_seed(13))   # colours in [0, 1)
         bufs = {k: getattr(sc, k).to(dev) for k in names}
     else:
-        shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1), "shs": (P, M, 3)}
+        shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1),
+                  "shs": (P, 3) if precomp else (P, M, 3)}
         bufs = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in names}
     bcast_ms = broadcast_gaussians(bufs, src=0) if world > 1 else 0.0
     gC, gD = upstream_grads(W, H, seed=1)
@@ -120,7 +129,9 @@ def main():
     def step():
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=do_bwd)
         color, radii, depth = rasterizer(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
-                                         shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+                                         shs=None if precomp else leaves["shs"],
+                                         colors_precomp=leaves["shs"] if precomp else None,
+                                         scales=leaves["scales"], rotations=leaves["rotations"])
         if do_bwd:
             for v in leaves.values():
                 v.grad = None
@@ -154,10 +165,10 @@ def main():
     from bloomscene_amd.rasterizer import _rasterize_gaussians_native
     e = torch.Tensor([])
     with torch.no_grad():
-        R = _rasterize_gaussians_native(settings.bg, bufs["means3D"], e, bufs["opacities"], bufs["scales"],
-                                        bufs["rotations"], 1.0, e, settings.viewmatrix, settings.projmatrix,
-                                        settings.tanfovx, settings.tanfovy, H, W, bufs["shs"], deg, settings.campos,
-                                        False, False)[0]
+        R = _rasterize_gaussians_native(settings.bg, bufs["means3D"], bufs["shs"] if precomp else e,
+                                        bufs["opacities"], bufs["scales"], bufs["rotations"], 1.0, e,
+                                        settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy,
+                                        H, W, e if precomp else bufs["shs"], deg, settings.campos, False, False)[0]
     visible = int((state["radii"] > 0).sum().item())
 
     if rank == 0:
@@ -165,6 +176,9 @@ def main():
         value = world * P * args.steps / dt / 1e6
         stages = {k: v[0] / max(v[1], 1) for k, v in prof.items()}  # mean ms per launch
         alg = algorithmic_bytes(P, M, R, N)
+        if precomp:   # 12 B/G of colours read by preprocess, 12 B/G of colour gradient passed through
+            alg["preprocess"] += 12 * P
+            alg["preprocess_bwd"] += 24 * P
         dom = max(stages, key=lambda k: stages[k]) if stages else None
         roofline = None
         if dom is not None:
@@ -174,25 +188,27 @@ def main():
                         "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4)}
         if roofline is not None:
             roofline["traffic"] = measured_traffic(args.config, dom)
-        whole = step_bytes(P, M, R, N, do_bwd) / (ms_per_step * 1e-3) / 1e9
+        sb = step_bytes(P, M, R, N, do_bwd) + (36 * P if precomp and do_bwd else 12 * P if precomp else 0)
+        whole = sb / (ms_per_step * 1e-3) / 1e9
         out = {
-            "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if args.config == "c3"
+            "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline"
+            if args.config == "c3" and not precomp and not args.gaussians
             else f"Msplats/s ({args.config})",
             "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P} Gaussians, SH deg {deg}, {W}x{H}, "
+            "config": {"workload": f"{args.config}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
                                    f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}, synthetic scene A seed 0",
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
                        "visible": visible, "parallelism": f"view-parallel x{world}",
                        "broadcast_ms": round(bcast_ms, 3)},
             "roofline": roofline,
-            "roofline_step": {"algorithmic_bytes": step_bytes(P, M, R, N, do_bwd), "achieved": round(whole, 2),
+            "roofline_step": {"algorithmic_bytes": sb, "achieved": round(whole, 2),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd)
+            out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd, precomp)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -211,21 +227,23 @@ def measured_traffic(config, stage):
         return None
 
 
-def cpu_baseline(args, P, W, H, deg, do_bwd):
+def cpu_baseline(args, P, W, H, deg, do_bwd, precomp=False):
     """The CPU oracle (oracle/bsr_oracle.c: a port of the reference algorithm, OpenMP over
     Gaussians/tiles) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     from bloomscene_amd.synthetic import scene_a, upstream_grads
     cores = os.cpu_count() or 1
     Ps = args.cpu_sample or min(P, max(50_000, 125_000 * cores))   # ~10-30 s of CPU work
-    sc = scene_a(Ps, W, H, deg, seed=0)
+    sc = scene_a(Ps, W, H, 0 if precomp else deg, seed=0)
+    col = torch.rand(Ps, 3, generator=torch.Generator().manual_seed(13)) if precomp else None
     cam = sc.cameras[0]
     rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
                          cam.world_view_transform, cam.full_proj_transform, deg, cam.camera_center)
     gC, gD = upstream_grads(W, H, seed=1)
     O.lib()
     t0 = time.perf_counter()
-    st = O.forward(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    st = O.forward(rs, sc.means3D, sc.opacities, shs=None if precomp else sc.shs, colors_precomp=col,
+                   scales=sc.scales, rotations=sc.rotations)
     if do_bwd:
         O.backward(st, gC, gD)
     dt = time.perf_counter() - t0

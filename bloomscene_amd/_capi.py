@@ -1,4 +1,5 @@
-"""ctypes binding of ``libbloomscene_rast.so`` (C ABI declared in ``include/bloomscene_rast.h``).
+"""ctypes binding of ``libbloomscene_rast.so`` (C ABI declared in ``include/bloomscene_rast.h`` and
+``include/bloomscene_anchors.h``).
 
 The library is built in-tree (``bloomscene_amd/csrc/Makefile``, hipcc --offload-arch=gfx950).
 There is deliberately NO fallback: if the shared object is missing or a call fails, this module
@@ -23,7 +24,7 @@ class StageProfile(C.Structure):
     _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_int)]
 
 
-# name -> (restype, argtypes); every symbol include/bloomscene_rast.h declares
+# name -> (restype, argtypes); every symbol include/*.h declares
 SIGNATURES = {
     "bsr_version": (C.c_int, []),
     "bsr_last_error": (C.c_char_p, []),
@@ -43,6 +44,11 @@ SIGNATURES = {
     "bsr_profile_enable": (C.c_int, [C.c_int]),
     "bsr_profile_reset": (C.c_int, []),
     "bsr_profile_read": (C.c_int, [C.POINTER(StageProfile), C.c_int]),
+    # include/bloomscene_anchors.h
+    "bsr_anchor_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "bsr_anchor_select": (C.c_int, [C.c_int, C.c_int, _F, _F, _F, C.POINTER(C.c_int), C.c_void_p]),
+    "bsr_anchor_expand": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_F] * 12 + [C.c_void_p]),
+    "bsr_anchor_expand_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_F] * 16 + [C.c_void_p]),
 }
 
 _lib = None

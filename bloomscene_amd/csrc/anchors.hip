@@ -1,0 +1,310 @@
+// Fused anchor expansion for gfx950 (include/bloomscene_anchors.h).
+//
+// The reference (gaussian_renderer/__init__.py:169-203) concatenates every per-candidate tensor
+// into [N*K, 22], boolean-indexes it, splits it again and post-processes the pieces: ~10 torch
+// kernels and ~25x the compulsory HBM traffic.  Here: one counting pass over neural_opacity, one
+// tiny scan, and one kernel that reads each input once and writes each selected output once.
+//
+// Work partition (shared by all kernels, so the prefix sums agree): a workgroup of 256 lanes owns
+// A = 256 / K whole anchors = A*K consecutive candidates; lane t < A*K is candidate base + t.
+// Consecutive lanes touch consecutive rows of every per-candidate tensor (coalesced across the
+// wave), and the K candidates of an anchor sit in one workgroup so the backward's per-anchor
+// sums are an LDS reduction in slot order -- no atomics, deterministic.
+#include "common.h"
+#include "../../include/bloomscene_anchors.h"
+
+namespace bsr {
+
+#define BSR_ANCHOR_BLOCK 256
+
+// Exclusive prefix of `flag` over the workgroup's lanes (lane order), and the workgroup total.
+__device__ __forceinline__ uint32_t wg_prefix(bool flag, uint32_t* s_wave, uint32_t& total)
+{
+	const uint64_t b = __ballot(flag);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t in_wave = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+	if (lane == 0) s_wave[wave] = (uint32_t)__popcll(b);
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+#pragma unroll
+	for (int w = 0; w < BSR_ANCHOR_BLOCK / 64; w++) {
+		const uint32_t c = s_wave[w];
+		before += (w < wave) ? c : 0u;
+		all += c;
+	}
+	total = all;
+	return before + in_wave;
+}
+
+__global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_anchor_select(int n_cand, int per_wg,
+                                                                    const float* __restrict__ neural_opacity,
+                                                                    uint8_t* __restrict__ mask,
+                                                                    uint32_t* __restrict__ wg_count)
+{
+	__shared__ uint32_t s_wave[BSR_ANCHOR_BLOCK / 64];
+	const int t = threadIdx.x;
+	const long long i = (long long)blockIdx.x * per_wg + t;
+	const bool live = t < per_wg && i < n_cand;
+	const bool sel = live && neural_opacity[i] > 0.0f;
+	if (live) mask[i] = sel ? 1 : 0;
+	uint32_t total;
+	wg_prefix(sel, s_wave, total);
+	if (t == 0) wg_count[blockIdx.x] = total;
+}
+
+// In-place exclusive scan of wg_count[0..n) by one workgroup; the grand total goes to wg_count[n].
+__global__ void __launch_bounds__(1024) k_anchor_scan(int n, uint32_t* __restrict__ wg_count)
+{
+	__shared__ uint32_t s_wave[16];
+	__shared__ uint32_t s_carry;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	if (t == 0) s_carry = 0;
+	__syncthreads();
+	for (int base = 0; base < n; base += 1024) {
+		const int i = base + t;
+		const uint32_t v = i < n ? wg_count[i] : 0u;
+		uint32_t incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t o = __shfl_up(incl, d);
+			if (lane >= d) incl += o;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		uint32_t before = s_carry, all = 0;
+#pragma unroll
+		for (int w = 0; w < 16; w++) {
+			const uint32_t c = s_wave[w];
+			before += (w < wave) ? c : 0u;
+			all += c;
+		}
+		if (i < n) wg_count[i] = before + incl - v;
+		__syncthreads();
+		if (t == 0) s_carry += all;
+		__syncthreads();
+	}
+	if (t == 0) wg_count[n] = s_carry;
+}
+
+// torch.sigmoid in fp32: 1 / (1 + exp(-x))
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + bsr_expf(-x)); }
+
+__global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_anchor_expand(
+    int n_cand, int K, int per_wg, const float* __restrict__ anchor, const float* __restrict__ grid_scaling,
+    const float* __restrict__ grid_offsets, const float* __restrict__ neural_opacity, const float* __restrict__ color,
+    const float* __restrict__ scale_rot, const uint32_t* __restrict__ wg_base, float* __restrict__ xyz,
+    float* __restrict__ color_out, float* __restrict__ opacity, float* __restrict__ scaling, float* __restrict__ rot)
+{
+	__shared__ uint32_t s_wave[BSR_ANCHOR_BLOCK / 64];
+	const int t = threadIdx.x;
+	const long long i = (long long)blockIdx.x * per_wg + t;
+	const bool live = t < per_wg && i < n_cand;
+	const float nop = live ? neural_opacity[i] : 0.0f;
+	const bool sel = live && nop > 0.0f;
+	uint32_t total;
+	const uint32_t rank = wg_prefix(sel, s_wave, total);
+	if (!sel) return;
+	const size_t dst = (size_t)wg_base[blockIdx.x] + rank;
+	const long long n = i / K;
+	const float* gs = grid_scaling + n * 6;
+	const float* an = anchor + n * 3;
+	const float* sr = scale_rot + i * 7;
+	const float* of = grid_offsets + i * 3;
+	const float* co = color + i * 3;
+	opacity[dst] = nop;
+	color_out[dst * 3 + 0] = co[0];
+	color_out[dst * 3 + 1] = co[1];
+	color_out[dst * 3 + 2] = co[2];
+	scaling[dst * 3 + 0] = gs[3] * sigmoidf(sr[0]);
+	scaling[dst * 3 + 1] = gs[4] * sigmoidf(sr[1]);
+	scaling[dst * 3 + 2] = gs[5] * sigmoidf(sr[2]);
+	const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+	const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+	reinterpret_cast<float4*>(rot)[dst] = make_float4(q0 / nrm, q1 / nrm, q2 / nrm, q3 / nrm);
+	xyz[dst * 3 + 0] = an[0] + of[0] * gs[0];
+	xyz[dst * 3 + 1] = an[1] + of[1] * gs[1];
+	xyz[dst * 3 + 2] = an[2] + of[2] * gs[2];
+}
+
+__global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_anchor_expand_bwd(
+    int n_cand, int n_anchors, int K, int per_wg, const float* __restrict__ grid_scaling,
+    const float* __restrict__ grid_offsets, const float* __restrict__ neural_opacity,
+    const float* __restrict__ scale_rot, const uint32_t* __restrict__ wg_base, const float* __restrict__ g_xyz,
+    const float* __restrict__ g_color, const float* __restrict__ g_opacity, const float* __restrict__ g_scaling,
+    const float* __restrict__ g_rot, float* __restrict__ d_anchor, float* __restrict__ d_gs,
+    float* __restrict__ d_offsets, float* __restrict__ d_nop, float* __restrict__ d_color, float* __restrict__ d_sr)
+{
+	__shared__ uint32_t s_wave[BSR_ANCHOR_BLOCK / 64];
+	__shared__ float s_part[BSR_ANCHOR_BLOCK][9];   // per candidate: d_anchor[3], d_gs[0:3], d_gs[3:6]
+	const int t = threadIdx.x;
+	const long long i = (long long)blockIdx.x * per_wg + t;
+	const bool live = t < per_wg && i < n_cand;
+	const bool sel = live && neural_opacity[i] > 0.0f;
+	uint32_t total;
+	const uint32_t rank = wg_prefix(sel, s_wave, total);
+	float part[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	if (live) {
+		float dn = 0.0f, dc[3] = {0, 0, 0}, dsr[7] = {0, 0, 0, 0, 0, 0, 0}, dof[3] = {0, 0, 0};
+		if (sel) {
+			const size_t src = (size_t)wg_base[blockIdx.x] + rank;
+			const long long n = i / K;
+			const float* gs = grid_scaling + n * 6;
+			const float* sr = scale_rot + i * 7;
+			const float* of = grid_offsets + i * 3;
+			if (g_opacity) dn = g_opacity[src];
+			if (g_color) { dc[0] = g_color[src * 3]; dc[1] = g_color[src * 3 + 1]; dc[2] = g_color[src * 3 + 2]; }
+			if (g_xyz) {
+#pragma unroll
+				for (int c = 0; c < 3; c++) {
+					const float g = g_xyz[src * 3 + c];
+					part[c] = g;               // d anchor
+					part[3 + c] = g * of[c];   // d grid_scaling[0:3]
+					dof[c] = g * gs[c];
+				}
+			}
+			if (g_scaling) {
+#pragma unroll
+				for (int c = 0; c < 3; c++) {
+					const float g = g_scaling[src * 3 + c];
+					const float s = sigmoidf(sr[c]);
+					part[6 + c] = g * s;                          // d grid_scaling[3:6]
+					dsr[c] = g * gs[3 + c] * (s * (1.0f - s));
+				}
+			}
+			if (g_rot) {
+				// r = v / max(|v|, eps):  dv = (g - r (r.g)) / |v|  (|v| > eps),  g / eps otherwise
+				const float4 g = reinterpret_cast<const float4*>(g_rot)[src];
+				const float q0 = sr[3], q1 = sr[4], q2 = sr[5], q3 = sr[6];
+				const float len = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+				if (len > 1e-12f) {
+					const float inv = 1.0f / len;
+					const float r0 = q0 * inv, r1 = q1 * inv, r2 = q2 * inv, r3 = q3 * inv;
+					const float dot = r0 * g.x + r1 * g.y + r2 * g.z + r3 * g.w;
+					dsr[3] = (g.x - r0 * dot) * inv;
+					dsr[4] = (g.y - r1 * dot) * inv;
+					dsr[5] = (g.z - r2 * dot) * inv;
+					dsr[6] = (g.w - r3 * dot) * inv;
+				} else {
+					dsr[3] = g.x / 1e-12f; dsr[4] = g.y / 1e-12f; dsr[5] = g.z / 1e-12f; dsr[6] = g.w / 1e-12f;
+				}
+			}
+		}
+		d_nop[i] = dn;
+#pragma unroll
+		for (int c = 0; c < 3; c++) { d_color[i * 3 + c] = dc[c]; d_offsets[i * 3 + c] = dof[c]; }
+#pragma unroll
+		for (int c = 0; c < 7; c++) d_sr[i * 7 + c] = dsr[c];
+	}
+#pragma unroll
+	for (int c = 0; c < 9; c++) s_part[t][c] = part[c];
+	__syncthreads();
+	// per-anchor sums over the K slots, slot order; lane t -> (anchor a = t / 9, component c = t % 9)
+	const int A = per_wg / K;
+	for (int u = t; u < A * 9; u += BSR_ANCHOR_BLOCK) {
+		const int a = u / 9, c = u - a * 9;
+		const long long n = (long long)blockIdx.x * A + a;
+		if (n >= n_anchors) continue;
+		float acc = 0.0f;
+		for (int k = 0; k < K; k++) acc += s_part[a * K + k][c];
+		if (c < 3) d_anchor[n * 3 + c] = acc;
+		else d_gs[n * 6 + (c - 3)] = acc;
+	}
+}
+
+}  // namespace bsr
+
+using namespace bsr;
+
+namespace {
+struct Partition { int per_wg, n_wg; long long n_cand; };
+inline bool make_partition(int N, int K, Partition* p)
+{
+	if (N < 0 || K <= 0 || K > BSR_ANCHOR_BLOCK) return false;
+	const int A = BSR_ANCHOR_BLOCK / K;
+	p->per_wg = A * K;
+	p->n_wg = (N + A - 1) / A;
+	p->n_cand = (long long)N * K;
+	return p->n_cand <= 0x7fffffffLL;
+}
+}  // namespace
+
+extern "C" {
+
+size_t bsr_anchor_scratch_bytes(int n_anchors, int n_offsets)
+{
+	Partition p;
+	if (!make_partition(n_anchors, n_offsets, &p)) return 0;
+	return align_up(((size_t)p.n_wg + 1) * sizeof(uint32_t), 256);
+}
+
+int bsr_anchor_select(int n_anchors, int n_offsets, const float* neural_opacity, uint8_t* mask, void* scratch,
+                      int* num_selected, void* stream)
+{
+	Partition p;
+	if (!make_partition(n_anchors, n_offsets, &p))
+		return fail("bsr_anchor_select: need 0 < n_offsets <= %d and n_anchors * n_offsets < 2^31", BSR_ANCHOR_BLOCK);
+	if (!num_selected) return fail("bsr_anchor_select: num_selected is NULL");
+	*num_selected = 0;
+	if (p.n_cand == 0) return 0;
+	if (!neural_opacity || !mask || !scratch) return fail("bsr_anchor_select: NULL buffer");
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t* wg = (uint32_t*)scratch;
+	hipLaunchKernelGGL(k_anchor_select, dim3(p.n_wg), dim3(BSR_ANCHOR_BLOCK), 0, s, (int)p.n_cand, p.per_wg,
+	                   neural_opacity, mask, wg);
+	hipLaunchKernelGGL(k_anchor_scan, dim3(1), dim3(1024), 0, s, p.n_wg, wg);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail("bsr_anchor_select: launch failed: %s", hipGetErrorString(e));
+	uint32_t total = 0;
+	e = hipMemcpyAsync(&total, wg + p.n_wg, sizeof(total), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) return fail("bsr_anchor_select: reading the count failed: %s", hipGetErrorString(e));
+	*num_selected = (int)total;
+	return 0;
+}
+
+int bsr_anchor_expand(int n_anchors, int n_offsets, int num_selected, const float* anchor, const float* grid_scaling,
+                      const float* grid_offsets, const float* neural_opacity, const float* color,
+                      const float* scale_rot, const void* scratch, float* xyz, float* color_out, float* opacity,
+                      float* scaling, float* rot, void* stream)
+{
+	Partition p;
+	if (!make_partition(n_anchors, n_offsets, &p)) return fail("bsr_anchor_expand: bad n_anchors / n_offsets");
+	if (num_selected < 0 || num_selected > p.n_cand) return fail("bsr_anchor_expand: bad num_selected");
+	if (p.n_cand == 0 || num_selected == 0) return 0;
+	if (!anchor || !grid_scaling || !grid_offsets || !neural_opacity || !color || !scale_rot || !scratch || !xyz ||
+	    !color_out || !opacity || !scaling || !rot)
+		return fail("bsr_anchor_expand: NULL buffer");
+	if (((uintptr_t)rot & 15) != 0) return fail("bsr_anchor_expand: rot must be 16-byte aligned");
+	hipLaunchKernelGGL(k_anchor_expand, dim3(p.n_wg), dim3(BSR_ANCHOR_BLOCK), 0, (hipStream_t)stream, (int)p.n_cand,
+	                   n_offsets, p.per_wg, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot,
+	                   (const uint32_t*)scratch, xyz, color_out, opacity, scaling, rot);
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail("bsr_anchor_expand: launch failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
+int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected, const float* grid_scaling,
+                               const float* grid_offsets, const float* neural_opacity, const float* scale_rot,
+                               const void* scratch, const float* dL_dxyz, const float* dL_dcolor_out,
+                               const float* dL_dopacity, const float* dL_dscaling, const float* dL_drot,
+                               float* dL_danchor, float* dL_dgrid_scaling, float* dL_dgrid_offsets,
+                               float* dL_dneural_opacity, float* dL_dcolor, float* dL_dscale_rot, void* stream)
+{
+	Partition p;
+	if (!make_partition(n_anchors, n_offsets, &p)) return fail("bsr_anchor_expand_backward: bad n_anchors / n_offsets");
+	if (num_selected < 0 || num_selected > p.n_cand) return fail("bsr_anchor_expand_backward: bad num_selected");
+	if (p.n_cand == 0) return 0;
+	if (!grid_scaling || !grid_offsets || !neural_opacity || !scale_rot || !scratch || !dL_danchor ||
+	    !dL_dgrid_scaling || !dL_dgrid_offsets || !dL_dneural_opacity || !dL_dcolor || !dL_dscale_rot)
+		return fail("bsr_anchor_expand_backward: NULL buffer");
+	if (dL_drot && ((uintptr_t)dL_drot & 15) != 0) return fail("bsr_anchor_expand_backward: dL_drot must be 16-byte aligned");
+	hipLaunchKernelGGL(k_anchor_expand_bwd, dim3(p.n_wg), dim3(BSR_ANCHOR_BLOCK), 0, (hipStream_t)stream,
+	                   (int)p.n_cand, n_anchors, n_offsets, p.per_wg, grid_scaling, grid_offsets, neural_opacity,
+	                   scale_rot, (const uint32_t*)scratch, dL_dxyz, dL_dcolor_out, dL_dopacity, dL_dscaling, dL_drot,
+	                   dL_danchor, dL_dgrid_scaling, dL_dgrid_offsets, dL_dneural_opacity, dL_dcolor, dL_dscale_rot);
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail("bsr_anchor_expand_backward: launch failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
+}  // extern "C"

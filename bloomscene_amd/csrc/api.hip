@@ -97,7 +97,7 @@ void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
 
-static int fail(const char* fmt, ...)
+int fail(const char* fmt, ...)
 {
 	va_list ap;
 	va_start(ap, fmt);

@@ -100,6 +100,9 @@ struct BwdArgs {
 	float* dL_drot;            // [P,4]
 };
 
+// Records the calling thread's error message (read back by bsr_last_error) and returns 1.  api.hip
+int fail(const char* fmt, ...);
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
 
 // ---- pinned exp: identical algorithm to bsro_expf in oracle/bsr_oracle.c (<= 1 ulp) ----

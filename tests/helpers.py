@@ -31,7 +31,8 @@ def cov3d_from_scale_rot(scales, rotations, mod=1.0):
 
 
 def make_case(P, W, H, deg, seed=0, scene="a", view=0, color_mode="sh", cov_mode="scale_rot", bg=(0.1, 0.2, 0.3),
-              scale_mul=1.0, scale_modifier=1.0, near_fraction=0.0, M_extra=0):
+              scale_mul=1.0, scale_modifier=1.0, near_fraction=0.0, M_extra=0, squeeze_xy=1.0, big_count=0,
+              big_mul=60.0):
     """One rasterizer call's worth of CPU inputs (torch fp32) + camera."""
     sc = scene_a(P, W, H, deg, seed=seed) if scene == "a" else scene_b(P, W, H, deg, seed=seed)
     cam = sc.cameras[view]
@@ -42,7 +43,11 @@ def make_case(P, W, H, deg, seed=0, scene="a", view=0, color_mode="sh", cov_mode
         k = max(1, int(P * near_fraction))
         idx = torch.randperm(P, generator=g)[:k]
         c.means3D[idx, 2] = torch.rand(k, generator=g) * 0.6 - 0.2
+    c.means3D[:, :2] *= squeeze_xy   # < 1: cluster the splats around the optical axis (very long tile lists)
     c.scales = (sc.scales * scale_mul).contiguous()
+    if big_count:                    # a few splats spanning hundreds of tiles
+        g = torch.Generator().manual_seed(seed + 31)
+        c.scales[torch.randperm(P, generator=g)[:big_count]] *= big_mul
     c.rotations = sc.rotations
     c.opacities = sc.opacities
     c.shs = sc.shs

@@ -16,12 +16,12 @@ ROOT = Hh.ROOT
 
 
 def test_library_loads_and_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "bloomscene_rast.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     hdr_nocomment = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(bsr_[a-z_]+)\s*\(", hdr_nocomment))
     declared -= {"bsr_alloc_fn"}
     assert {"bsr_forward", "bsr_backward", "bsr_visible_filter", "bsr_mark_visible", "bsr_last_error",
-            "bsr_version"} <= declared
+            "bsr_version", "bsr_anchor_select", "bsr_anchor_expand", "bsr_anchor_expand_backward"} <= declared
     lib = _capi.lib()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bloomscene_rast.h but not exported"
@@ -33,6 +33,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.bsr_geometry_bytes(1000) >= 1000 * (64 + 4 + 8 + 24 + 1)
     assert lib.bsr_binning_bytes(1000) >= 1000 * 36
     assert lib.bsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 4
+    # include/bloomscene_anchors.h: one u32 per workgroup of 256 // K anchors, + the total
+    assert lib.bsr_anchor_scratch_bytes(1000, 10) >= (1000 // 25 + 1) * 4
+    assert lib.bsr_anchor_scratch_bytes(1000, 0) == 0 and lib.bsr_anchor_scratch_bytes(1000, 257) == 0
 
 
 def test_every_entry_point_cites_the_reference_interface_it_replaces():
