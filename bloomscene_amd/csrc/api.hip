@@ -65,7 +65,7 @@ BinState BinState::carve(char* p, size_t R)
 }
 size_t ImgState::bytes(size_t N, size_t T)
 {
-	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + 256;
+	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + align_up(T * 4, 256) + 256;
 }
 ImgState ImgState::carve(char* p, size_t N, size_t T)
 {
@@ -74,7 +74,8 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 	i.final_T = (float*)p;        p += align_up(N * 4, 256);
 	i.n_contrib = (uint32_t*)p;   p += align_up(N * 4, 256);
 	i.tile_start = (uint32_t*)p;  p += align_up((T + 1) * 4, 256);
-	i.flags = (int*)p;
+	i.flags = (int*)p;            p += 256;
+	i.big_tiles = (uint32_t*)p;
 	return i;
 }
 
@@ -83,9 +84,10 @@ void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
 void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
-                    int hist_blocks_max, uint32_t* tile_start, uint4** elems_sorted, uint4** elems_free, hipStream_t s);
-void launch_sort_tiles(int T, const uint32_t* tile_start, const uint4* elems, uint4* elems_free, uint32_t* point_list,
-                       hipStream_t s);
+                    int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles, int* flags, uint4** elems_sorted,
+                    uint4** elems_free, hipStream_t s);
+void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
+                       const uint4* elems, uint4* elems_free, uint32_t* point_list, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
@@ -428,12 +430,12 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	{
 		StageTimer t("binning", s);
 		launch_binning(P, T, gx, n_kept, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX, img.tile_start,
-		               &elems_sorted, &elems_free, s);
+		               img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
 	}
 	STAGE_CHECK("binning", debug, s);
 	if (n_kept > 0) {
 		StageTimer t("sort_tiles", s);
-		launch_sort_tiles(T, img.tile_start, elems_sorted, elems_free, bin.point_list, s);
+		launch_sort_tiles(T, n_kept, img.tile_start, img.big_tiles, img.flags, elems_sorted, elems_free, bin.point_list, s);
 	}
 	STAGE_CHECK("sort_tiles", debug, s);
 	{

@@ -218,17 +218,37 @@ __global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shi
 }
 
 // ---- tile ranges: tile_start[t] = first sorted position whose tile id is >= t ----
-__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint4* __restrict__ elems_sorted,
-                                                     uint32_t* __restrict__ tile_start)
+// Tiles holding more than BSR_SORT_SMALL instances are also appended (one atomic per wave, order
+// irrelevant) to big_tiles, the work list of the wide sort kernels; flags[1] counts them.
+#define BSR_SORT_SMALL 1024
+__device__ __forceinline__ int first_not_below(const uint4* __restrict__ elems_sorted, int n, uint32_t t)
 {
-	const int t = blockIdx.x * 256 + threadIdx.x;
-	if (t > T) return;
 	int lo = 0, hi = n;
 	while (lo < hi) {
 		const int mid = (lo + hi) >> 1;
-		if (elems_sorted[mid].x < (uint32_t)t) lo = mid + 1; else hi = mid;
+		if (elems_sorted[mid].x < t) lo = mid + 1; else hi = mid;
 	}
-	tile_start[t] = (uint32_t)lo;
+	return lo;
+}
+
+__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint4* __restrict__ elems_sorted,
+                                                     uint32_t* __restrict__ tile_start,
+                                                     uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	bool big = false;
+	if (t <= T) {
+		const int lo = first_not_below(elems_sorted, n, (uint32_t)t);
+		tile_start[t] = (uint32_t)lo;
+		if (t < T && n - lo > BSR_SORT_SMALL) big = first_not_below(elems_sorted, n, (uint32_t)t + 1u) - lo > BSR_SORT_SMALL;
+	}
+	const uint64_t b = __ballot(big);
+	if (b == 0) return;
+	const int lane = threadIdx.x & 63;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(&flags[1], __popcll(b));
+	base = __shfl(base, 0);
+	if (big) big_tiles[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
 }
 
 // ---- per-tile bitonic sort of 64-bit keys ----
@@ -286,72 +306,101 @@ __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 
 __device__ __forceinline__ uint64_t elem_key(const uint4 e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
 
+// LDS sort of one segment (n <= CAP)
 template <int CAP, int NT>
-__global__ void __launch_bounds__(NT) k_sort_tiles(int T, int min_n, const uint32_t* __restrict__ tile_start,
-                                                    const uint4* __restrict__ elems,
-                                                    uint32_t* __restrict__ point_list)
+__device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t start, int n, const uint4* __restrict__ elems,
+                                                 uint32_t* __restrict__ point_list)
 {
-	__shared__ uint64_t s_keys[CAP];
-	const int tile = blockIdx.x;
-	if (tile >= T) return;
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
-	if (n <= min_n || n > CAP) return;   // handled by another size class
 	const int tid = threadIdx.x;
 	for (int i = tid; i < n; i += NT) s_keys[i] = elem_key(elems[start + i]);
 	bitonic_sort_asc<NT>(s_keys, n, tid);
 	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)s_keys[i];
 }
 
-// keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
-#define BSR_SORT_CHUNK 8192
-#define BSR_SORT_NT 1024
-__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_global(int T, int min_n,
-                                                                   const uint32_t* __restrict__ tile_start,
-                                                                   const uint4* __restrict__ elems, uint64_t* keys,
-                                                                   uint32_t* __restrict__ point_list)
+// Small class: one workgroup per tile, n <= BSR_SORT_SMALL.
+__global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t* __restrict__ tile_start,
+                                                          const uint4* __restrict__ elems,
+                                                          uint32_t* __restrict__ point_list)
 {
-	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
-	__shared__ uint64_t s_keys[CH];
+	__shared__ uint64_t s_keys[BSR_SORT_SMALL];
 	const int tile = blockIdx.x;
 	if (tile >= T) return;
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
-	if (n <= min_n) return;
+	if (n > BSR_SORT_SMALL) return;   // on the big-tile list
+	sort_segment_lds<BSR_SORT_SMALL, 256>(s_keys, start, n, elems, point_list);
+}
+
+// Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, const uint32_t* __restrict__ tile_start,
+                                                        const uint32_t* __restrict__ big_tiles,
+                                                        const int* __restrict__ flags, const uint4* __restrict__ elems,
+                                                        uint32_t* __restrict__ point_list)
+{
+	__shared__ uint64_t s_keys[CAP];
+	const int b = blockIdx.x;
+	if (b >= flags[1]) return;
+	const uint32_t tile = big_tiles[b];
+	const uint32_t start = tile_start[tile];
+	const int n = (int)(tile_start[tile + 1] - start);
+	if (n <= min_n || n > CAP) return;   // another class (uniform over the workgroup)
+	sort_segment_lds<CAP, NT>(s_keys, start, n, elems, point_list);
+}
+
+// keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
+#define BSR_SORT_CHUNK 8192
+#define BSR_SORT_NT 1024
+__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ big_tiles,
+                                                                 const int* __restrict__ flags,
+                                                                 const uint4* __restrict__ elems, uint64_t* keys,
+                                                                 uint32_t* __restrict__ point_list)
+{
+	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
+	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
-	uint64_t* k = keys + start;
-	int n2 = 1;
-	while (n2 < n) n2 <<= 1;
-	// runs of CH: every chunk sorted on its own in LDS
-	for (int base = 0; base < n; base += CH) {
-		const int m = min(CH, n - base);
-		__syncthreads();
-		for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(elems[start + base + i]);
-		bitonic_sort_asc<NT>(s_keys, m, tid);
-		for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
-	}
-	// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
-	for (int size = 2 * CH; size <= n2; size <<= 1) {
-		__syncthreads();
-		merge_mirror_step<NT>(k, n, n2, size, tid);
-		for (int stride = size >> 2; stride >= CH; stride >>= 1) {
-			__syncthreads();
-			merge_stride_step<NT>(k, n, n2, stride, tid);
-		}
+	const int b = blockIdx.x;
+	if (b >= flags[1]) return;
+	{
+		const uint32_t tile = big_tiles[b];
+		const uint32_t start = tile_start[tile];
+		const int n = (int)(tile_start[tile + 1] - start);
+		if (n <= CH) return;
+		uint64_t* k = keys + start;
+		int n2 = 1;
+		while (n2 < n) n2 <<= 1;
+		// runs of CH: every chunk sorted on its own in LDS
 		for (int base = 0; base < n; base += CH) {
 			const int m = min(CH, n - base);
 			__syncthreads();
-			for (int i = tid; i < m; i += NT) s_keys[i] = k[base + i];
-			for (int stride = CH >> 1; stride > 0; stride >>= 1) {
-				__syncthreads();
-				merge_stride_step<NT>(s_keys, m, CH, stride, tid);
-			}
-			__syncthreads();
+			for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(elems[start + base + i]);
+			bitonic_sort_asc<NT>(s_keys, m, tid);
 			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
 		}
+		// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
+		for (int size = 2 * CH; size <= n2; size <<= 1) {
+			__syncthreads();
+			merge_mirror_step<NT>(k, n, n2, size, tid);
+			for (int stride = size >> 2; stride >= CH; stride >>= 1) {
+				__syncthreads();
+				merge_stride_step<NT>(k, n, n2, stride, tid);
+			}
+			for (int base = 0; base < n; base += CH) {
+				const int m = min(CH, n - base);
+				__syncthreads();
+				for (int i = tid; i < m; i += NT) s_keys[i] = k[base + i];
+				for (int stride = CH >> 1; stride > 0; stride >>= 1) {
+					__syncthreads();
+					merge_stride_step<NT>(s_keys, m, CH, stride, tid);
+				}
+				__syncthreads();
+				for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
+			}
+		}
+		__syncthreads();
+		for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
 	}
-	__syncthreads();
-	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
 }
 
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s)
@@ -362,12 +411,14 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 // Bins n kept instances: emit -> radix passes on the tile id -> tile ranges.  keys_a/tiles_a and
 // keys_b/tiles_b ping-pong; returns (through *keys_sorted) the buffer holding the final keys.
 void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
-                    int hist_blocks_max, uint32_t* tile_start, uint4** elems_sorted, uint4** elems_free, hipStream_t s)
+                    int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles, int* flags, uint4** elems_sorted,
+                    uint4** elems_free, hipStream_t s)
 {
 	*elems_sorted = elems_a;
 	*elems_free = elems_b;
 	if (n <= 0) {   // nothing survived the culls: every tile range is empty
-		hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, 0, elems_a, tile_start);
+		hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, 0, elems_a, tile_start, big_tiles,
+		                   flags);
 		return;
 	}
 	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, geom.rect, geom.kept_mask,
@@ -387,20 +438,29 @@ void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* e
 		                   n_blocks);
 		uint4* tt = ei; ei = eo; eo = tt;
 	}
-	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ei, tile_start);
+	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ei, tile_start, big_tiles, flags);
 	*elems_sorted = ei;
 	*elems_free = eo;
 }
 
-// Size classes: (0, 1024] -> 8 KB LDS, (1024, 4096] -> 32 KB, (4096, 8192] -> 64 KB, > 8192 -> hybrid.
-void launch_sort_tiles(int T, const uint32_t* tile_start, const uint4* elems, uint4* elems_free, uint32_t* point_list,
-                       hipStream_t s)
+// Size classes: (0, 1024] -> 8 KB LDS, one workgroup per tile; the wide classes (1024, 4096] -> 32 KB,
+// (4096, 8192] -> 64 KB and > 8192 -> hybrid take one entry of the big-tile list per workgroup.  n
+// instances can fill at most n / 1024 such tiles (n / 4096, n / 8192 for the wider classes), which
+// bounds their grids: a frame without long lists pays near-empty launches, not 3 x T idle workgroups.
+void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
+                       const uint4* elems, uint4* elems_free, uint32_t* point_list, hipStream_t s)
 {
-	hipLaunchKernelGGL((k_sort_tiles<1024, 256>), dim3(T), dim3(256), 0, s, T, 0, tile_start, elems, point_list);
-	hipLaunchKernelGGL((k_sort_tiles<4096, 512>), dim3(T), dim3(512), 0, s, T, 1024, tile_start, elems, point_list);
-	hipLaunchKernelGGL((k_sort_tiles<8192, 1024>), dim3(T), dim3(1024), 0, s, T, 4096, tile_start, elems, point_list);
-	hipLaunchKernelGGL(k_sort_tiles_global, dim3(T), dim3(BSR_SORT_NT), 0, s, T, BSR_SORT_CHUNK, tile_start, elems,
-	                   reinterpret_cast<uint64_t*>(elems_free), point_list);
+	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, tile_start, elems, point_list);
+	const int g1 = min(T, n / BSR_SORT_SMALL), g4 = min(T, n / 4096), g8 = min(T, n / BSR_SORT_CHUNK);
+	if (g1 > 0)
+		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, tile_start,
+		                   big_tiles, flags, elems, point_list);
+	if (g4 > 0)
+		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, tile_start, big_tiles,
+		                   flags, elems, point_list);
+	if (g8 > 0)
+		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, tile_start, big_tiles, flags, elems,
+		                   reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 
 }  // namespace bsr

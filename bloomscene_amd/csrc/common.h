@@ -45,7 +45,8 @@ struct ImgState {
 	float* final_T;        // [N]
 	uint32_t* n_contrib;   // [N]
 	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
-	int* flags;            // [4]: prefiltered violation | - | kept instances | rect tiles (= reference num_rendered)
+	int* flags;            // [4]: prefiltered violation | #big_tiles | kept instances | rect tiles (= reference num_rendered)
+	uint32_t* big_tiles;   // [T] tiles with more than 1024 instances (any order): work list of the wide sort kernels
 	static size_t bytes(size_t N, size_t T);
 	static ImgState carve(char* p, size_t N, size_t T);
 };

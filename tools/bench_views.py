@@ -67,6 +67,13 @@ def main():
         return views.render_views_sharded(cams, bufs, bg, deg, rank=rank, world=world)
 
     sweep()   # warm-up (allocator, first-touch)
+    from bloomscene_amd import _capi
+    _capi.profile_enable(True)
+    _capi.profile_reset()
+    sweep()
+    torch.cuda.synchronize()
+    stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in _capi.profile_read().items()}   # mean per view
+    _capi.profile_enable(False)
     times = []
     for _ in range(args.repeats):
         if world > 1:
@@ -93,7 +100,8 @@ def main():
             "workload": f"c4: {P} Gaussians scene B, SH deg {deg}, {W}x{H}, {args.views}-view rotate360 sweep, fwd only",
             "n_gpus": world, "views": args.views, "views_rank0": len(mine), "seconds": round(t, 5),
             "ms_per_view": round(t / len(mine) * 1e3, 4), "value": round(args.views * P / t / 1e6, 2),
-            "unit": "Msplats/s", "broadcast_ms": round(bcast_ms, 3), "visible_first_view": visible}), flush=True)
+            "unit": "Msplats/s", "broadcast_ms": round(bcast_ms, 3), "visible_first_view": visible,
+            "stage_ms_per_view_rank0": stage_ms}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
