@@ -25,6 +25,7 @@ CASES = {
     "sh3_dense_48x48": dict(P=2500, W=48, H=48, deg=3, seed=4, scale_mul=10.0),
     "sh1_extraM_scalemod_80x48": dict(P=1000, W=80, H=48, deg=1, seed=5, M_extra=5, scale_modifier=1.7, bg=(1.0, 0.5, 0.0)),
     "shell_view3_96x64": dict(P=2000, W=96, H=64, deg=2, seed=6, scene="b", view=3, scale_mul=5.0),
+    "sh3_free_camera_120x80": dict(P=1500, W=120, H=80, deg=3, seed=8, scale_mul=3.0, free_camera=True),
 }
 
 
@@ -54,7 +55,10 @@ def golden_arrays(c):
 
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])   # optional: names to (re)generate; default all
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         c = Hh.make_case(**kw)
         arrs = golden_arrays(c)
         path = os.path.join(HERE, name + ".npz")

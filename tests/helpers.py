@@ -32,12 +32,29 @@ def cov3d_from_scale_rot(scales, rotations, mod=1.0):
 
 def make_case(P, W, H, deg, seed=0, scene="a", view=0, color_mode="sh", cov_mode="scale_rot", bg=(0.1, 0.2, 0.3),
               scale_mul=1.0, scale_modifier=1.0, near_fraction=0.0, M_extra=0, squeeze_xy=1.0, big_count=0,
-              big_mul=60.0):
+              big_mul=60.0, free_camera=False):
     """One rasterizer call's worth of CPU inputs (torch fp32) + camera."""
     sc = scene_a(P, W, H, deg, seed=seed) if scene == "a" else scene_b(P, W, H, deg, seed=seed)
     cam = sc.cameras[view]
     c = SimpleNamespace(P=P, W=W, H=H, deg=deg, cam=cam)
     c.means3D = sc.means3D.clone()
+    if free_camera:
+        # Arbitrarily rotated AND translated camera (non-zero campos, full 4x4 view matrix), built the
+        # way the reference builds cameras (scene/dataset_readers.py:124-131 via make_minicam); the
+        # scene is carried along so it stays in view: W2C = [R^T | t]  =>  p_world = R (p_cam - t).
+        import numpy as np
+        from bloomscene_amd.cameras import make_minicam
+        g = torch.Generator().manual_seed(seed + 57)
+        q = torch.randn(4, generator=g).double()
+        q = (q / q.norm()).tolist()
+        r, x, y, z = q
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                       [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                       [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+        t = (torch.randn(3, generator=g).double() * 2.0).numpy()
+        cam = make_minicam(Rm, t, cam.FoVx, cam.FoVy, W, H)
+        c.cam = cam
+        c.means3D = ((c.means3D.double() - torch.from_numpy(t)) @ torch.from_numpy(Rm).T).float().contiguous()
     if near_fraction > 0 and P > 0:   # push some Gaussians behind / next to the near plane
         g = torch.Generator().manual_seed(seed + 99)
         k = max(1, int(P * near_fraction))

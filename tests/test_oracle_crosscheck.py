@@ -13,7 +13,8 @@ import helpers as Hh
 from oracle import oracle as O
 from oracle import torch_splat as TS
 
-TOL = 2e-5   # fp32 oracle vs fp64 autograd, relative to the largest magnitude of the tensor
+TOL = 5e-5   # fp32 oracle vs fp64 autograd, relative to the largest magnitude of the tensor (a general
+             # camera rotation makes every view-matrix entry inexact: up to 2.5e-5 seen; identity: 1e-5)
 
 
 def _rel(a, b):
@@ -30,6 +31,8 @@ def _rel(a, b):
     dict(P=250, W=45, H=30, deg=0, seed=9, scale_mul=6.0, color_mode="precomp"),
     dict(P=250, W=45, H=30, deg=2, seed=10, scale_mul=6.0, cov_mode="precomp"),
     dict(P=300, W=40, H=24, deg=1, seed=12, scale_mul=8.0, scene="b", view=9),
+    dict(P=300, W=48, H=32, deg=3, seed=14, scale_mul=6.0, free_camera=True),    # campos != 0, general W2C
+    dict(P=250, W=40, H=40, deg=2, seed=15, scale_mul=6.0, free_camera=True, cov_mode="precomp"),
 ])
 def test_oracle_matches_autograd(kw):
     c = Hh.make_case(**kw)

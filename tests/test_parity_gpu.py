@@ -47,6 +47,9 @@ CASES = {
     "lists_gt_1024": dict(P=20000, W=48, H=48, deg=1, seed=7, scale_mul=12.0),       # 64-KB LDS sort class
     "lists_gt_8192": dict(P=30000, W=20, H=20, deg=0, seed=8, scale_mul=30.0),       # global-memory sort class
     "clustered_84k_list": dict(P=150000, W=640, H=360, deg=1, seed=5, scale_mul=3.0, squeeze_xy=0.08, big_count=300),
+    "free_camera_sh3": dict(P=3000, W=200, H=120, deg=3, seed=13, scale_mul=3.0, free_camera=True),
+    "free_camera_precomp_cov": dict(P=2000, W=97, H=61, deg=2, seed=14, scale_mul=4.0, free_camera=True,
+                                    cov_mode="precomp", near_fraction=0.05),
     "single_pixel": dict(P=200, W=1, H=1, deg=0, seed=9, scale_mul=50.0),
     "one_gaussian": dict(P=1, W=40, H=40, deg=3, seed=10, scale_mul=40.0),
     "huge_splats": dict(P=300, W=70, H=50, deg=0, seed=11, scale_mul=2000.0),
@@ -169,7 +172,8 @@ def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD):
 
 
 BWD_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "extraM_scalemod_bg", "shell_view",
-             "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "huge_splats", "c2_100k_800x800"]
+             "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "free_camera_sh3",
+             "free_camera_precomp_cov", "huge_splats", "c2_100k_800x800"]
 
 
 @pytest.mark.parametrize("name", BWD_CASES)
@@ -218,7 +222,8 @@ def test_backward_stagewise_vs_oracle(name):
         assert not out[k][~vis].any(), k   # culled rows are exactly zero
 
 
-@pytest.mark.parametrize("name", ["sh3", "precomp_color", "precomp_cov", "shell_view", "c2_100k_800x800"])
+@pytest.mark.parametrize("name", ["sh3", "precomp_color", "precomp_cov", "shell_view", "free_camera_sh3",
+                                  "c2_100k_800x800"])
 def test_autograd_end_to_end(name):
     """The reference call shape (gaussian_renderer/__init__.py:224-262) through torch.autograd."""
     c = Hh.make_case(**CASES[name])
