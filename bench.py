@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--colors", default="sh", choices=["sh", "precomp"],
                     help="precomp: colors_precomp[P,3] instead of SHs, the call shape of the reference's render() "
                          "(gaussian_renderer/__init__.py:254-262); experiments only, the metric is quoted on sh")
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="N > 1 only: data-parallel training over views -- sum the per-view gradients with one "
+                         "packed RCCL all-reduce inside every step (SURVEY.md §8f rank 3); off by default, the "
+                         "metric's path has no data-path collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -91,7 +95,7 @@ def main():
 
     from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
     from bloomscene_amd.synthetic import scene_a, upstream_grads
-    from bloomscene_amd.views import broadcast_gaussians, yawed_camera
+    from bloomscene_amd.views import allreduce_gradients, broadcast_gaussians, yawed_camera
 
     P, W, H, deg, do_bwd = CONFIGS[args.config]
     if args.gaussians:
@@ -136,6 +140,8 @@ def main():
             for v in leaves.values():
                 v.grad = None
             torch.autograd.backward((color, depth), (gC, gD))
+            if args.allreduce_grads and world > 1:
+                state["allreduce_ms"] = state.get("allreduce_ms", 0.0) + allreduce_gradients(leaves)
         state["radii"] = radii
 
     def fence():
@@ -200,7 +206,9 @@ def main():
             "config": {"workload": f"{args.config}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
                                    f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}, synthetic scene A seed 0",
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
-                       "visible": visible, "parallelism": f"view-parallel x{world}",
+                       "visible": visible,
+                       "parallelism": f"view-parallel x{world}" + (" + gradient all-reduce" if args.allreduce_grads
+                                                                    and world > 1 and do_bwd else ""),
                        "broadcast_ms": round(bcast_ms, 3)},
             "roofline": roofline,
             "roofline_step": {"algorithmic_bytes": sb, "achieved": round(whole, 2),

@@ -1,5 +1,6 @@
 """N > 1 path on CPU: world_size-2 `gloo` processes exercise the view sharding and the packed
-broadcast of the Gaussian buffers (the only collective of the path; RCCL on the GPU box)."""
+broadcast of the Gaussian buffers (the only collective of the inference path; RCCL on the GPU
+box) and the packed gradient all-reduce of data-parallel training over views (§8f rank 3)."""
 import os
 import socket
 
@@ -35,6 +36,19 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(gathered, mine)
         flat = sorted(i for part in gathered for i in part)
         ok = ok and flat == list(range(64)) and mine == list(range(rank, 64, world))
+        # data-parallel training step: per-rank gradients -> one packed all-reduce (sum and mean)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in src.items()}
+        for i, (k, v) in enumerate(sorted(leaves.items())):
+            if not (rank == 1 and k == "scales"):      # rank 1 has no gradient for `scales`
+                v.grad = torch.full_like(v, float(rank + 1) * (i + 1))
+        views.allreduce_gradients(leaves, average=False)
+        for i, (k, v) in enumerate(sorted(leaves.items())):
+            want = (1.0 if k == "scales" else 3.0) * (i + 1)
+            ok = ok and v.grad is not None and bool((v.grad == want).all())
+        views.allreduce_gradients(list(leaves.values()), average=True)   # all ranks now hold equal grads
+        for i, (k, v) in enumerate(sorted(leaves.items())):
+            want = (1.0 if k == "scales" else 3.0) * (i + 1)
+            ok = ok and bool((v.grad == want).all())
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -58,3 +72,6 @@ def test_broadcast_and_view_sharding_world2():
 def test_broadcast_is_a_noop_without_process_group():
     b = {"means3D": torch.ones(3, 3)}
     assert views.broadcast_gaussians(b) == 0.0 and torch.equal(b["means3D"], torch.ones(3, 3))
+    p = torch.ones(3, requires_grad=True)
+    p.grad = torch.full((3,), 2.0)
+    assert views.allreduce_gradients([p]) == 0.0 and torch.equal(p.grad, torch.full((3,), 2.0))
