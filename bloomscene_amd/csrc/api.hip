@@ -82,6 +82,10 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 // ---------------------------------------------------------------- kernels (other translation units)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
+void launch_visible_filter_views(int P, int V, const float* means3D, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
+                                 const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
+                                 hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
 void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
                     int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles, int* flags, uint4** elems_sorted,
@@ -340,6 +344,26 @@ int bsr_visible_filter(int P, int M, int width, int height, const float* means3D
 		HIP_TRY(hipFreeAsync(d_flag, s));
 		if (h) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
 	}
+	return 0;
+}
+
+int bsr_visible_filter_views(int P, int n_views, int width, int height, const float* means3D, const float* scales,
+                             float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                             const float* viewmatrices, const float* projmatrices, float tan_fovx, float tan_fovy,
+                             int* radii, int debug, void* stream)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (n_views < 0) return fail("n_views must be >= 0");
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrices, projmatrices)) return 1;
+	if (P == 0 || n_views == 0) return 0;
+	if (!radii) return fail("radii is null");
+	{
+		StageTimer t("visible_filter_views", s);
+		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
+		                            projmatrices, width, height, tan_fovx, tan_fovy, radii, s);
+	}
+	STAGE_CHECK("visible_filter_views", debug, s);
 	return 0;
 }
 

@@ -267,6 +267,73 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
 	present[idx] = !(pvz <= BSR_NEAR);
 }
 
+// visible_filter for V cameras in one pass over the Gaussians: the mean and the
+// view-independent 3-D covariance are loaded/built once, then every view repeats exactly the
+// arithmetic of k_preprocess<true> (same helpers, same order), so radii[v] is bit-identical to a
+// single-view call with camera v.  Camera matrices are wave-uniform -> scalar loads.
+__global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, const float* __restrict__ means3D,
+                                                              const float* __restrict__ scales, float scale_modifier,
+                                                              const float* __restrict__ rotations,
+                                                              const float* __restrict__ cov3D_precomp,
+                                                              const float* __restrict__ viewmatrices,
+                                                              const float* __restrict__ projmatrices, int W, int H,
+                                                              float focal_x, float focal_y, float tan_fovx,
+                                                              float tan_fovy, int gx, int gy, int* __restrict__ radii)
+{
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= P) return;
+	const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+	float cov3D[6];
+	if (cov3D_precomp != nullptr) {
+#pragma unroll
+		for (int k = 0; k < 6; k++) cov3D[k] = cov3D_precomp[(size_t)idx * 6 + k];
+	} else {
+		const float sc[3] = {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]};
+		const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+		cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
+	}
+	for (int v = 0; v < V; v++) {
+		const float* vm = viewmatrices + 16 * v;
+		const float* pm = projmatrices + 16 * v;
+		int radius_out = 0;
+		const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+		if (!(pvz <= BSR_NEAR)) {
+			const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+			const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+			const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+			const float p_w = 1.0f / (hw + 0.0000001f);
+			const float projx = hx * p_w, projy = hy * p_w;
+			Cov2DTerms tt;
+			cov2d_terms(p, focal_x, focal_y, tan_fovx, tan_fovy, vm, tt);
+			float ca, cb, cc;
+			cov2d_eval(tt, cov3D, ca, cb, cc);
+			const float det = (ca * cc - cb * cb);
+			if (det != 0.0f) {
+				const float mid = 0.5f * (ca + cc);
+				const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+				const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+				const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+				const float pix_x = ndc2pix(projx, W), pix_y = ndc2pix(projy, H);
+				int rmin[2], rmax[2];
+				get_rect(pix_x, pix_y, (int)my_radius, gx, gy, rmin, rmax);
+				if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) != 0) radius_out = (int)my_radius;
+			}
+		}
+		radii[(size_t)v * P + idx] = radius_out;
+	}
+}
+
+void launch_visible_filter_views(int P, int V, const float* means3D, const float* scales, float scale_modifier,
+                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
+                                 const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
+                                 hipStream_t s)
+{
+	hipLaunchKernelGGL(k_visible_filter_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, means3D, scales,
+	                   scale_modifier, rotations, cov3D_precomp, viewmatrices, projmatrices, W, H,
+	                   W / (2.0f * tan_fovx), H / (2.0f * tan_fovy), tan_fovx, tan_fovy, (W + BSR_TILE - 1) / BSR_TILE,
+	                   (H + BSR_TILE - 1) / BSR_TILE, radii);
+}
+
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s)
 {
 	const int blocks = (a.P + 255) / 256;

@@ -195,6 +195,32 @@ def _rasterize_gaussians_filter_native(means3D, scales, rotations, scale_modifie
     return radii
 
 
+def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
+                                             projmatrices, tan_fovx, tan_fovy, image_height, image_width, debug):
+    """visible_filter for V cameras in one pass (bsr_visible_filter_views): -> int32 [V, P]."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P = means3D.size(0)
+    if viewmatrices.dim() != 3 or tuple(viewmatrices.shape[1:]) != (4, 4) or viewmatrices.shape != projmatrices.shape:
+        raise RuntimeError("viewmatrices and projmatrices must both have dimensions (num_views, 4, 4)")
+    V = viewmatrices.size(0)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    if P != 0 and V != 0:
+        m = _dev_f32(means3D, "means3D", dev)
+        s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)
+        c = _dev_f32(cov3D_precomp, "cov3D_precomp", dev)
+        v, p = _dev_f32(viewmatrices, "viewmatrices", dev), _dev_f32(projmatrices, "projmatrices", dev)
+        with torch.cuda.device(dev):
+            rc = _capi.lib().bsr_visible_filter_views(
+                P, V, int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier), _ptr(r),
+                _ptr(c), v.data_ptr(), p.data_ptr(), float(tan_fovx), float(tan_fovy), radii.data_ptr(),
+                int(bool(debug)), _stream_handle(dev))
+        _capi.check(rc, "rasterize_gaussians_filter_views")
+    return radii
+
+
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):

@@ -145,6 +145,30 @@ def prefilter(cam: MiniCam, means3D, scales, rotations, bg_color, scaling_modifi
     return radii_pure > 0
 
 
+def prefilter_views(cams, means3D, scales, rotations, scaling_modifier=1.0, debug=False):
+    """prefilter_voxel for a whole camera path at once: bool [V, P], row v equal
+    to ``prefilter(cams[v], ...)``.  The reference filters the anchors once per view of the rotate360
+    sweep (bloomscene.py:191-193 -> GR:342-349); here the anchors are read, and their 3-D covariances
+    built, once for all V views.  All cameras must share image size and field of view (they do in
+    the sweep: utils/trajectory.py:110-121)."""
+    from .rasterizer import _rasterize_gaussians_filter_views_native
+    if not cams:
+        return torch.zeros((0, means3D.shape[0]), dtype=torch.bool, device=means3D.device)
+    c0 = cams[0]
+    for c in cams:
+        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx \
+                or c.FoVy != c0.FoVy:
+            raise ValueError("prefilter_views needs cameras of one image size and field of view")
+    dev = means3D.device
+    vms = torch.stack([c.world_view_transform.to(dev) for c in cams]).contiguous()
+    pms = torch.stack([c.full_proj_transform.to(dev) for c in cams]).contiguous()
+    with torch.no_grad():
+        radii = _rasterize_gaussians_filter_views_native(
+            means3D, scales[:, :3], rotations, scaling_modifier, torch.Tensor([]), vms, pms,
+            math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5), int(c0.image_height), int(c0.image_width), debug)
+    return radii > 0
+
+
 def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, world=None, keep_outputs=False):
     """The rotate360 loop of BloomScene.render_video (reference bloomscene.py:191-211), sharded:
     this rank renders its round-robin share of ``cams`` with torch.no_grad() and returns

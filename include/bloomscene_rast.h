@@ -106,6 +106,26 @@ int bsr_visible_filter(int P, int M,
                        int debug,
                        void* stream);
 
+/* bsr_visible_filter for n_views cameras of one image size and field of view in ONE pass over the
+ * Gaussians: radii[v*P + i] is exactly what bsr_visible_filter writes to radii[i] with
+ * viewmatrices + 16*v / projmatrices + 16*v (DEVICE float[n_views,16] each).  Each Gaussian is read,
+ * and its 3-D covariance built, once for all views.  No reference counterpart: the reference calls
+ * visible_filter once per view of the rotate360 sweep (gaussian_renderer/__init__.py:342-347 from
+ * bloomscene.py:191-193); SURVEY.md §8f rank 2. */
+int bsr_visible_filter_views(int P, int n_views,
+                             int width, int height,
+                             const float* means3D,
+                             const float* scales,
+                             float scale_modifier,
+                             const float* rotations,
+                             const float* cov3D_precomp,
+                             const float* viewmatrices,
+                             const float* projmatrices,
+                             float tan_fovx, float tan_fovy,
+                             int* radii,
+                             int debug,
+                             void* stream);
+
 /* Backward pass for the forward call that produced (radii, geom/binning/image buffers, R).
  * dL_dpix is [3,H,W]; dL_depths [1,H,W] is accepted and ignored exactly like the reference
  * (backward.cu:457-463,539-554).  All nine gradient outputs are FULLY OVERWRITTEN (no pre-zeroing

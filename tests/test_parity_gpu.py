@@ -27,6 +27,8 @@ import os
 
 import numpy as np
 import pytest
+import math
+
 import torch
 
 import helpers as Hh
@@ -306,6 +308,43 @@ def test_visible_filter_and_mark_visible():
     cov = Hh.cov3d_from_scale_rot(c.scales, c.rotations)
     radii2 = rast.visible_filter(c.means3D.to(dev), cov3D_precomp=cov.to(dev))
     np.testing.assert_array_equal(radii2.cpu().numpy(), O.visible_filter(rs, c.means3D, cov3D_precomp=cov))
+
+
+def test_multi_view_visible_filter_equals_per_view_calls():
+    """bsr_visible_filter_views: row v bit-equal to the single-view filter and to
+    the oracle's visible_filter with camera v, on the rotate360 path with 6-column anchor scales."""
+    from bloomscene_amd import views
+    from bloomscene_amd.synthetic import scene_b
+    dev = _dev()
+    P, W, H, V = 20000, 320, 180, 16
+    sc = scene_b(P, W, H, 1, n_views=V, seed=3)
+    scales6 = torch.cat([sc.scales * 6.0, torch.rand(P, 3)], dim=1)     # anchors carry 6 scale columns (GR:345)
+    means, rots = sc.means3D.to(dev), sc.rotations.to(dev)
+    masks = views.prefilter_views([c.to(dev) for c in sc.cameras], means, scales6.to(dev), rots)
+    assert masks.shape == (V, P) and masks.dtype == torch.bool
+    for v, cam in enumerate(sc.cameras):
+        single = views.prefilter(cam.to(dev), means, scales6.to(dev), rots, torch.zeros(3, device=dev))
+        assert torch.equal(masks[v], single), v
+        rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
+                             cam.world_view_transform, cam.full_proj_transform, 1, cam.camera_center)
+        want = O.visible_filter(rs, sc.means3D, scales=scales6[:, :3].contiguous(), rotations=sc.rotations)
+        np.testing.assert_array_equal(masks[v].cpu().numpy(), want > 0)
+        assert 0 < int(masks[v].sum()) < P
+    # radii themselves (not only the mask), through the native entry point
+    from bloomscene_amd import rasterizer as RZ
+    vms = torch.stack([c.world_view_transform for c in sc.cameras]).to(dev)
+    pms = torch.stack([c.full_proj_transform for c in sc.cameras]).to(dev)
+    cam = sc.cameras[0]
+    radii = RZ._rasterize_gaussians_filter_views_native(
+        means, scales6[:, :3].contiguous().to(dev), rots, 1.0, torch.Tensor([]), vms, pms, math.tan(cam.FoVx * 0.5),
+        math.tan(cam.FoVy * 0.5), H, W, False)
+    rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
+                         sc.cameras[5].world_view_transform, sc.cameras[5].full_proj_transform, 1,
+                         sc.cameras[5].camera_center)
+    np.testing.assert_array_equal(radii[5].cpu().numpy(),
+                                  O.visible_filter(rs, sc.means3D, scales=scales6[:, :3].contiguous(),
+                                                   rotations=sc.rotations))
+    assert views.prefilter_views([], means, scales6.to(dev), rots).shape == (0, P)
 
 
 def test_empty_inputs_errors_debug_and_streams():

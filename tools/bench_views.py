@@ -94,6 +94,20 @@ def main():
     with torch.no_grad():
         res = views.render_view(cams[mine[0]], bufs, bg, deg)
         visible = int(res["visibility_filter"].sum().item())
+    # anchor prefilter of the whole path (§8f rank 2): one call per view (reference shape) vs one batched call
+    scales6 = torch.cat([bufs["scales"], bufs["scales"]], dim=1)
+    mine_cams = [cams[i] for i in mine]
+
+    def _time(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3 * 1e3
+    pf_per_view = _time(lambda: [views.prefilter(c, bufs["means3D"], scales6, bufs["rotations"], bg) for c in mine_cams])
+    pf_batched = _time(lambda: views.prefilter_views(mine_cams, bufs["means3D"], scales6, bufs["rotations"]))
     if rank == 0:
         t = sorted(times)[len(times) // 2]
         print(json.dumps({
@@ -101,7 +115,9 @@ def main():
             "n_gpus": world, "views": args.views, "views_rank0": len(mine), "seconds": round(t, 5),
             "ms_per_view": round(t / len(mine) * 1e3, 4), "value": round(args.views * P / t / 1e6, 2),
             "unit": "Msplats/s", "broadcast_ms": round(bcast_ms, 3), "visible_first_view": visible,
-            "stage_ms_per_view_rank0": stage_ms}), flush=True)
+            "stage_ms_per_view_rank0": stage_ms,
+            "prefilter_ms_rank0": {"per_view_calls": round(pf_per_view, 3), "one_batched_call": round(pf_batched, 3),
+                                   "views": len(mine)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
