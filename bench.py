@@ -72,6 +72,9 @@ def main():
                     help="N > 1 only: data-parallel training over views -- sum the per-view gradients with one "
                          "packed RCCL all-reduce inside every step (SURVEY.md §8f rank 3); off by default, the "
                          "metric's path has no data-path collective")
+    ap.add_argument("--depth-gradient", action="store_true",
+                    help="opt-in extension: also backpropagate the depth target (bsr_backward_depth); the metric "
+                         "is quoted without it (the reference ignores grad_depth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -126,7 +129,7 @@ def main():
         image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
         bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
         projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(settings)
+    rasterizer = GaussianRasterizer(settings, depth_gradient=args.depth_gradient)
     leaves = {k: v.requires_grad_(do_bwd) for k, v in bufs.items()}
     state = {}
 
@@ -198,13 +201,14 @@ def main():
         whole = sb / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline"
-            if args.config == "c3" and not precomp and not args.gaussians
+            if args.config == "c3" and not precomp and not args.gaussians and not args.depth_gradient
             else f"Msplats/s ({args.config})",
             "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
-                                   f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}, synthetic scene A seed 0",
+                                   f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
+                                   f"{' WITH depth gradient (extension)' if args.depth_gradient and do_bwd else ''}, synthetic scene A seed 0",
                        "gaussians": P, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
                        "visible": visible,
                        "parallelism": f"view-parallel x{world}" + (" + gradient all-reduce" if args.allreduce_grads

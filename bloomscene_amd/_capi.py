@@ -40,6 +40,9 @@ SIGNATURES = {
     "bsr_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
                                _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
                                _F, _F, _F, _F, C.c_int, C.c_void_p]),
+    "bsr_backward_depth": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
+                                     _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
+                                     _F, _F, _F, _F, _F, _F, C.c_int, C.c_void_p]),
     "bsr_geometry_bytes": (C.c_size_t, [C.c_int]),
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),

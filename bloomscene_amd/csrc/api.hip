@@ -97,7 +97,8 @@ void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
                        float* out_depth, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
-                       const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s);
+                       const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
+                       uint32_t* slot_of, float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- errors
@@ -471,16 +472,18 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	return 0;
 }
 
-int bsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
-                 char* binning_buffer, char* image_buffer, const float* dL_dpix, const float* dL_depths,
-                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
-                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+}  // extern "C"
+
+// out_depth == nullptr: the reference's backward (dL_depths ignored); otherwise the depth-gradient extension
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                         char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                         const float* out_depth, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
+                         float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
-	(void)dL_depths;   // accepted and ignored, as in the reference (backward.cu:457-463,539-554)
-	(void)colors_precomp;
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (P == 0) return 0;
@@ -518,7 +521,7 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 		{
 			StageTimer t("render_bwd", s);
 			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
-			                  img.n_contrib, dL_dpix, slot_of, slab, s);
+			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slot_of, slab, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}
@@ -531,7 +534,7 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	a.focal_y = height / (2.0f * tan_fovy);
 	a.focal_x = width / (2.0f * tan_fovx);
 	a.geom = geom;
-	a.slot_of = slot_of; a.slab = slab;
+	a.slot_of = slot_of; a.slab = slab; a.depth_grad = out_depth != nullptr;
 	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
 	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
 	{
@@ -540,6 +543,44 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	}
 	STAGE_CHECK("preprocess_bwd", debug, s);
 	return 0;
+}
+
+extern "C" {
+
+int bsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer,
+                 char* binning_buffer, char* image_buffer, const float* dL_dpix, const float* dL_depths,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+	(void)dL_depths;   // accepted and ignored, as in the reference (backward.cu:457-463,539-554)
+	(void)colors_precomp;
+	return backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
+	                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, nullptr, nullptr, dL_dmean2D, dL_dconic, dL_dopacity,
+	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
+}
+
+int bsr_backward_depth(int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                       float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* out_depth, const float* dL_dpix, const float* dL_depths, float* dL_dmean2D,
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                       float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+	(void)colors_precomp;
+	if (P > 0 && (!out_depth || !dL_depths)) {
+		g_err[0] = 0;
+		return fail("bsr_backward_depth needs out_depth and dL_depths");
+	}
+	return backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
+	                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, out_depth, dL_depths, dL_dmean2D, dL_dconic, dL_dopacity,
+	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
 }
 
 }  // extern "C"

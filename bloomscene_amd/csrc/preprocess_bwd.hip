@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
 	// the order is fixed, so the per-Gaussian sums do not depend on scheduling.
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float g_z = 0.f;   // dL/d(view z): written only by the depth-gradient variant of k_render_bwd (else 0)
 	{
 		const uint32_t area = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
@@ -179,6 +180,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 			g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
 			g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
 			g[8] += s2.x;
+			g_z += s2.y;
 		}
 	}
 	if (in_range) {
@@ -355,6 +357,11 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	}
 	if (!in_range) return;
 
+	if (a.depth_grad && visible) {   // z_view = vm[2] x + vm[6] y + vm[10] z + vm[14]
+		dmean[0] += a.viewmatrix[2] * g_z;
+		dmean[1] += a.viewmatrix[6] * g_z;
+		dmean[2] += a.viewmatrix[10] * g_z;
+	}
 	a.dL_dmean3D[3 * idx] = dmean[0];
 	a.dL_dmean3D[3 * idx + 1] = dmean[1];
 	a.dL_dmean3D[3 * idx + 2] = dmean[2];

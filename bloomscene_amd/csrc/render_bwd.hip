@@ -98,6 +98,29 @@ __device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float 
 	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
+// Ten values (depth-gradient extension): the ninth and tenth share a register the way 0..7 do, so on
+// return lanes with lane&8 hold component 8 + (lane&1).  35 VALU instructions.
+__device__ __forceinline__ float wave_sums10_butterfly(float x0, float x1, float x2, float x3, float x4, float x5,
+                                                       float x6, float x7, float x8, float x9, int lane)
+{
+	const bool b1 = (lane & 1) != 0, b2 = (lane & 2) != 0, b4 = (lane & 4) != 0, b8 = (lane & 8) != 0;
+	const float a0 = (b1 ? x4 : x0) + dpp_mov<0xB1>(b1 ? x0 : x4);
+	const float a1 = (b1 ? x5 : x1) + dpp_mov<0xB1>(b1 ? x1 : x5);
+	const float a2 = (b1 ? x6 : x2) + dpp_mov<0xB1>(b1 ? x2 : x6);
+	const float a3 = (b1 ? x7 : x3) + dpp_mov<0xB1>(b1 ? x3 : x7);
+	float y = (b1 ? x9 : x8) + dpp_mov<0xB1>(b1 ? x8 : x9);
+	const float c0 = (b2 ? a2 : a0) + dpp_mov<0x4E>(b2 ? a0 : a2);
+	const float c1 = (b2 ? a3 : a1) + dpp_mov<0x4E>(b2 ? a1 : a3);
+	y = y + dpp_mov<0x4E>(y);
+	float d = (b4 ? c1 : c0) + dpp_mov<0x124>(b4 ? c0 : c1);
+	y = y + dpp_mov<0x124>(y);
+	d = (b8 ? y : d) + dpp_mov<0x128>(b8 ? d : y);
+	auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+	d = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+	auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 // Index of this tile's instance of a Gaussian in the Gaussian-major order of KEPT instances (its
 // block starts at inst_offset and enumerates the kept tiles of its rect row-major), from q3 / q2.w of
 // the splat record.
@@ -112,12 +135,18 @@ __device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ 
 }
 
 #define BSR_BWD_BATCH 128
+template <int NV>
 struct BwdShared {
 	TileStageT<BSR_BWD_BATCH> st;
-	float part[4][9][BSR_BWD_BATCH];   // per-wave partial sums of the current batch (plain stores)
+	float part[4][NV][BSR_BWD_BATCH];   // per-wave partial sums of the current batch (plain stores)
 	uint32_t max_contrib[4];
 };
 
+// DEPTH = false: the reference's backward (dL_depths ignored).  DEPTH = true: the opt-in extension
+// that also differentiates the normalised depth target (math in
+// oracle/bsr_oracle.c:bsro_render_backward_depth): a tenth partial sum dL/dz per instance and one more
+// term in dL/dalpha.  out_depth is the forward's depth image (its zeros are the acc <= 0.5 gate).
+template <bool DEPTH>
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, int W, int H,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
@@ -127,10 +156,13 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                                                           const float* __restrict__ final_Ts,
                                                           const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpixels,
+                                                          const float* __restrict__ out_depth,   // DEPTH only
+                                                          const float* __restrict__ dL_depths,   // DEPTH only
                                                           uint32_t* __restrict__ slot_of,   // [R]
                                                           float4* __restrict__ slab)        // [R][3]
 {
-	__shared__ BwdShared sh;
+	constexpr int NV = DEPTH ? 10 : 9;
+	__shared__ BwdShared<NV> sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
@@ -160,8 +192,17 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	}
 	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
 	const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;
-	// component whose wave total lands in this lane after wave_sums9_butterfly (lanes 0..8 store)
-	const int comp_of_lane = (lane & 8) ? 8 : (((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1));
+	// depth extension: d_i = gz * z_i + g1 plays the role of a fourth colour channel
+	float gz = 0.f, g1 = 0.f, Rd = 0.f;
+	if (DEPTH && inside) {
+		const float depth_px = out_depth[pix_id];
+		if (depth_px != 0.0f) {   // the forward's acc > 0.5 decision
+			gz = dL_depths[pix_id] / (1e-6f + (1.0f - T_final));
+			g1 = -gz * depth_px;
+		}
+	}
+	// component whose wave total lands in this lane after the butterfly (lanes 0..NV-1 store)
+	const int comp_of_lane = (lane & 8) ? (DEPTH ? 8 + (lane & 1) : 8) : (((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1));
 	float* const part_mine = &sh.part[wave][comp_of_lane][0];
 	const float ddelx_dx = (float)(0.5 * W);
 	const float ddely_dy = (float)(0.5 * H);
@@ -176,7 +217,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 #pragma unroll
 		for (int w = 0; w < 4; w++)
 #pragma unroll
-			for (int k = 0; k < 9; k++) sh.part[w][k][tid] = 0.f;
+			for (int k = 0; k < NV; k++) sh.part[w][k][tid] = 0.f;
 	}
 	__syncthreads();
 	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
@@ -222,7 +263,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// unchanged (T*1 = T, acc + 0*(c-acc) = acc) and all nine contributions are exactly 0.
 			const float alpha = active ? alpha_raw : 0.f;
 			const float G = active ? Graw : 0.f;
-			float v0, v1, v2, v3, v4, v5, v6, v7, v8;
+			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
 			{
 				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
 				// unordered), so this block may fuse multiply-adds and use a refined reciprocal
@@ -238,7 +279,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// accum_rec folded eagerly: acc' = alpha*c + (1-alpha)*acc is what the reference computes
 				// lazily at the next processed entry (:529); no last_alpha/last_color state is needed.
 				const float e0 = q2.x - accum_rec0, e1 = q2.y - accum_rec1, e2 = q2.z - accum_rec2;
-				const float S = e0 * dpx0 + e1 * dpx1 + e2 * dpx2;
+				float S = e0 * dpx0 + e1 * dpx1 + e2 * dpx2;
+				if (DEPTH) {
+					const float ed = __builtin_fmaf(gz, q1.w, g1) - Rd;
+					S += ed;
+					Rd = Rd + alpha * ed;
+				}
 				accum_rec0 = accum_rec0 + alpha * e0;
 				accum_rec1 = accum_rec1 + alpha * e1;
 				accum_rec2 = accum_rec2 + alpha * e2;
@@ -259,15 +305,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				v6 = aT * dpx0;
 				v7 = aT * dpx1;
 				v8 = aT * dpx2;
+				if (DEPTH) v9 = aT * gz;
 			}
-			const float tot = wave_sums9_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
-			if (lane < 9) part_mine[j] = tot;   // lane l holds component comp(l): one 9-lane store
+			const float tot = DEPTH ? wave_sums10_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane)
+			                        : wave_sums9_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
+			if (lane < NV) part_mine[j] = tot;   // lane l holds component comp(l): one NV-lane store
 		}
 		__syncthreads();
 		if (valid) {
-			float a9[9];
+			float a9[10];
+			a9[9] = 0.f;
 #pragma unroll
-			for (int k = 0; k < 9; k++) {   // fixed order over the 4 quadrants -> deterministic
+			for (int k = 0; k < NV; k++) {   // fixed order over the 4 quadrants -> deterministic
 				a9[k] = ((sh.part[0][k][tid] + sh.part[1][k][tid]) + sh.part[2][k][tid]) + sh.part[3][k][tid];
 				sh.part[0][k][tid] = 0.f;
 				sh.part[1][k][tid] = 0.f;
@@ -277,7 +326,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			float4* row = slab + (size_t)my_slot * 3;
 			row[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
 			row[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
-			row[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
+			row[2] = make_float4(a9[8], a9[9], 0.f, 0.f);
 		}
 		__syncthreads();
 	}
@@ -297,12 +346,17 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
-                       const uint32_t* n_contrib, const float* dL_dpix, uint32_t* slot_of, float4* slab, hipStream_t s)
+                       const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
+                       uint32_t* slot_of, float4* slab, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
-	hipLaunchKernelGGL(k_render_bwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
-	                   wg_base, bg, final_T, n_contrib, dL_dpix, slot_of, slab);
+	if (out_depth && dL_depths)
+		hipLaunchKernelGGL(k_render_bwd<true>, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start,
+		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, out_depth, dL_depths, slot_of, slab);
+	else
+		hipLaunchKernelGGL(k_render_bwd<false>, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start,
+		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, nullptr, nullptr, slot_of, slab);
 }
 
 }  // namespace bsr

@@ -116,8 +116,9 @@ def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations,
 def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rotations, scale_modifier,
                                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                          dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                         imageBuffer, debug):
-    """Counterpart of `_C.rasterize_gaussians_backward` = RasterizeGaussiansBackwardCUDA (RP:119-200)."""
+                                         imageBuffer, debug, out_depth=None):
+    """Counterpart of `_C.rasterize_gaussians_backward` = RasterizeGaussiansBackwardCUDA (RP:119-200).
+    ``out_depth`` (the forward's depth image) selects the depth-gradient extension bsr_backward_depth."""
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -142,16 +143,21 @@ def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rot
                  sh=_dev_f32(sh, "shs", dev), campos=_dev_f32(campos, "campos", dev),
                  gcol=_dev_f32(dL_dout_color, "dL_dout_color", dev), gdep=_dev_f32(dL_dout_depth, "dL_dout_depth", dev))
         radii_c = radii.contiguous()
-        with torch.cuda.device(dev):
-            rc = _capi.lib().bsr_backward(
-                P, int(degree), int(M), int(R), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]),
+        head = (P, int(degree), int(M), int(R), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]),
                 _ptr(t["colors"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
                 _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]), float(tan_fovx), float(tan_fovy),
                 radii_c.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr() if binningBuffer.numel() else None,
-                imageBuffer.data_ptr(), _ptr(t["gcol"]), _ptr(t["gdep"]), dL_dmeans2D.data_ptr(),
+                imageBuffer.data_ptr())
+        tail = (_ptr(t["gcol"]), _ptr(t["gdep"]), dL_dmeans2D.data_ptr(),
                 dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
                 dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
                 dL_drotations.data_ptr(), int(bool(debug)), _stream_handle(dev))
+        with torch.cuda.device(dev):
+            if out_depth is None:
+                rc = _capi.lib().bsr_backward(*head, *tail)
+            else:
+                od = _dev_f32(out_depth, "out_depth", dev)
+                rc = _capi.lib().bsr_backward_depth(*head, od.data_ptr(), *tail)
         _capi.check(rc, "rasterize_gaussians_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
@@ -223,9 +229,9 @@ def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_m
 
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, depth_gradient=False):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, depth_gradient)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -233,7 +239,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, depth_gradient=False):
         # same argument order as the reference hands to its C++ lib (PYW:60-80)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -265,8 +271,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             _RasterizeGaussians.last_final_T = None
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.depth_gradient = bool(depth_gradient)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
+        if ctx.depth_gradient:
+            ctx.out_depth = depth.detach().clone()   # the extension differentiates through this image
         return color, radii, depth
 
     @staticmethod
@@ -286,6 +295,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.projmatrix, raster_settings.tanfovx, raster_settings.tanfovy, grad_out_color,
                 grad_depth, sh, raster_settings.sh_degree, raster_settings.campos, geomBuffer, num_rendered,
                 binningBuffer, imgBuffer, raster_settings.debug)
+        if ctx.depth_gradient:
+            args = args + (ctx.out_depth,)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
@@ -314,14 +325,20 @@ class _RasterizeGaussians(torch.autograd.Function):
             _fit(grad_rotations, rotations),
             _fit(grad_cov3Ds_precomp, cov3Ds_precomp),
             None,
+            None,
         )
         return grads
 
 
 class GaussianRasterizer(nn.Module):  # PYW:172-249
-    def __init__(self, raster_settings):
+    def __init__(self, raster_settings, depth_gradient=False):
+        """``depth_gradient`` (extension, default off = the reference's behaviour): also backpropagate the
+        gradient of the depth output.  The reference accepts grad_depth and drops it (backward.cu:457-463,
+        539-554), so depth losses never move the Gaussians there; see include/bloomscene_rast.h
+        bsr_backward_depth."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.depth_gradient = bool(depth_gradient)
 
     def markVisible(self, positions):
         # Mark visible points (based on frustum culling for camera) with a boolean
@@ -357,9 +374,9 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
 
         if not return_alpha:
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings)
+                                       cov3D_precomp, raster_settings, self.depth_gradient)
         color, radii, depth = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
-                                                  rotations, cov3D_precomp, raster_settings)
+                                                  rotations, cov3D_precomp, raster_settings, self.depth_gradient)
         final_T = _RasterizeGaussians.last_final_T
         alpha = torch.zeros_like(depth) if final_T is None else (1.0 - final_T)
         return color, radii, depth, alpha.detach()

@@ -168,6 +168,46 @@ int bsr_backward(int P, int D, int M, int R,
                  int debug,
                  void* stream);
 
+/* EXTENSION (no reference counterpart): bsr_backward that ALSO differentiates
+ * the depth target.  The reference forward normalises out_depth = D / acc where acc > 0.5 (else 0;
+ * forward.cu:459-468) but its backward drops dL_depths (backward.cu:457-463,539-554), so BloomScene's
+ * depth regularisers (bloomscene.py:307-325) never reach the Gaussians.  This entry point adds the
+ * true derivative of that forward -- through alpha into mean2D / conic / opacity and through the
+ * view-space z into dL_dmean3D -- to everything bsr_backward computes.  out_depth is the [1,H,W]
+ * depth image the matching bsr_forward wrote.  Same outputs and overwrite rules as bsr_backward. */
+int bsr_backward_depth(int P, int D, int M, int R,
+                       const float* background,
+                       int width, int height,
+                       const float* means3D,
+                       const float* shs,
+                       const float* colors_precomp,
+                       const float* scales,
+                       float scale_modifier,
+                       const float* rotations,
+                       const float* cov3D_precomp,
+                       const float* viewmatrix,
+                       const float* projmatrix,
+                       const float* campos,
+                       float tan_fovx, float tan_fovy,
+                       const int* radii,
+                       char* geom_buffer,
+                       char* binning_buffer,
+                       char* image_buffer,
+                       const float* out_depth,
+                       const float* dL_dpix,
+                       const float* dL_depths,
+                       float* dL_dmean2D,
+                       float* dL_dconic,
+                       float* dL_dopacity,
+                       float* dL_dcolor,
+                       float* dL_dmean3D,
+                       float* dL_dcov3D,
+                       float* dL_dsh,
+                       float* dL_dscale,
+                       float* dL_drot,
+                       int debug,
+                       void* stream);
+
 /* Scratch sizes, for callers that pre-allocate instead of growing inside the callback
  * (the reference's required<T>(n), cuda_rasterizer/rasterizer_impl.h:68-73). */
 size_t bsr_geometry_bytes(int P);

@@ -611,6 +611,103 @@ void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* 
 	if (aacc) free(aacc);
 }
 
+/* ---------------------------------------------------------------- EXTENSION (not in the reference)
+ * Opt-in gradient of the depth target.  The reference forward normalises
+ * depth = D / acc (acc > 0.5, else 0; CR/forward.cu:459-468) but its backward drops dL_ddepth
+ * entirely (CR/backward.cu:457-463,539-554 are commented out, and written for another depth
+ * definition).  This is the TRUE derivative of the shipped forward, restated in the same walk as
+ * bsro_render_backward; its pin is the float64 autograd of oracle/torch_splat.py, not the reference.
+ *   w_i = alpha_i T_i,  D = sum z_i w_i,  A = 1e-6 + sum w_i,  depth = D / A  (A > 0.5)
+ *   gz = g / A,  g1 = -g depth / A,  d_i = gz z_i + g1          (g = dL/d depth of the pixel)
+ *   dL/dz_i     = gz w_i
+ *   dL/dalpha_i = T_i (d_i - Rd_i),  Rd_{i-1} = alpha_i d_i + (1 - alpha_i) Rd_i   (back to front)
+ * and dL/dalpha_i feeds mean2D / conic / opacity exactly like the colour term (no background term).
+ * The gate is the forward's own decision (out_depth != 0: view z > 0.2 makes D > 0 whenever
+ * A > 0.5) and A is rebuilt as 1e-6 + (1 - T_final).  ADDS to dL_dmean2D [P,3], dL_dconic2D [P,4],
+ * dL_dopacity [P] (binary64 partial sums, rounded once) and writes dL_dz [P]. */
+void bsro_render_backward_depth(int P, int R, const uint32_t* ranges, const uint32_t* point_list, int W, int H,
+                                const float* points_xy_image, const float* conic_opacity, const float* depths,
+                                const float* final_Ts, const uint32_t* n_contrib, const float* out_depth,
+                                const float* dL_depths, float* dL_dmean2D, float* dL_dconic2D, float* dL_dopacity,
+                                float* dL_dz)
+{
+	const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+	double* slab = (double*)calloc((size_t)(R > 0 ? R : 1) * 7, sizeof(double));
+	const float ddelx_dx = 0.5 * W;
+	const float ddely_dy = 0.5 * H;
+#pragma omp parallel for schedule(dynamic, 4)
+	for (int tile = 0; tile < gx * gy; tile++) {
+		const int tx = tile % gx, ty = tile / gx;
+		const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+		for (int ly = 0; ly < BLOCK_Y; ly++)
+			for (int lx = 0; lx < BLOCK_X; lx++) {
+				const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+				if (!(px < W && py < H)) continue;
+				const uint32_t pix_id = (uint32_t)W * py + px;
+				const float depth_px = out_depth[pix_id];
+				if (!(depth_px != 0.0f)) continue; /* acc <= 0.5: the forward wrote a constant 0 */
+				const float pixf[2] = {(float)px, (float)py};
+				const float T_final = final_Ts[pix_id];
+				const float A = 1e-6f + (1.0f - T_final);
+				const float gz = dL_depths[pix_id] / A;
+				const float g1 = -gz * depth_px;
+				float T = T_final;
+				uint32_t contributor = r1 - r0;
+				const int last_contributor = (int)n_contrib[pix_id];
+				float Rd = 0.0f;
+				for (uint32_t k = 0; k < r1 - r0; k++) {
+					const uint32_t slot = r1 - k - 1;
+					contributor--;
+					if (contributor >= (uint32_t)last_contributor) continue;
+					const uint32_t id = point_list[slot];
+					const float dx = points_xy_image[2 * id] - pixf[0];
+					const float dy = points_xy_image[2 * id + 1] - pixf[1];
+					const float* con_o = conic_opacity + 4 * (size_t)id;
+					const float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+					if (power > 0.0f) continue;
+					const float G = bsro_expf(power);
+					const float alpha = fminf(0.99f, con_o[3] * G);
+					if (alpha < 1.0f / 255.0f) continue;
+					T = T / (1.f - alpha);
+					const float d_i = gz * depths[id] + g1;
+					const float e = d_i - Rd;
+					Rd = Rd + alpha * e;
+					const float dL_dalpha = T * e;
+					const float dL_dG = con_o[3] * dL_dalpha;
+					const float gdx = G * dx;
+					const float gdy = G * dy;
+					const float dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
+					const float dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+					double* sl = slab + (size_t)slot * 7;
+					sl[0] += dL_dG * dG_ddelx * ddelx_dx;
+					sl[1] += dL_dG * dG_ddely * ddely_dy;
+					sl[2] += -0.5f * gdx * dx * dL_dG;
+					sl[3] += -0.5f * gdx * dy * dL_dG;
+					sl[4] += -0.5f * gdy * dy * dL_dG;
+					sl[5] += G * dL_dalpha;
+					sl[6] += gz * (alpha * T);
+				}
+			}
+	}
+	double* acc = (double*)calloc((size_t)(P > 0 ? P : 1) * 7, sizeof(double));
+	for (int s = 0; s < R; s++) {
+		const uint32_t id = point_list[s];
+		for (int k = 0; k < 7; k++) acc[(size_t)id * 7 + k] += slab[(size_t)s * 7 + k];
+	}
+	for (int i = 0; i < P; i++) {
+		const double* a = acc + (size_t)i * 7;
+		dL_dmean2D[3 * i + 0] += (float)a[0];
+		dL_dmean2D[3 * i + 1] += (float)a[1];
+		dL_dconic2D[4 * i + 0] += (float)a[2];
+		dL_dconic2D[4 * i + 1] += (float)a[3];
+		dL_dconic2D[4 * i + 3] += (float)a[4];
+		dL_dopacity[i] += (float)a[5];
+		dL_dz[i] = (float)a[6];
+	}
+	free(slab);
+	free(acc);
+}
+
 /* ---------------------------------------------------------------- CR/backward.cu:144-274 */
 void bsro_backward_cov2d(int P, const float* means, const int* radii, const float* cov3Ds, float h_x, float h_y,
                          float tan_fovx, float tan_fovy, const float* view_matrix, const float* dL_dconics,

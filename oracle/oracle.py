@@ -194,10 +194,13 @@ def forward(rs, means3D, opacities, shs=None, colors_precomp=None, scales=None, 
     return st
 
 
-def backward(st, grad_color, grad_depth=None, want_abs_sums=False):
+def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradient=False):
     """Rasterizer::backward (rasterizer_impl.cu:403-504) + RasterizeGaussiansBackwardCUDA
-    (rasterize_points.cu:119-200).  ``grad_depth`` is accepted and ignored, like the reference.
-    Returns the 8 gradients in the order of the reference tuple plus the internal dL_dconic."""
+    (rasterize_points.cu:119-200).  ``grad_depth`` is accepted and ignored, like the reference --
+    unless ``depth_gradient=True``, the opt-in EXTENSION that adds the true
+    derivative of the normalised depth target (bsro_render_backward_depth; pinned by autograd, not
+    by the reference).  Returns the 8 gradients in the order of the reference tuple plus the
+    internal dL_dconic."""
     L = lib()
     rs, inp = st.rs, st.inputs
     P, M, W, H = st.P, st.M, st.W, st.H
@@ -225,7 +228,18 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False):
         _p(st.conic_opacity), _p(st.features), _p(st.final_T), _p(st.n_contrib), _p(grad_color), _p(grad_depth),
         _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors),
         _p(g.abs_sums) if want_abs_sums else None)
-    return backward_chain(st, g)
+    if not depth_gradient:
+        return backward_chain(st, g)
+    g.dL_dz = np.zeros((P,), dtype=np.float32)
+    L.bsro_render_backward_depth(
+        C.c_int(P), C.c_int(R), _p(st.ranges), _p(plist), C.c_int(W), C.c_int(H), _p(st.means2D),
+        _p(st.conic_opacity), _p(st.depths), _p(st.final_T), _p(st.n_contrib), _p(st.depth), _p(grad_depth),
+        _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dz))
+    backward_chain(st, g)
+    # view z = vm[2] x + vm[6] y + vm[10] z + vm[14] (flat, column-vector convention of auxiliary.h:58-66)
+    vm = np.asarray(rs.viewmatrix, dtype=np.float32).reshape(-1)
+    g.dL_dmeans3D += g.dL_dz[:, None] * np.array([vm[2], vm[6], vm[10]], dtype=np.float32)[None, :]
+    return g
 
 
 def backward_chain(st, g):

@@ -51,11 +51,14 @@ def quat_to_rot(q):
 
 
 def render(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, bg, scale_modifier=1.0,
-           sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, means2D=None):
+           sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, means2D=None,
+           depth_gradient=False):
     """Returns (color [3,H,W], radii [P] int, depth [1,H,W]) as float64 torch tensors.
 
     ``means2D`` (optional zeros [P,3] leaf) is added to the NDC position so that its autograd
-    gradient is the reference's dL_dmean2D (gradient w.r.t. NDC, backward.cu:473-474,574-575)."""
+    gradient is the reference's dL_dmean2D (gradient w.r.t. NDC, backward.cu:473-474,574-575).
+    The depth output is detached (the reference drops dL_ddepth) unless ``depth_gradient=True``, which
+    keeps it in the graph: the pin of the opt-in depth-gradient extension."""
     dt = torch.float64
     P = means3D.shape[0]
     V = viewmatrix.to(dt).reshape(4, 4)   # V[j, i] = column-vector matrix element (i, j)
@@ -148,8 +151,8 @@ def render(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
     wgt = a_keep * T_before
     T_final = T_after[:, -1]
     color = (wgt @ rgb[o]).T + T_final[None, :] * bg.to(dt)[:, None]
-    wd = wgt.detach()
+    wd = wgt if depth_gradient else wgt.detach()
     acc = 1e-6 + wd.sum(dim=1)
-    Dsum = wd @ tz.detach()[o]
+    Dsum = wd @ (tz if depth_gradient else tz.detach())[o]
     depth = torch.where(acc > 0.5, Dsum / acc, torch.zeros_like(acc))
     return color.reshape(3, H, W), radii, depth.reshape(1, H, W)

@@ -95,11 +95,11 @@ def oracle_settings(c, prefiltered=False):
                            c.cam.full_proj_transform, c.deg, c.cam.camera_center, prefiltered=prefiltered)
 
 
-def run_oracle(c, backward=True, want_abs_sums=False):
+def run_oracle(c, backward=True, want_abs_sums=False, depth_gradient=False):
     rs = oracle_settings(c)
     st = O.forward(rs, c.means3D, c.opacities, shs=c.shs, colors_precomp=c.colors_precomp, scales=c.scales,
                    rotations=c.rotations, cov3D_precomp=c.cov3D_precomp)
-    g = O.backward(st, c.gC, c.gD, want_abs_sums=want_abs_sums) if backward else None
+    g = O.backward(st, c.gC, c.gD, want_abs_sums=want_abs_sums, depth_gradient=depth_gradient) if backward else None
     return st, g
 
 
@@ -112,7 +112,7 @@ def hip_settings(c, device, debug=False, prefiltered=False):
         prefiltered=prefiltered, debug=debug)
 
 
-def run_hip(c, device="cuda", backward=True, debug=False):
+def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False):
     """The reference call shape (gaussian_renderer/__init__.py:224-262) against the HIP path."""
     from bloomscene_amd import GaussianRasterizer
     dev = torch.device(device)
@@ -124,7 +124,7 @@ def run_hip(c, device="cuda", backward=True, debug=False):
                           cov3D_precomp=leaf(c.cov3D_precomp))
     means2D = torch.zeros_like(inp.means3D, requires_grad=True) + 0
     means2D.retain_grad()
-    rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug))
+    rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug), depth_gradient=depth_gradient)
     color, radii, depth = rast(means3D=inp.means3D, means2D=means2D, opacities=inp.opacities, shs=inp.shs,
                                colors_precomp=inp.colors_precomp, scales=inp.scales, rotations=inp.rotations,
                                cov3D_precomp=inp.cov3D_precomp)

@@ -72,3 +72,43 @@ def test_oracle_matches_autograd(kw):
         # the reference stores off-diagonal gradients "once, doubled" (backward.cu:221-227);
         # autograd w.r.t. the 6 packed entries sees each off-diagonal twice as well
         assert _rel(og.cov3D_precomp, inp["cov3D_precomp"].grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("kw", [
+    dict(P=300, W=48, H=32, deg=2, seed=20, scale_mul=6.0),
+    dict(P=250, W=40, H=40, deg=0, seed=21, scale_mul=8.0, color_mode="precomp", free_camera=True),
+    dict(P=300, W=40, H=24, deg=1, seed=22, scale_mul=8.0, scene="b", view=9),
+])
+def test_depth_gradient_extension_matches_autograd(kw):
+    """EXTENSION: with depth_gradient=True the oracle adds the true derivative of
+    the normalised depth target; its pin is float64 autograd through the same forward semantics
+    (acc > 0.5 gate, D / acc).  The default (reference) behaviour ignores grad_depth: see
+    test_oracle.py::test_depth_gradient_is_ignored."""
+    c = Hh.make_case(**kw)
+    c.opacities.clamp_(max=0.95)
+    st = O.forward(Hh.oracle_settings(c), c.means3D, c.opacities, shs=c.shs, colors_precomp=c.colors_precomp,
+                   scales=c.scales, rotations=c.rotations, cov3D_precomp=c.cov3D_precomp)
+    g = O.backward(st, c.gC, c.gD, depth_gradient=True)
+    dt = torch.float64
+
+    def leaf(t):
+        return None if t is None else t.to(dt).clone().requires_grad_(True)
+    inp = dict(means3D=leaf(c.means3D), opacities=leaf(c.opacities), shs=leaf(c.shs),
+               colors_precomp=leaf(c.colors_precomp), scales=leaf(c.scales), rotations=leaf(c.rotations))
+    means2D = torch.zeros(c.P, 3, dtype=dt, requires_grad=True)
+    color, radii, depth = TS.render(inp["means3D"], inp["opacities"], c.cam.world_view_transform,
+                                    c.cam.full_proj_transform, c.cam.camera_center, c.tanfovx, c.tanfovy, c.W, c.H,
+                                    c.bg, c.scale_modifier, c.deg, shs=inp["shs"], colors_precomp=inp["colors_precomp"],
+                                    scales=inp["scales"], rotations=inp["rotations"], means2D=means2D,
+                                    depth_gradient=True)
+    assert (depth != 0).any() and (depth == 0).any()        # both sides of the acc > 0.5 gate
+    ((color * c.gC.to(dt)).sum() + (depth * c.gD.to(dt)).sum()).backward()
+    og = Hh.oracle_grads(c, g)
+    assert _rel(og.means2D[:, :2], means2D.grad.numpy()[:, :2]) < TOL
+    for k in ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations"):
+        if getattr(og, k) is None:
+            continue
+        assert _rel(getattr(og, k), inp[k].grad.numpy()) < TOL, k
+    # and the extension really changed something: the reference-mode gradient differs
+    g_ref = O.backward(st, c.gC, c.gD)
+    assert _rel(Hh.oracle_grads(c, g_ref).means3D, inp["means3D"].grad.numpy()) > 1e-2

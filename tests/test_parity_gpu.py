@@ -246,6 +246,38 @@ def test_autograd_end_to_end(name):
         assert frac < 5e-3, (k, frac)   # elements losing > 1e-4 to cancellation in the unordered sums
 
 
+@pytest.mark.parametrize("name", ["sh3", "precomp_color", "precomp_cov", "shell_view", "free_camera_sh3",
+                                  "lists_gt_1024", "c2_100k_800x800"])
+def test_depth_gradient_extension(name):
+    """GaussianRasterizer(..., depth_gradient=True) (bsr_backward_depth): forward
+    unchanged and bit-exact, every gradient within 1e-5 of its tensor's scale of the oracle's extension
+    (itself pinned by float64 autograd, tests/test_oracle_crosscheck.py).  The gD term must matter, and
+    the default module must keep ignoring it like the reference."""
+    c = Hh.make_case(**CASES[name])
+    st, g = Hh.run_oracle(c, depth_gradient=True)
+    out = Hh.run_hip(c, depth_gradient=True)
+    np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+    og = Hh.oracle_grads(c, g)
+    for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        ref, got = getattr(og, k), getattr(out.grads, k)
+        if ref is None:
+            assert got is None, k
+            continue
+        assert np.isfinite(got).all(), k
+        assert Hh.max_err_over_scale(got, ref) < 1e-5, (k, Hh.max_err_over_scale(got, ref))
+    _, g_ref = Hh.run_oracle(c)                      # reference behaviour: gD ignored
+    base = Hh.run_hip(c)
+    assert Hh.max_err_over_scale(base.grads.means3D, g_ref.dL_dmeans3D) < 1e-5
+    assert Hh.max_err_over_scale(out.grads.means3D, g_ref.dL_dmeans3D) > 1e-3
+    assert Hh.max_err_over_scale(out.grads.opacities, g_ref.dL_dopacity) > 1e-3
+    # colour gradients do not depend on the depth loss at all
+    if c.shs is not None:
+        np.testing.assert_array_equal(out.grads.shs, base.grads.shs)
+    else:
+        np.testing.assert_array_equal(out.grads.colors_precomp, base.grads.colors_precomp)
+
+
 def test_alpha_target_extension():
     """return_alpha=True appends alpha = 1 - final_T (the reference has no alpha output; north_star
     asks for the extra depth/alpha targets).  Default call shape and results are unchanged."""
