@@ -8,7 +8,8 @@ talk on the data path.  Views are dealt round-robin so yaw-dependent load balanc
 
 ``render_view`` / ``prefilter`` reproduce the call shapes of ``gaussian_renderer.render`` and
 ``prefilter_voxel`` (reference ``gaussian_renderer/__init__.py:211-291,294-349``) for already
-decoded Gaussians; the anchor/MLP decode that precedes them in BloomScene is out of scope.
+decoded Gaussians; ``render_neural`` starts one step earlier, at the outputs of the anchor MLP heads
+(the MLPs, the context model and the entropy coder themselves are out of scope).
 """
 from __future__ import annotations
 
@@ -134,6 +135,33 @@ def render_view(cam: MiniCam, gaussians: dict, bg_color, sh_degree=0, scaling_mo
         cov3D_precomp=gaussians.get("cov3D_precomp"))
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth}
+
+
+def render_neural(cam: MiniCam, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, bg_color,
+                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False):
+    """gaussian_renderer.render for BloomScene's anchor representation (GR:211-291) from the point
+    where the MLP heads have produced their outputs: fused anchor expansion (GR:165-203,
+    ``neural_gaussians.expand_anchors``) -> rasterizer with ``colors_precomp`` and ``sh_degree=1``
+    (GR:235-262).  Returns the training-mode result dict of GR:266-279 minus the entropy-coder rates
+    (``bit_per_*`` come from the out-of-scope context model): render, viewspace_points,
+    visibility_filter, radii, depth, selection_mask, neural_opacity, scaling."""
+    from .neural_gaussians import expand_anchors
+    from .rasterizer import GaussianRasterizer
+    xyz, rgb, opacity, scaling, rot, mask = expand_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color,
+                                                           scale_rot)
+    screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device) + 0
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    rasterizer = GaussianRasterizer(raster_settings=make_settings(cam, bg_color, 1, scaling_modifier, debug),
+                                    depth_gradient=depth_gradient)
+    rendered_image, radii, depth = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=rgb,
+                                              opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "selection_mask": mask, "neural_opacity": neural_opacity,
+            "scaling": scaling}
 
 
 def prefilter(cam: MiniCam, means3D, scales, rotations, bg_color, scaling_modifier=1.0, debug=False):

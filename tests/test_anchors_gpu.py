@@ -168,3 +168,30 @@ def test_backward_is_bit_reproducible_and_feeds_the_rasterizer():
     for name, a, b in zip(IN_NAMES, g1, g3):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 1e-4 * scale, (name, float((a - b).abs().max()) / scale)
+
+
+def test_render_neural_result_dict():
+    """views.render_neural: the training-mode result dict of the reference's render() (GR:266-279) for the
+    anchor representation; viewspace_points receives the screen-space gradient after retain_grad()."""
+    import math
+    from bloomscene_amd import cameras, views
+    dev = _dev()
+    W, H = 128, 80
+    cam = cameras.identity_camera(W, H, math.radians(60)).to(dev)
+    inp = list(OA.synthetic_anchor_inputs(2000, 10, seed=21))
+    inp[0] = inp[0] * torch.tensor([0.6, 0.35, 0.0]) + torch.tensor([0.0, 0.0, 6.0])
+    leaves = [t.to(dev).requires_grad_(True) for t in inp]
+    res = views.render_neural(cam, *leaves, torch.zeros(3, device=dev), retain_grad=True)
+    assert set(res) == {"render", "viewspace_points", "visibility_filter", "radii", "depth", "selection_mask",
+                        "neural_opacity", "scaling"}
+    S = int((inp[3] > 0).sum())
+    assert res["render"].shape == (3, H, W) and res["depth"].shape == (1, H, W)
+    assert res["radii"].shape == (S,) and res["visibility_filter"].dtype == torch.bool
+    assert res["selection_mask"].shape == (20000,) and int(res["selection_mask"].sum()) == S
+    assert res["scaling"].shape == (S, 3) and res["neural_opacity"] is leaves[3]
+    (res["render"].sum() + res["scaling"].prod(dim=1).mean()).backward()      # image loss + scaling regulariser
+    vp = res["viewspace_points"].grad
+    assert vp is not None and vp.shape == (S, 3) and bool(vp[res["visibility_filter"]].abs().sum() > 0)
+    assert not vp[:, 2].any()
+    for leaf in leaves:
+        assert leaf.grad is not None and torch.isfinite(leaf.grad).all()
