@@ -146,6 +146,11 @@ __device__ __forceinline__ float bsr_expf_nonpos(float x)
 	return (x < -104.0f) ? 0.0f : v;
 }
 
+// Wave-wide vote on a predicate, straight from the compare's lane mask.  (HIP's __ballot(int)
+// materialises the predicate as 0/1 in a VGPR and compares it again: two VALU ops per vote, which
+// matters inside the tile walks.)
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // Dense index of rect tile k (row-major) among the Gaussian's kept tiles.
 __device__ __forceinline__ uint32_t kept_rank(uint32_t area, uint64_t mask, uint32_t k)
 {

@@ -251,14 +251,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float dy = q0.y - pixfy;
 			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
 			const bool cand = (contributor < last_contributor) && !(power > 0.0f) && !(power < q1.y);
-			if (__ballot(cand) == 0ull) continue;   // wave-uniform
+			if (wave_ballot(cand) == 0ull) continue;   // wave-uniform
 
 			// slow path: fully predicated
 			const float4 q2 = sh.st.q2[j];
 			const float Graw = bsr_expf_nonpos(power);      // same pinned exp as the forward: identical decisions
 			const float alpha_raw = fminf(0.99f, q1.z * Graw);
 			const bool active = cand && !(alpha_raw < 1.0f / 255.0f);
-			if (__ballot(active) == 0ull) continue;
+			if (wave_ballot(active) == 0ull) continue;
 			// Inactive lanes take alpha = 0, G = 0: every recurrence below then leaves their state
 			// unchanged (T*1 = T, acc + 0*(c-acc) = acc) and all nine contributions are exactly 0.
 			const float alpha = active ? alpha_raw : 0.f;

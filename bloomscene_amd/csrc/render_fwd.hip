@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 
 	for (int base = 0; base < n; base += BSR_BLOCK) {
 		// whole tile finished?  (the barrier is also the WAR fence for the staging buffers)
-		const bool wave_done = (__ballot(!done) == 0ull);
+		const bool wave_done = (wave_ballot(!done) == 0ull);
 		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
 		__syncthreads();
 		if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !done && !(power > 0.0f) && !(power < ct.y);
-				if (__ballot(cand) == 0ull) continue;
+				if (wave_ballot(cand) == 0ull) continue;
 				const float2 od = *(reinterpret_cast<const float2*>(&st.q1[j]) + 1);      // opacity, depth
 				const float4 q2 = st.q2[j];
 				const float alpha = fminf(0.99f, od.x * bsr_expf_nonpos(power));
@@ -92,21 +92,19 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float test_T = T * (1 - alpha);
 				const bool stop = c2 && (test_T < 0.0001f);
 				const bool blend = c2 && !stop;
-				const float n0 = C0 + q2.x * alpha * T;
-				const float n1 = C1 + q2.y * alpha * T;
-				const float n2 = C2 + q2.z * alpha * T;
-				const float nd = D + od.y * alpha * T;
-				const float na = acc + alpha * T;
-				C0 = blend ? n0 : C0;
-				C1 = blend ? n1 : C1;
-				C2 = blend ? n2 : C2;
-				D = blend ? nd : D;
-				acc = blend ? na : acc;
+				// Lanes that do not blend this entry take alpha = 0: x + (c * 0) * T == x exactly for every
+				// finite c, so the five accumulators need no per-lane select (reference :439-446 order kept).
+				const float a = blend ? alpha : 0.0f;
+				C0 = C0 + q2.x * a * T;
+				C1 = C1 + q2.y * a * T;
+				C2 = C2 + q2.z * a * T;
+				D = D + od.y * a * T;
+				acc = acc + a * T;
 				T = blend ? test_T : T;
 				last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
 				done = done || stop;
-				if (__ballot(stop) != 0ull) {
-					if (__ballot(!done) == 0ull) break;
+				if (wave_ballot(stop) != 0ull) {
+					if (wave_ballot(!done) == 0ull) break;
 				}
 			}
 		}

@@ -76,7 +76,7 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 	}
 	unsigned long long m[4];
 #pragma unroll
-	for (int q = 0; q < 4; q++) m[q] = __ballot(h[q]);
+	for (int q = 0; q < 4; q++) m[q] = wave_ballot(h[q]);
 	if (lane == 0) {
 #pragma unroll
 		for (int q = 0; q < 4; q++) st.cnt[wave][q] = (unsigned int)__popcll(m[q]);
