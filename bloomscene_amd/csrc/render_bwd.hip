@@ -121,6 +121,107 @@ __device__ __forceinline__ float wave_sums10_butterfly(float x0, float x1, float
 	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
 }
 
+// ---- halving reduction v2: lane-masked DPP writes instead of selects ------------------------
+// Measured on MI355X (tools/microbench/valu_rates.hip, 8 waves/SIMD): v_fma/v_mul issue every ~2.6
+// cycles per SIMD, but v_cndmask (SGPR mask), v_cmp -> SGPR and every DPP add every ~4.3.  The
+// butterfly above spends 2 selects + 1 DPP add per pair; here the halving steps run over the lane
+// bits whose DPP writes the hardware can mask -- bit 2 and 3 through bank_mask (banks of 4 lanes),
+// bit 4 and 5 through v_permlane16/32_swap of a PAIR (swap, then one add) -- so a pair-step costs 2
+// instructions and no select; the plain steps over bits 0 and 1 come last, on the single survivor.
+// 24 instructions for 9 values (25 for 10) instead of 33 (35), in place in the input registers.
+// Which lane ends with which component is not assumed: calibrate_components() runs the reduction once
+// on constants and reads the mapping off the result.
+// Hazards: inline asm gets no automatic wait states; a DPP/permlane read needs 2 after a VALU write
+// of the same VGPR -- the order below keeps >= 2 instructions between, s_nop where it cannot.
+template <bool TEN>
+__device__ __forceinline__ float wave_sums_masked(float x0, float x1, float x2, float x3, float x4, float x5, float x6,
+                                                  float x7, float x8, float x9)
+{
+	float t;
+	if (TEN) {
+		asm volatile(
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %0, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %1, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %2, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %4, %10, %10 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+		    "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+		    "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+		    "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+		    "v_mov_b32 %5, %4\n"
+		    "v_permlane16_swap_b32 %0, %1\n"
+		    "v_add_f32 %0, %0, %1\n"
+		    "v_permlane16_swap_b32 %4, %5\n"
+		    "v_add_f32 %4, %4, %5\n"
+		    "s_nop 1\n"
+		    "v_permlane32_swap_b32 %0, %4\n"
+		    "v_add_f32 %0, %0, %4\n"
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t)
+		    : "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x9));
+	} else {
+		asm volatile(
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %0, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %1, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %2, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %3, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+		    "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+		    "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+		    "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+		    "v_mov_b32 %5, %4\n"
+		    "v_permlane16_swap_b32 %0, %1\n"
+		    "v_add_f32 %0, %0, %1\n"
+		    "v_permlane16_swap_b32 %4, %5\n"
+		    "v_add_f32 %4, %4, %5\n"
+		    "s_nop 1\n"
+		    "v_permlane32_swap_b32 %0, %4\n"
+		    "v_add_f32 %0, %0, %4\n"
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t)
+		    : "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+	}
+	(void)t;
+	return x0;
+}
+
+// Component (0..NV-1) whose wave total this lane holds after wave_sums_masked, and whether this lane is
+// the one that stores it (the lowest lane holding that component).  Sums of small integers are exact.
+template <bool TEN>
+__device__ __forceinline__ int calibrate_components(int lane, bool& stores)
+{
+	const float r = wave_sums_masked<TEN>(0.f, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f, 9.f);
+	const int comp = (int)(r * (1.0f / 64.0f));
+	stores = false;
+#pragma unroll
+	for (int c = 0; c < (TEN ? 10 : 9); c++) {
+		const uint64_t m = wave_ballot(comp == c);
+		if (comp == c) stores = (m != 0ull) && (lane == (int)__builtin_ctzll(m));
+	}
+	return comp;
+}
+
 // Index of this tile's instance of a Gaussian in the Gaussian-major order of KEPT instances (its
 // block starts at inst_offset and enumerates the kept tiles of its rect row-major), from q3 / q2.w of
 // the splat record.
@@ -201,9 +302,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			g1 = -gz * depth_px;
 		}
 	}
-	// component whose wave total lands in this lane after the butterfly (lanes 0..NV-1 store)
-	const int comp_of_lane = (lane & 8) ? (DEPTH ? 8 + (lane & 1) : 8) : (((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1));
-	float* const part_mine = &sh.part[wave][comp_of_lane][0];
+	// component whose wave total lands in this lane after the reduction; one lane per component stores
+	bool stores;
+	const int comp_of_lane = calibrate_components<DEPTH>(lane, stores);
+	float* const part_mine = &sh.part[wave][stores ? comp_of_lane : 0][0];
 	const float ddelx_dx = (float)(0.5 * W);
 	const float ddely_dy = (float)(0.5 * H);
 
@@ -255,14 +357,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 
 			// slow path: fully predicated
 			const float4 q2 = sh.st.q2[j];
-			const float Graw = bsr_expf_nonpos(power);      // same pinned exp as the forward: identical decisions
-			const float alpha_raw = fminf(0.99f, q1.z * Graw);
-			const bool active = cand && !(alpha_raw < 1.0f / 255.0f);
+			const float G = bsr_expf_walk(power);           // same pinned exp as the forward: identical decisions
+			// Lanes that are not candidates take alpha = 0 before the 1/255 test (so one compare decides
+			// `active`), and inactive lanes keep alpha = 0: every recurrence below then leaves their state
+			// unchanged (T*1 = T, acc + 0*(c-acc) = acc); their dL_dalpha is zeroed below, which makes all
+			// nine contributions exactly 0 (G itself may be anything finite there).
+			const float alpha_c = cand ? fminf(0.99f, q1.z * G) : 0.f;
+			const bool active = !(alpha_c < 1.0f / 255.0f);
 			if (wave_ballot(active) == 0ull) continue;
-			// Inactive lanes take alpha = 0, G = 0: every recurrence below then leaves their state
-			// unchanged (T*1 = T, acc + 0*(c-acc) = acc) and all nine contributions are exactly 0.
-			const float alpha = active ? alpha_raw : 0.f;
-			const float G = active ? Graw : 0.f;
+			const float alpha = active ? alpha_c : 0.f;
 			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
 			{
 				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
@@ -307,9 +410,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				v8 = aT * dpx2;
 				if (DEPTH) v9 = aT * gz;
 			}
-			const float tot = DEPTH ? wave_sums10_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, lane)
-			                        : wave_sums9_butterfly(v0, v1, v2, v3, v4, v5, v6, v7, v8, lane);
-			if (lane < NV) part_mine[j] = tot;   // lane l holds component comp(l): one NV-lane store
+			const float tot = wave_sums_masked<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+			if (stores) part_mine[j] = tot;   // one NV-lane store
 		}
 		__syncthreads();
 		if (valid) {

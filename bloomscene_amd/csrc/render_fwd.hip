@@ -38,7 +38,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
 	const bool inside = px < W && py < H;
-	const float pixfx = (float)px, pixfy = (float)py;
+	// A finished lane (outside the image, or stopped at T < 1e-4) gets its pixel centre moved ~1e15 px
+	// away: `power` then falls far below any cut, so the per-entry candidate vote needs no `!done` term.
+	// (Only an optimisation of the vote: the blend predicate below still carries `!done`.)
+	float pixfx = inside ? (float)px : 1.0e15f;
+	const float pixfy = (float)py;
 	const float tile_x0 = (float)(tx * BSR_TILE), tile_y0 = (float)(ty * BSR_TILE);
 
 	const uint32_t start = tile_start[tile];
@@ -83,27 +87,33 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float dy = q0.y - pixfy;
 				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
-				const bool cand = !done && !(power > 0.0f) && !(power < ct.y);
+				const bool cand = !(power > 0.0f) && !(power < ct.y);
 				if (wave_ballot(cand) == 0ull) continue;
 				const float2 od = *(reinterpret_cast<const float2*>(&st.q1[j]) + 1);      // opacity, depth
 				const float4 q2 = st.q2[j];
-				const float alpha = fminf(0.99f, od.x * bsr_expf_nonpos(power));
-				const bool c2 = cand && !(alpha < 1.0f / 255.0f);
-				const float test_T = T * (1 - alpha);
-				const bool stop = c2 && (test_T < 0.0001f);
-				const bool blend = c2 && !stop;
-				// Lanes that do not blend this entry take alpha = 0: x + (c * 0) * T == x exactly for every
-				// finite c, so the five accumulators need no per-lane select (reference :439-446 order kept).
-				const float a = blend ? alpha : 0.0f;
+				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
+				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
+				//   not a candidate           -> alpha_c = 0
+				//   alpha < 1/255, or done    -> a_eff   = 0   (reference: continue)
+				//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
+				// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
+				const float alpha_c = cand ? fminf(0.99f, od.x * bsr_expf_walk(power)) : 0.0f;
+				const bool c2 = !(alpha_c < 1.0f / 255.0f) && !done;
+				const float a_eff = c2 ? alpha_c : 0.0f;
+				const float test_T = T * (1 - a_eff);
+				const bool stop = test_T < 0.0001f;
+				const float a = stop ? 0.0f : a_eff;
+				// x + (c * 0) * T == x exactly for every finite c (reference :439-446 order kept)
 				C0 = C0 + q2.x * a * T;
 				C1 = C1 + q2.y * a * T;
 				C2 = C2 + q2.z * a * T;
 				D = D + od.y * a * T;
 				acc = acc + a * T;
-				T = blend ? test_T : T;
-				last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
-				done = done || stop;
-				if (wave_ballot(stop) != 0ull) {
+				T = stop ? T : test_T;
+				last_contributor = (c2 && !stop) ? (uint32_t)(base + j + 1) : last_contributor;
+				if (wave_ballot(stop) != 0ull) {   // rare
+					pixfx = stop ? 1.0e15f : pixfx;
+					done = done || stop;
 					if (wave_ballot(!done) == 0ull) break;
 				}
 			}
