@@ -344,19 +344,22 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
+		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
+		const int joff_min = (top - (int)last_contributor) * 16;
 		for (int i = 0; i < n_u; i++) {
-			const int j = __builtin_amdgcn_readfirstlane((int)sh.st.list[wave][i]);
-			const uint32_t contributor = (uint32_t)(top - j);
-			const float4 q0 = sh.st.q0[j];
-			const float4 q1 = sh.st.q1[j];   // conic c, power cut, opacity, depth
+			const unsigned int joff = sh.st.list[wave][i];
+			const char* rec = stage_rec(sh.st, joff);
+			const float4 q0 = rec_q0<BSR_BWD_BATCH>(rec);
+			const float4 q1 = rec_q1<BSR_BWD_BATCH>(rec);   // conic c, power cut, opacity, depth
 			const float dx = q0.x - pixfx;
 			const float dy = q0.y - pixfy;
 			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-			const bool cand = (contributor < last_contributor) && !(power > 0.0f) && !(power < q1.y);
+			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
 			if (wave_ballot(cand) == 0ull) continue;   // wave-uniform
 
 			// slow path: fully predicated
-			const float4 q2 = sh.st.q2[j];
+			const float4 q2 = rec_q2<BSR_BWD_BATCH>(rec);
 			const float G = bsr_expf_walk(power);           // same pinned exp as the forward: identical decisions
 			// Lanes that are not candidates take alpha = 0 before the 1/255 test (so one compare decides
 			// `active`), and inactive lanes keep alpha = 0: every recurrence below then leaves their state
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				if (DEPTH) v9 = aT * gz;
 			}
 			const float tot = wave_sums_masked<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
-			if (stores) part_mine[j] = tot;   // one NV-lane store
+			if (stores) *reinterpret_cast<float*>(reinterpret_cast<char*>(part_mine) + (joff >> 2)) = tot;   // part_mine[j]
 		}
 		__syncthreads();
 		if (valid) {

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 
 	bool done = !inside;
 	float T = 1.0f;
-	uint32_t last_contributor = 0;
+	uint32_t last16 = 0;   // 16 * last_contributor (list offsets are kept pre-scaled)
 	float C0 = 0.f, C1 = 0.f, C2 = 0.f;
 	float D = 0.f;
 	float acc = 0.000001f;
@@ -79,18 +79,20 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
 			// candidate) is one ballot; the slow path is fully predicated -- no per-lane branches.
 			const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+			const uint32_t base16 = (uint32_t)(base + 1) << 4;
 			for (int i = 0; i < n_u; i++) {
-				const int j = __builtin_amdgcn_readfirstlane((int)st.list[wave][i]);
-				const float4 q0 = st.q0[j];                                            // x, y, conic a, conic b
-				const float2 ct = *reinterpret_cast<const float2*>(&st.q1[j]);          // conic c, power cut
+				const unsigned int joff = st.list[wave][i];
+				const char* rec = stage_rec(st, joff);
+				const float4 q0 = rec_q0<BSR_BLOCK>(rec);      // x, y, conic a, conic b
+				const float2 ct = rec_q1lo<BSR_BLOCK>(rec);    // conic c, power cut
 				const float dx = q0.x - pixfx;
 				const float dy = q0.y - pixfy;
 				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !(power > 0.0f) && !(power < ct.y);
 				if (wave_ballot(cand) == 0ull) continue;
-				const float2 od = *(reinterpret_cast<const float2*>(&st.q1[j]) + 1);      // opacity, depth
-				const float4 q2 = st.q2[j];
+				const float2 od = rec_q1hi<BSR_BLOCK>(rec);    // opacity, depth
+				const float4 q2 = rec_q2<BSR_BLOCK>(rec);
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
 				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
 				//   not a candidate           -> alpha_c = 0
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				D = D + od.y * a * T;
 				acc = acc + a * T;
 				T = stop ? T : test_T;
-				last_contributor = (c2 && !stop) ? (uint32_t)(base + j + 1) : last_contributor;
+				last16 = (c2 && !stop) ? joff + base16 : last16;   // 16 * (list position + 1)
 				if (wave_ballot(stop) != 0ull) {   // rare
 					pixfx = stop ? 1.0e15f : pixfx;
 					done = done || stop;
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		const size_t pix_id = (size_t)W * py + px;
 		const size_t plane = (size_t)H * W;
 		final_T[pix_id] = T;
-		n_contrib[pix_id] = last_contributor;
+		n_contrib[pix_id] = last16 >> 4;
 		out_color[pix_id] = C0 + T * bg_color[0];
 		out_color[plane + pix_id] = C1 + T * bg_color[1];
 		out_color[2 * plane + pix_id] = C2 + T * bg_color[2];

@@ -47,13 +47,14 @@ struct TileStageT {
 	float4 q0[BATCH];                // x, y, conic a, conic b
 	float4 q1[BATCH];                // conic c, power cut, opacity, depth
 	float4 q2[BATCH];                // r, g, b, -
-	unsigned short list[4][BATCH];
+	unsigned short list[4][BATCH];   // per quadrant: BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
 	unsigned int cnt[4][4];          // [staging wave][quadrant]
 };
 using TileStage = TileStageT<BSR_BLOCK>;
 
 // Thread `tid` holds the record of batch entry `tid` (valid iff tid < cnt).  Writes the record
-// to LDS and appends tid to the list of every quadrant it may touch, preserving list order
+// to LDS and appends tid << 4 (its byte offset in the three record arrays, so the walks use the list
+// value as the LDS address directly) to the list of every quadrant it may touch, preserving list order
 // (64-bit ballots + prefix popcounts inside a wave, a 4x4 count table across waves).
 // On return (after the trailing barrier) st.list[q][0 .. total[q]) is ready; returns total[wave].
 template <int BATCH>
@@ -88,12 +89,26 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 		if (h[q]) {
 			const unsigned int off = (wave > 0 ? st.cnt[0][q] : 0u) + (wave > 1 ? st.cnt[1][q] : 0u) +
 			                         (wave > 2 ? st.cnt[2][q] : 0u);
-			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned short)tid;
+			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned short)(tid << 4);
 		}
 	}
 	const int total = (int)(st.cnt[0][wave] + st.cnt[1][wave] + st.cnt[2][wave] + st.cnt[3][wave]);
 	__syncthreads();
 	return total;
 }
+
+// Record fields of the list entry at byte offset `joff` (wave-uniform, but deliberately left in a VGPR:
+// a readfirstlane + scalar shift + move back costs four issue slots per visit and buys nothing, the
+// LDS broadcasts a uniform address anyway).
+template <int BATCH>
+__device__ __forceinline__ const char* stage_rec(const TileStageT<BATCH>& st, unsigned int joff)
+{
+	return reinterpret_cast<const char*>(&st.q0[0]) + joff;
+}
+template <int BATCH> __device__ __forceinline__ float4 rec_q0(const char* r) { return *reinterpret_cast<const float4*>(r); }
+template <int BATCH> __device__ __forceinline__ float4 rec_q1(const char* r) { return *reinterpret_cast<const float4*>(r + BATCH * 16); }
+template <int BATCH> __device__ __forceinline__ float2 rec_q1lo(const char* r) { return *reinterpret_cast<const float2*>(r + BATCH * 16); }
+template <int BATCH> __device__ __forceinline__ float2 rec_q1hi(const char* r) { return *reinterpret_cast<const float2*>(r + BATCH * 16 + 8); }
+template <int BATCH> __device__ __forceinline__ float4 rec_q2(const char* r) { return *reinterpret_cast<const float4*>(r + BATCH * 32); }
 
 }  // namespace bsr
