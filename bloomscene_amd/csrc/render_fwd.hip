@@ -95,13 +95,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float4 q2 = rec_q2<BSR_BLOCK>(rec);
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
 				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
-				//   not a candidate           -> alpha_c = 0
-				//   alpha < 1/255, or done    -> a_eff   = 0   (reference: continue)
+				//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
 				//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
 				// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
-				const float alpha_c = cand ? fminf(0.99f, od.x * bsr_expf_walk(power)) : 0.0f;
-				const bool c2 = !(alpha_c < 1.0f / 255.0f) && !done;
-				const float a_eff = c2 ? alpha_c : 0.0f;
+				const float alpha_raw = fminf(0.99f, od.x * bsr_expf_walk(power));   // all lanes: no exec games
+				const bool c2 = cand && !(alpha_raw < 1.0f / 255.0f) && !done;
+				const float a_eff = c2 ? alpha_raw : 0.0f;
 				const float test_T = T * (1 - a_eff);
 				const bool stop = test_T < 0.0001f;
 				const float a = stop ? 0.0f : a_eff;
@@ -116,7 +115,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				if (wave_ballot(stop) != 0ull) {   // rare
 					pixfx = stop ? 1.0e15f : pixfx;
 					done = done || stop;
-					if (wave_ballot(!done) == 0ull) break;
+					if (wave_ballot(!done) == 0ull) i = n_u;   // every pixel of the quadrant is done: leave (single loop exit)
 				}
 			}
 		}
