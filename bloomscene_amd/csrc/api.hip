@@ -79,6 +79,41 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 	return i;
 }
 
+// ---------------------------------------------------------------- host-side cache for the forward's one read-back
+// Pinned landing buffer + event for the asynchronous copy of the counters, and the shape / num_rendered
+// of the previous forward call on this thread (the size guess of the next one).  Nothing here carries
+// results between calls.
+struct SyncCache {
+	int* pinned = nullptr;       // [4] = flags[0..3]
+	hipEvent_t copied = nullptr;
+	int device = -1;
+	int last_P = -1, last_W = -1, last_H = -1;
+	uint32_t last_R = 0;
+};
+static SyncCache* sync_cache()
+{
+	static thread_local SyncCache c;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { fail("hipGetDevice failed"); return nullptr; }
+	if (c.device != dev) {   // first use on this thread, or the thread moved to another GPU
+		if (c.copied) (void)hipEventDestroy(c.copied);
+		c.copied = nullptr;
+		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+			c.pinned = nullptr;
+			fail("hipHostMalloc failed");
+			return nullptr;
+		}
+		if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess) {
+			c.copied = nullptr;
+			fail("hipEventCreate failed");
+			return nullptr;
+		}
+		c.device = dev;
+		c.last_P = -1;
+	}
+	return &c;
+}
+
 // ---------------------------------------------------------------- kernels (other translation units)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
@@ -87,9 +122,9 @@ void launch_visible_filter_views(int P, int V, const float* means3D, const float
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
                                  hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
-void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
-                    int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles, int* flags, uint4** elems_sorted,
-                    uint4** elems_free, hipStream_t s);
+void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, uint4* elems_a,
+                    uint4* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    int* flags, uint4** elems_sorted, uint4** elems_free, hipStream_t s);
 void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
                        const uint4* elems, uint4* elems_free, uint32_t* point_list, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
@@ -433,29 +468,51 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	STAGE_CHECK("scan_wg", debug, s);
 
 	// flags[2] = instances kept after the exact tile cull, flags[3] = the reference's num_rendered
-	// (sum of rect areas, rasterizer_impl.cu:278-282) which sizes the scratch -> host; the one
-	// blocking read of the forward pass.
-	uint32_t h_cnt[2] = {0, 0};
-	int h_flag = 0;
-	HIP_TRY(hipMemcpyAsync(h_cnt, img.flags + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-	if (prefiltered) HIP_TRY(hipMemcpyAsync(&h_flag, img.flags, sizeof(int), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipStreamSynchronize(s));
-	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-	if (h_cnt[1] > 0x7fffffffu) return fail("too many tile instances (%u)", h_cnt[1]);
-	const int R = (int)h_cnt[1];
-	const int n_kept = (int)h_cnt[0];
-	if (num_rendered) *num_rendered = R;
-
-	char* bin_p = binningBuffer(binning_user, BinState::bytes((size_t)R));
-	if (!bin_p) return fail("scratch allocation callback returned null");
-	BinState bin = BinState::carve(bin_p, (size_t)R);
-
-	uint4* elems_sorted = bin.elems_a;
-	uint4* elems_free = bin.elems_b;
-	{
+	// (sum of rect areas, rasterizer_impl.cu:278-282), which sizes the binning scratch -> host: the one
+	// blocking read of the forward pass (the reference has the same one, rasterizer_impl.cu:282).
+	//
+	// The read is overlapped with the binning kernels: they take the instance count from device memory,
+	// so when the previous call on this thread had the same (P, width, height) the scratch is sized
+	// from its num_rendered (+12.5 %) BEFORE the read, the binning stage is enqueued behind the copy,
+	// and the host only waits for the copy's event.  If the guess was too small the stage's kernels
+	// returned without touching anything and it is simply run again with the exact size.
+	SyncCache* sc = sync_cache();
+	if (!sc) return 1;
+	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_R > 0;
+	size_t cap = 0;
+	BinState bin;
+	uint4* elems_sorted = nullptr;
+	uint4* elems_free = nullptr;
+	auto run_binning = [&](size_t capacity) -> int {
+		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
+		if (!bin_p) return fail("scratch allocation callback returned null");
+		bin = BinState::carve(bin_p, capacity);
+		cap = capacity;
 		StageTimer t("binning", s);
-		launch_binning(P, T, gx, n_kept, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX, img.tile_start,
-		               img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+		launch_binning(P, T, gx, img.flags + 2, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist,
+		               BSR_HIST_BLOCKS_MAX, img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+		return 0;
+	};
+	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipEventRecord(sc->copied, s));
+	if (guess) {
+		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 8 + 4096;
+		if (c > 0x7fffffffu) c = 0x7fffffffu;
+		if (run_binning(c)) return 1;
+	}
+	HIP_TRY(hipEventSynchronize(sc->copied));
+	const int h_flag = prefiltered ? sc->pinned[0] : 0;
+	const uint32_t h_kept = (uint32_t)sc->pinned[2], h_R = (uint32_t)sc->pinned[3];
+	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
+	const int R = (int)h_R;
+	const int n_kept = (int)h_kept;
+	if (num_rendered) *num_rendered = R;
+	sc->last_P = P; sc->last_W = width; sc->last_H = height; sc->last_R = h_R;
+	if (!guess || (size_t)R > cap) {
+		// first call of this shape, or more instances than guessed
+		if (guess) HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));   // big-tile count of the discarded pass
+		if (run_binning((size_t)R)) return 1;
 	}
 	STAGE_CHECK("binning", debug, s);
 	if (n_kept > 0) {

@@ -83,13 +83,36 @@ __global__ void __launch_bounds__(1024) k_scan_wg(int n_wg, uint32_t* __restrict
 	}
 }
 
+// The binning kernels take the number of kept instances from DEVICE memory (flags[2], written by
+// k_scan_wg) and derive their work partition from it themselves, so the host can enqueue the whole
+// binning stage before it has read that number back (bsr_forward overlaps its one blocking read with
+// these kernels).  `capacity` is the number of instances the scratch buffers were sized for; if more
+// were kept, every kernel returns at once and the host re-runs the stage with the right size.
+struct RadixPartition { int n, chunk, n_blocks; };
+__device__ __forceinline__ RadixPartition radix_partition(const int* __restrict__ n_ptr, int capacity,
+                                                          int hist_blocks_max)
+{
+	RadixPartition p;
+	p.n = *n_ptr;
+	if (p.n > capacity || p.n < 0) p.n = -1;   // overflow: do nothing
+	// chunk: multiple of 256, at least 1024 elements, at most hist_blocks_max workgroups
+	int chunk = ((max(p.n, 0) + hist_blocks_max - 1) / hist_blocks_max + 255) / 256 * 256;
+	p.chunk = chunk < 1024 ? 1024 : chunk;
+	p.n_blocks = (max(p.n, 0) + p.chunk - 1) / p.chunk;
+	return p;
+}
+
 // One workgroup per digit d: exclusive scan of row d of the digit-major histogram (in place) and the
 // row total.  256 short, independent scans instead of one long latency-bound one.
-__global__ void __launch_bounds__(256) k_radix_rowscan(int n_blocks, uint32_t* __restrict__ hist,
+__global__ void __launch_bounds__(256) k_radix_rowscan(const int* __restrict__ n_ptr, int capacity, int hist_blocks_max,
+                                                       uint32_t* __restrict__ hist,
                                                        uint32_t* __restrict__ digit_total)
 {
 	__shared__ uint32_t s_wave[4];
 	__shared__ uint32_t s_carry;
+	const RadixPartition part = radix_partition(n_ptr, capacity, hist_blocks_max);
+	if (part.n <= 0) return;
+	const int n_blocks = part.n_blocks;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	uint32_t* row = hist + (size_t)blockIdx.x * n_blocks;
 	if (tid == 0) s_carry = 0;
@@ -116,7 +139,8 @@ __global__ void __launch_bounds__(256) k_radix_rowscan(int n_blocks, uint32_t* _
 }
 
 // ---- every kept instance at its Gaussian-major position ----
-__global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __restrict__ rect,
+__global__ void __launch_bounds__(256) k_emit(int P, int gx, const int* __restrict__ n_ptr, int capacity,
+                                              const ushort4* __restrict__ rect,
                                               const uint64_t* __restrict__ kept_mask,
                                               const uint32_t* __restrict__ inst_offset,
                                               const uint32_t* __restrict__ wg_base, const float4* __restrict__ rec,
@@ -124,6 +148,10 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __re
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
+	{
+		const int n = *n_ptr;
+		if (n <= 0 || n > capacity) return;
+	}
 	const ushort4 r = rect[idx];
 	if (r.z <= r.x || r.w <= r.y) return;
 	const uint32_t area = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
@@ -142,10 +170,14 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const ushort4* __re
 
 // ---- stable LSD radix pass on bits [shift, shift+8) of the tile id ----
 // Workgroup b owns elements [b*chunk, (b+1)*chunk).  hist is digit-major: hist[d * n_blocks + b].
-__global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift, const uint4* __restrict__ elems,
-                                                    uint32_t* __restrict__ hist, int n_blocks)
+__global__ void __launch_bounds__(256) k_radix_hist(const int* __restrict__ n_ptr, int capacity, int hist_blocks_max,
+                                                    int shift, const uint4* __restrict__ elems,
+                                                    uint32_t* __restrict__ hist)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
+	const RadixPartition part = radix_partition(n_ptr, capacity, hist_blocks_max);
+	if ((int)blockIdx.x >= part.n_blocks) return;   // also the overflow / empty case (n_blocks = 0)
+	const int n = part.n, chunk = part.chunk, n_blocks = part.n_blocks;
 	const int tid = threadIdx.x;
 	s_hist[tid] = 0;
 	__syncthreads();
@@ -155,15 +187,19 @@ __global__ void __launch_bounds__(256) k_radix_hist(int n, int chunk, int shift,
 	hist[(size_t)tid * n_blocks + blockIdx.x] = s_hist[tid];
 }
 
-__global__ void __launch_bounds__(256) k_radix_scatter(int n, int chunk, int shift,
+__global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n_ptr, int capacity,
+                                                       int hist_blocks_max, int shift,
                                                        const uint4* __restrict__ elems_in,
                                                        uint4* __restrict__ elems_out,
                                                        const uint32_t* __restrict__ hist,
-                                                       const uint32_t* __restrict__ digit_total, int n_blocks)
+                                                       const uint32_t* __restrict__ digit_total)
 {
 	__shared__ uint32_t s_off[BSR_RADIX_BINS];        // next output position per digit for this workgroup
 	__shared__ uint32_t s_wcnt[4][BSR_RADIX_BINS];    // (round << 8 | count) per wave and digit, stamped
 	__shared__ uint32_t s_scan[4];
+	const RadixPartition part = radix_partition(n_ptr, capacity, hist_blocks_max);
+	if ((int)blockIdx.x >= part.n_blocks) return;
+	const int n = part.n, chunk = part.chunk, n_blocks = part.n_blocks;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this block's row prefix
 		const uint32_t v = digit_total[tid];
@@ -231,10 +267,14 @@ __device__ __forceinline__ int first_not_below(const uint4* __restrict__ elems_s
 	return lo;
 }
 
-__global__ void __launch_bounds__(256) k_tile_ranges(int T, int n, const uint4* __restrict__ elems_sorted,
+__global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restrict__ n_ptr, int capacity,
+                                                     const uint4* __restrict__ elems_sorted,
                                                      uint32_t* __restrict__ tile_start,
                                                      uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
 {
+	int n = *n_ptr;
+	if (n > capacity) return;   // overflow: the stage is re-run
+	if (n < 0) n = 0;
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	bool big = false;
 	if (t <= T) {
@@ -408,37 +448,33 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 	hipLaunchKernelGGL(k_scan_wg, dim3(1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags);
 }
 
-// Bins n kept instances: emit -> radix passes on the tile id -> tile ranges.  keys_a/tiles_a and
-// keys_b/tiles_b ping-pong; returns (through *keys_sorted) the buffer holding the final keys.
-void launch_binning(int P, int T, int gx, int n, const GeomState& geom, uint4* elems_a, uint4* elems_b, uint32_t* hist,
-                    int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles, int* flags, uint4** elems_sorted,
-                    uint4** elems_free, hipStream_t s)
+// Bins the kept instances (their number is read from *n_ptr on the device): emit -> radix passes on
+// the tile id -> tile ranges.  elems_a / elems_b ping-pong; *elems_sorted is the buffer holding the
+// final order.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
+void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, uint4* elems_a,
+                    uint4* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    int* flags, uint4** elems_sorted, uint4** elems_free, hipStream_t s)
 {
-	*elems_sorted = elems_a;
-	*elems_free = elems_b;
-	if (n <= 0) {   // nothing survived the culls: every tile range is empty
-		hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, 0, elems_a, tile_start, big_tiles,
-		                   flags);
-		return;
-	}
-	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, geom.rect, geom.kept_mask,
+	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect, geom.kept_mask,
 	                   geom.inst_offset, geom.wg_kept, geom.rec, elems_a);
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
-	// chunk: multiple of 256, at least 1024 elements, at most hist_blocks_max workgroups
-	int chunk = ((n + hist_blocks_max - 1) / hist_blocks_max + 255) / 256 * 256;
-	if (chunk < 1024) chunk = 1024;
-	const int n_blocks = (n + chunk - 1) / chunk;
+	int max_blocks = (capacity + 1023) / 1024;   // chunk >= 1024
+	if (max_blocks > hist_blocks_max) max_blocks = hist_blocks_max;
+	if (max_blocks < 1) max_blocks = 1;
 	uint32_t* digit_total = hist + (size_t)BSR_RADIX_BINS * hist_blocks_max;
 	uint4* ei = elems_a; uint4* eo = elems_b;
 	for (int shift = 0; shift < bits; shift += BSR_RADIX_BITS) {
-		hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ei, hist, n_blocks);
-		hipLaunchKernelGGL(k_radix_rowscan, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_blocks, hist, digit_total);
-		hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(256), 0, s, n, chunk, shift, ei, eo, hist, digit_total,
-		                   n_blocks);
+		hipLaunchKernelGGL(k_radix_hist, dim3(max_blocks), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, shift, ei,
+		                   hist);
+		hipLaunchKernelGGL(k_radix_rowscan, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, hist,
+		                   digit_total);
+		hipLaunchKernelGGL(k_radix_scatter, dim3(max_blocks), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, shift, ei,
+		                   eo, hist, digit_total);
 		uint4* tt = ei; ei = eo; eo = tt;
 	}
-	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n, ei, tile_start, big_tiles, flags);
+	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n_ptr, capacity, ei, tile_start,
+	                   big_tiles, flags);
 	*elems_sorted = ei;
 	*elems_free = eo;
 }

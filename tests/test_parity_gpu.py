@@ -278,6 +278,29 @@ def test_depth_gradient_extension(name):
         np.testing.assert_array_equal(out.grads.colors_precomp, base.grads.colors_precomp)
 
 
+def test_scratch_size_guess_paths():
+    """bsr_forward sizes the binning scratch from the previous call of the same shape and overlaps its one
+    read-back with the binning kernels; a guess that is too small must be detected and the stage re-run.
+    Same (P, W, H) three times: first call (no guess), many more instances (guess too small), far fewer
+    (guess too large) -- every result bit-exact, backward included."""
+    kw = dict(P=3000, W=200, H=120, deg=1, seed=17)
+    variants = [dict(scale_mul=1.0), dict(scale_mul=8.0), dict(scale_mul=1.0, near_fraction=0.7), dict(scale_mul=8.0)]
+    rs = []
+    for v in variants:
+        c = Hh.make_case(**kw, **v)
+        st, g = Hh.run_oracle(c)
+        rs.append(st.num_rendered)
+        out = Hh.run_hip(c)
+        np.testing.assert_array_equal(out.radii, st.radii)
+        np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+        np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+        og = Hh.oracle_grads(c, g)
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            assert Hh.max_err_over_scale(getattr(out.grads, k), getattr(og, k)) < 1e-5, (v, k)
+    # the sequence really exercises both mis-guesses (guess = previous num_rendered + 12.5 % + 4096)
+    assert rs[1] > 1.125 * rs[0] + 4096 and rs[2] < 0.6 * rs[1] and rs[3] > 1.125 * rs[2] + 4096
+
+
 def test_alpha_target_extension():
     """return_alpha=True appends alpha = 1 - final_T (the reference has no alpha output; north_star
     asks for the extra depth/alpha targets).  Default call shape and results are unchanged."""
