@@ -133,7 +133,7 @@ void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       uint32_t* slot_of, float4* slab, hipStream_t s);
+                       float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- errors
@@ -560,15 +560,13 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0));
 
 	// Backward-only scratch (stream-ordered, from the device's default memory pool):
-	//   slot_of[R] u32 | slab[R][12] f32
+	//   slab[R][12] f32: per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows)
 	const size_t Rn = (size_t)(R > 0 ? R : 0);
-	const size_t off_slab = align_up(Rn * 4, 256);
-	const size_t scratch_bytes = off_slab + align_up(Rn * 48, 256) + 256;
+	const size_t scratch_bytes = align_up(Rn * 48, 256) + 256;
 	if (ensure_pool_keeps_memory()) return 1;
 	char* scratch = nullptr;
 	HIP_TRY(hipMallocAsync((void**)&scratch, scratch_bytes, s));
-	uint32_t* slot_of = (uint32_t*)scratch;
-	float4* slab = (float4*)(scratch + off_slab);
+	float4* slab = (float4*)scratch;
 	struct ScratchFree {
 		char* p; hipStream_t s;
 		~ScratchFree() { if (p) (void)hipFreeAsync(p, s); }
@@ -578,7 +576,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		{
 			StageTimer t("render_bwd", s);
 			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
-			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slot_of, slab, s);
+			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slab, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}
@@ -591,7 +589,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	a.focal_y = height / (2.0f * tan_fovy);
 	a.focal_x = width / (2.0f * tan_fovx);
 	a.geom = geom;
-	a.slot_of = slot_of; a.slab = slab; a.depth_grad = out_depth != nullptr;
+	a.slab = slab; a.depth_grad = out_depth != nullptr;
 	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
 	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
 	{

@@ -88,8 +88,8 @@ struct BwdArgs {
 	const float* campos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	GeomState geom;
-	const uint32_t* slot_of;       // [R]  list slot of the k-th tile instance of each Gaussian
-	const float4* slab;            // [R][3] per-instance partial sums written by k_render_bwd
+	const float4* slab;            // [R][3] per-instance partial sums written by k_render_bwd, Gaussian-major:
+	                               //        row wg_base[g/256] + inst_offset[g] + k = k-th kept tile of Gaussian g
 	int depth_grad;                // extension: slab row[2].y carries dL/d(view z), added to dL_dmean3D
 	float* dL_dmean2D;         // [P,3]  (outputs; fully written)
 	float* dL_dconic;          // [P,4]

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	const ushort4 rc = in_range ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
 	const bool visible = in_range && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
 
-	// ---- gather: add the per-instance partial sums of this Gaussian in tile (row-major) order.
+	// ---- add the per-instance partial sums of this Gaussian (adjacent slab rows) in tile (row-major) order.
 	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
 	// the order is fixed, so the per-Gaussian sums do not depend on scheduling.
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
 		const uint32_t off = n_inst ? a.geom.wg_kept[idx >> 8] + a.geom.inst_offset[idx] : 0u;
 		for (uint32_t k = 0; k < n_inst; k++) {
-			const float4* row = a.slab + (size_t)a.slot_of[off + k] * 3;
+			const float4* row = a.slab + (size_t)(off + k) * 3;
 			const float4 s0 = row[0], s1 = row[1], s2 = row[2];
 			g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
 			g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
