@@ -135,6 +135,8 @@ __device__ __forceinline__ float wave_sums10_butterfly(float x0, float x1, float
 // 24 instructions for 9 values (25 for 10) instead of 33 (35), in place in the input registers.
 // Which lane ends with which component is not assumed: calibrate_components() runs the reduction once
 // on constants and reads the mapping off the result.
+// All ten values are declared in/out so that no two of them can be given the same register (two inputs
+// holding the same SSA value otherwise could, and the block overwrites x0..x3, x8 in place).
 // Hazards: inline asm gets no automatic wait states; a DPP/permlane read needs 2 after a VALU write
 // of the same VGPR -- the order below keeps >= 2 instructions between, s_nop where it cannot.
 template <bool TEN>
@@ -172,8 +174,7 @@ __device__ __forceinline__ float wave_sums_masked(float x0, float x1, float x2, 
 		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 		    "s_nop 1\n"
 		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t)
-		    : "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(x9));
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x9));
 	} else {
 		asm volatile(
 		    "s_nop 1\n"
@@ -203,8 +204,7 @@ __device__ __forceinline__ float wave_sums_masked(float x0, float x1, float x2, 
 		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 		    "s_nop 1\n"
 		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t)
-		    : "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x8), "=&v"(t), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
 	}
 	(void)t;
 	return x0;

@@ -7,7 +7,8 @@
  * absent" exactly like the empty CPU tensors -> nullptr convention of the reference
  * (depth_diff_gaussian_rasterization/__init__.py:198-208, rasterize_points.cu:95-113).
  * Every function returns 0 on success, non-zero on failure; bsr_last_error() then describes it.
- * The library keeps no state between calls (apart from the opt-in stage profiler); the three
+ * The library keeps no results between calls (per host thread: a pinned 16-byte landing buffer, an
+ * event and the previous call's shape / num_rendered as a size hint; plus the opt-in stage profiler); the three
  * scratch buffers handed from forward to backward are opaque, as in the reference
  * (__init__.py:97,106).
  *
@@ -53,7 +54,10 @@ int bsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * cov3D_precomp must be non-NULL.  background, viewmatrix, projmatrix, cam_pos are DEVICE
  * float[3]/[16]/[16]/[3].  debug != 0: synchronise and check after every stage.  prefiltered != 0:
  * a culled Gaussian is an error (the reference printf+__trap()s, auxiliary.h:156-160).
- * Performs one blocking 8-byte device->host read (the reference reads 4 bytes, rasterizer_impl.cu:282).
+ * Performs one blocking 16-byte device->host read (the reference reads 4 bytes, rasterizer_impl.cu:282);
+ * it is overlapped with the binning kernels, for which binningBuffer may be called with a size guessed
+ * from the calling thread's previous call of the same (P, width, height) -- and a second time, with
+ * the exact size, when that guess was short.  The last buffer returned is the one handed to backward.
  * *num_rendered is the reference's value (sum over Gaussians of the tiles of their bounding rect,
  * rasterizer_impl.cu:278-282); it sizes the binning scratch.  Instances whose tile the splat provably
  * cannot reach with alpha >= 1/255 are not listed internally (no output depends on them).
