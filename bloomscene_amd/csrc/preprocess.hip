@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	int radius_out = 0;
 	ushort4 rect_out = make_ushort4(0, 0, 0, 0);
 	uint64_t kept_mask = 0;
+	float4 rq0 = make_float4(0.f, 0.f, 0.f, 0.f), rq1 = rq0, rq2 = rq0;   // splat record, stored at the end
 
 	const int ld = in_range ? idx : 0;
 	const float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
@@ -167,9 +168,8 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					// alpha = min(0.99, o*exp(power)) < 1/255  <=>  power < -ln(255*o); keep a margin far
 					// above the rounding of logf/expf so the cut only skips pairs the exact test rejects.
 					const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
-					float4* rec = a.geom.rec + (size_t)idx * BSR_REC;
-					rec[0] = make_float4(pix_x, pix_y, conic_a, conic_b);
-					rec[1] = make_float4(conic_c, power_cut, opacity, pvz);
+					rq0 = make_float4(pix_x, pix_y, conic_a, conic_b);
+					rq1 = make_float4(conic_c, power_cut, opacity, pvz);
 					a.geom.clamped[idx] = clamp_bits;
 					// Keep one instance per tile of the rect the splat can actually reach: the reference
 					// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
 							}
 					}
-					rec[2] = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
+					rq2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
 				}
 			}
 		}
@@ -249,11 +249,19 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			a.geom.rect[idx] = rect_out;
 			a.geom.inst_offset[idx] = off;
 			a.geom.kept_mask[idx] = kept_mask;
-			if (n_inst)
-				a.geom.rec[(size_t)idx * BSR_REC + 3] = make_float4(
+			if (radius_out > 0) {
+				// the whole 64-B splat record in four back-to-back stores: each cache line is written once,
+				// completely (written piecemeal across the kernel, partially filled lines were evicted and
+				// re-written: 181 MB of HBM writes for 113 MB of data at C3)
+				float4* rec = a.geom.rec + (size_t)idx * BSR_REC;
+				rec[0] = rq0;
+				rec[1] = rq1;
+				rec[2] = rq2;
+				rec[3] = make_float4(
 				    __uint_as_float(off), __uint_as_float((uint32_t)rect_out.x | ((uint32_t)rect_out.y << 16)),
 				    __uint_as_float((uint32_t)(rect_out.z - rect_out.x) | ((uint32_t)(rect_out.w - rect_out.y) << 16)),
 				    __uint_as_float((uint32_t)kept_mask));
+			}
 		}
 	}
 }
