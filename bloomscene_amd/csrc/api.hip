@@ -50,7 +50,7 @@ GeomState GeomState::carve(char* p, size_t P)
 }
 size_t BinState::bytes(size_t R)
 {
-	return align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(uint4), 256) +
+	return align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(BinElem), 256) +
 	       align_up((size_t)BSR_RADIX_BINS_ * (BSR_HIST_BLOCKS_MAX + 1) * sizeof(uint32_t), 256) + 256;
 }
 BinState BinState::carve(char* p, size_t R)
@@ -58,8 +58,8 @@ BinState BinState::carve(char* p, size_t R)
 	BinState b;
 	p = (char*)align_up((size_t)p, 256);
 	b.point_list = (uint32_t*)p; p += align_up(R * sizeof(uint32_t), 256);
-	b.elems_a = (uint4*)p;       p += align_up(R * sizeof(uint4), 256);
-	b.elems_b = (uint4*)p;       p += align_up(R * sizeof(uint4), 256);
+	b.elems_a = (BinElem*)p;       p += align_up(R * sizeof(BinElem), 256);
+	b.elems_b = (BinElem*)p;       p += align_up(R * sizeof(BinElem), 256);
 	b.hist = (uint32_t*)p;
 	return b;
 }
@@ -122,11 +122,11 @@ void launch_visible_filter_views(int P, int V, const float* means3D, const float
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
                                  hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
-void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, uint4* elems_a,
-                    uint4* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
-                    int* flags, uint4** elems_sorted, uint4** elems_free, hipStream_t s);
+void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
+                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s);
 void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
-                       const uint4* elems, uint4* elems_free, uint32_t* point_list, hipStream_t s);
+                       const BinElem* elems, BinElem* elems_free, uint32_t* point_list, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
@@ -481,8 +481,8 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_R > 0;
 	size_t cap = 0;
 	BinState bin;
-	uint4* elems_sorted = nullptr;
-	uint4* elems_free = nullptr;
+	BinElem* elems_sorted = nullptr;
+	BinElem* elems_free = nullptr;
 	auto run_binning = [&](size_t capacity) -> int {
 		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
 		if (!bin_p) return fail("scratch allocation callback returned null");

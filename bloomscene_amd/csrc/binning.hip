@@ -9,10 +9,10 @@
 //      (exact conservative ellipse-vs-tile test; ~1/3 of the reference's instances are dropped on the
 //      synthetic scenes, no pixel changes) and numbered the kept instances Gaussian-major inside
 //      its workgroup; k_scan_wg prefix-sums the workgroup totals (one workgroup, <= 20k values),
-//   2. k_emit writes every kept instance as one 16-byte element (tile id, Gaussian id, depth bits)
+//   2. k_emit writes every kept instance as one 12-byte element (tile id, Gaussian id, depth bits)
 //      at its Gaussian-major position (coalesced, one thread per Gaussian),
 //   3. ceil(bits(T)/8) stable LSD radix passes on the TILE ID only (1080p: 2 passes instead of the
-//      reference's 6; elements move as single 16-byte loads/stores): per-workgroup digit histogram
+//      reference's 6; elements move as single 12-byte loads/stores): per-workgroup digit histogram
 //      -> 256 parallel row scans -> stable scatter (wave ballots for the in-round rank, stamped
 //      per-wave counters across the 4 waves),
 //   4. k_tile_ranges finds each tile's segment by binary search in the sorted tile ids,
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const int* __restri
                                               const uint64_t* __restrict__ kept_mask,
                                               const uint32_t* __restrict__ inst_offset,
                                               const uint32_t* __restrict__ wg_base, const float4* __restrict__ rec,
-                                              uint4* __restrict__ elems)
+                                              BinElem* __restrict__ elems)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const int* __restri
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
 			if (!tile_kept(area, mask, k)) continue;
-			elems[pos] = make_uint4((uint32_t)(y * gx + x), (uint32_t)idx, depth_bits, 0u);   // one 16-B store
+			store_elem(elems + pos, BinElem{(uint32_t)(y * gx + x), (uint32_t)idx, depth_bits});   // one 12-B store
 			pos++;
 		}
 }
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_emit(int P, int gx, const int* __restri
 // ---- stable LSD radix pass on bits [shift, shift+8) of the tile id ----
 // Workgroup b owns elements [b*chunk, (b+1)*chunk).  hist is digit-major: hist[d * n_blocks + b].
 __global__ void __launch_bounds__(256) k_radix_hist(const int* __restrict__ n_ptr, int capacity, int hist_blocks_max,
-                                                    int shift, const uint4* __restrict__ elems,
+                                                    int shift, const BinElem* __restrict__ elems,
                                                     uint32_t* __restrict__ hist)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(256) k_radix_hist(const int* __restrict__ n_pt
 
 __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n_ptr, int capacity,
                                                        int hist_blocks_max, int shift,
-                                                       const uint4* __restrict__ elems_in,
-                                                       uint4* __restrict__ elems_out,
+                                                       const BinElem* __restrict__ elems_in,
+                                                       BinElem* __restrict__ elems_out,
                                                        const uint32_t* __restrict__ hist,
                                                        const uint32_t* __restrict__ digit_total)
 {
@@ -223,8 +223,8 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 	for (int base = beg; base < end; base += 256, round++) {
 		const int i = base + tid;
 		const bool valid = i < end;
-		uint4 e = make_uint4(0u, 0u, 0u, 0u);
-		if (valid) e = elems_in[i];
+		BinElem e = BinElem{0u, 0u, 0u};
+		if (valid) e = load_elem(elems_in + i);
 		const uint32_t d = (e.x >> shift) & (BSR_RADIX_BINS - 1);
 		// lanes of this wave with the same digit (invalid lanes match nobody)
 		unsigned long long peers = __ballot(valid);
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 				if (w < wave && (c >> 8) == round) lower += c & 0xffu;
 			}
 			const uint32_t pos = s_off[d] + lower + rank_w;
-			elems_out[pos] = e;
+			store_elem(elems_out + pos, e);
 		}
 		__syncthreads();
 		if (valid && rank_w == 0) atomicAdd(&s_off[d], cnt_w);   // LDS; order irrelevant, positions are taken
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 // Tiles holding more than BSR_SORT_SMALL instances are also appended (one atomic per wave, order
 // irrelevant) to big_tiles, the work list of the wide sort kernels; flags[1] counts them.
 #define BSR_SORT_SMALL 1024
-__device__ __forceinline__ int first_not_below(const uint4* __restrict__ elems_sorted, int n, uint32_t t)
+__device__ __forceinline__ int first_not_below(const BinElem* __restrict__ elems_sorted, int n, uint32_t t)
 {
 	int lo = 0, hi = n;
 	while (lo < hi) {
@@ -268,7 +268,7 @@ __device__ __forceinline__ int first_not_below(const uint4* __restrict__ elems_s
 }
 
 __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restrict__ n_ptr, int capacity,
-                                                     const uint4* __restrict__ elems_sorted,
+                                                     const BinElem* __restrict__ elems_sorted,
                                                      uint32_t* __restrict__ tile_start,
                                                      uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
 {
@@ -344,22 +344,22 @@ __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 	__syncthreads();
 }
 
-__device__ __forceinline__ uint64_t elem_key(const uint4 e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
+__device__ __forceinline__ uint64_t elem_key(const BinElem e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
 
 // LDS sort of one segment (n <= CAP)
 template <int CAP, int NT>
-__device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t start, int n, const uint4* __restrict__ elems,
+__device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t start, int n, const BinElem* __restrict__ elems,
                                                  uint32_t* __restrict__ point_list)
 {
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += NT) s_keys[i] = elem_key(elems[start + i]);
+	for (int i = tid; i < n; i += NT) s_keys[i] = elem_key(load_elem(elems + start + i));
 	bitonic_sort_asc<NT>(s_keys, n, tid);
 	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)s_keys[i];
 }
 
 // Small class: one workgroup per tile, n <= BSR_SORT_SMALL.
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t* __restrict__ tile_start,
-                                                          const uint4* __restrict__ elems,
+                                                          const BinElem* __restrict__ elems,
                                                           uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[BSR_SORT_SMALL];
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t*
 template <int CAP, int NT>
 __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ big_tiles,
-                                                        const int* __restrict__ flags, const uint4* __restrict__ elems,
+                                                        const int* __restrict__ flags, const BinElem* __restrict__ elems,
                                                         uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[CAP];
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, const uint32_t
 __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
-                                                                 const uint4* __restrict__ elems, uint64_t* keys,
+                                                                 const BinElem* __restrict__ elems, uint64_t* keys,
                                                                  uint32_t* __restrict__ point_list)
 {
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t*
 		for (int base = 0; base < n; base += CH) {
 			const int m = min(CH, n - base);
 			__syncthreads();
-			for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(elems[start + base + i]);
+			for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(load_elem(elems + start + base + i));
 			bitonic_sort_asc<NT>(s_keys, m, tid);
 			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
 		}
@@ -451,9 +451,9 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 // Bins the kept instances (their number is read from *n_ptr on the device): emit -> radix passes on
 // the tile id -> tile ranges.  elems_a / elems_b ping-pong; *elems_sorted is the buffer holding the
 // final order.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
-void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, uint4* elems_a,
-                    uint4* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
-                    int* flags, uint4** elems_sorted, uint4** elems_free, hipStream_t s)
+void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
+                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect, geom.kept_mask,
 	                   geom.inst_offset, geom.wg_kept, geom.rec, elems_a);
@@ -463,7 +463,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 	if (max_blocks > hist_blocks_max) max_blocks = hist_blocks_max;
 	if (max_blocks < 1) max_blocks = 1;
 	uint32_t* digit_total = hist + (size_t)BSR_RADIX_BINS * hist_blocks_max;
-	uint4* ei = elems_a; uint4* eo = elems_b;
+	BinElem* ei = elems_a; BinElem* eo = elems_b;
 	for (int shift = 0; shift < bits; shift += BSR_RADIX_BITS) {
 		hipLaunchKernelGGL(k_radix_hist, dim3(max_blocks), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, shift, ei,
 		                   hist);
@@ -471,7 +471,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 		                   digit_total);
 		hipLaunchKernelGGL(k_radix_scatter, dim3(max_blocks), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, shift, ei,
 		                   eo, hist, digit_total);
-		uint4* tt = ei; ei = eo; eo = tt;
+		BinElem* tt = ei; ei = eo; eo = tt;
 	}
 	hipLaunchKernelGGL(k_tile_ranges, dim3((T + 1 + 255) / 256), dim3(256), 0, s, T, n_ptr, capacity, ei, tile_start,
 	                   big_tiles, flags);
@@ -484,7 +484,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 // instances can fill at most n / 1024 such tiles (n / 4096, n / 8192 for the wider classes), which
 // bounds their grids: a frame without long lists pays near-empty launches, not 3 x T idle workgroups.
 void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
-                       const uint4* elems, uint4* elems_free, uint32_t* point_list, hipStream_t s)
+                       const BinElem* elems, BinElem* elems_free, uint32_t* point_list, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, tile_start, elems, point_list);
 	const int g1 = min(T, n / BSR_SORT_SMALL), g4 = min(T, n / 4096), g8 = min(T, n / BSR_SORT_CHUNK);

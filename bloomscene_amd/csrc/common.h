@@ -32,11 +32,29 @@ struct GeomState {
 	static size_t bytes(size_t P);
 	static GeomState carve(char* p, size_t P);
 };
+// One tile instance in the radix passes: 12 bytes, 4-byte aligned, moved as one dwordx3 access
+// (load_elem / store_elem: a plain struct copy is split into dwordx2 + dword).
+struct BinElem {
+	uint32_t x;   // tile id
+	uint32_t y;   // Gaussian id
+	uint32_t z;   // bits of the view-space depth
+};
+typedef uint32_t bsr_u32x3 __attribute__((ext_vector_type(3)));
+typedef bsr_u32x3 bsr_u32x3_a4 __attribute__((aligned(4)));
+__device__ __forceinline__ BinElem load_elem(const BinElem* p)
+{
+	const bsr_u32x3 v = *reinterpret_cast<const bsr_u32x3_a4*>(p);
+	return BinElem{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void store_elem(BinElem* p, const BinElem e)
+{
+	*reinterpret_cast<bsr_u32x3_a4*>(p) = bsr_u32x3{e.x, e.y, e.z};
+}
 #define BSR_HIST_BLOCKS_MAX 2048
 struct BinState {
 	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
-	uint4* elems_a;       // [R] (tile id, gaussian id, depth bits, -): ping-pong buffers of the radix passes
-	uint4* elems_b;       // [R]
+	BinElem* elems_a;     // [R] (tile id, gaussian id, depth bits): ping-pong buffers of the radix passes
+	BinElem* elems_b;       // [R]
 	uint32_t* hist;       // [256 * BSR_HIST_BLOCKS_MAX] digit-major workgroup histograms, then [256] digit totals
 	static size_t bytes(size_t R);
 	static BinState carve(char* p, size_t R);
