@@ -473,7 +473,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	//
 	// The read is overlapped with the binning kernels: they take the instance count from device memory,
 	// so when the previous call on this thread had the same (P, width, height) the scratch is sized
-	// from its num_rendered (+12.5 %) BEFORE the read, the binning stage is enqueued behind the copy,
+	// from its num_rendered (+25 %, decaying slowly after a large view) BEFORE the read, the binning stage is enqueued behind the copy,
 	// and the host only waits for the copy's event.  If the guess was too small the stage's kernels
 	// returned without touching anything and it is simply run again with the exact size.
 	SyncCache* sc = sync_cache();
@@ -496,7 +496,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipEventRecord(sc->copied, s));
 	if (guess) {
-		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 8 + 4096;
+		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
 		if (c > 0x7fffffffu) c = 0x7fffffffu;
 		if (run_binning(c)) return 1;
 	}
@@ -508,7 +508,14 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	const int R = (int)h_R;
 	const int n_kept = (int)h_kept;
 	if (num_rendered) *num_rendered = R;
-	sc->last_P = P; sc->last_W = width; sc->last_H = height; sc->last_R = h_R;
+	// size hint for the next call: this call's count, but decaying only by 1/8 per call after a large view
+	// (training visits views in random order; a short guess costs a second binning pass)
+	{
+		const bool same = sc->last_P == P && sc->last_W == width && sc->last_H == height;
+		const uint32_t decayed = same ? sc->last_R - sc->last_R / 8 : 0u;
+		sc->last_P = P; sc->last_W = width; sc->last_H = height;
+		sc->last_R = h_R > decayed ? h_R : decayed;
+	}
 	if (!guess || (size_t)R > cap) {
 		// first call of this shape, or more instances than guessed
 		if (guess) HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));   // big-tile count of the discarded pass

@@ -281,10 +281,11 @@ def test_depth_gradient_extension(name):
 def test_scratch_size_guess_paths():
     """bsr_forward sizes the binning scratch from the previous call of the same shape and overlaps its one
     read-back with the binning kernels; a guess that is too small must be detected and the stage re-run.
-    Same (P, W, H) three times: first call (no guess), many more instances (guess too small), far fewer
-    (guess too large) -- every result bit-exact, backward included."""
+    Same (P, W, H) five times: first call (no guess), many more instances (guess too small), far fewer twice
+    (guess too large, hint decaying), many more again -- every result bit-exact, backward included."""
     kw = dict(P=3000, W=200, H=120, deg=1, seed=17)
-    variants = [dict(scale_mul=1.0), dict(scale_mul=8.0), dict(scale_mul=1.0, near_fraction=0.7), dict(scale_mul=8.0)]
+    variants = [dict(scale_mul=1.0), dict(scale_mul=16.0), dict(scale_mul=1.0, near_fraction=0.9),
+                dict(scale_mul=1.0, near_fraction=0.95), dict(scale_mul=48.0)]
     rs = []
     for v in variants:
         c = Hh.make_case(**kw, **v)
@@ -297,8 +298,13 @@ def test_scratch_size_guess_paths():
         og = Hh.oracle_grads(c, g)
         for k in ("means3D", "opacities", "shs", "scales", "rotations"):
             assert Hh.max_err_over_scale(getattr(out.grads, k), getattr(og, k)) < 1e-5, (v, k)
-    # the sequence really exercises both mis-guesses (guess = previous num_rendered + 12.5 % + 4096)
-    assert rs[1] > 1.125 * rs[0] + 4096 and rs[2] < 0.6 * rs[1] and rs[3] > 1.125 * rs[2] + 4096
+    # the sequence really exercises both mis-guesses (guess = hint * 1.25 + 4096, the hint being the previous
+    # num_rendered or 7/8 of the previous hint, whichever is larger)
+    hint, short = rs[0], []
+    for r in rs[1:]:
+        short.append(r > hint * 1.25 + 4096)
+        hint = max(r, hint - hint // 8)
+    assert short == [True, False, False, True]
 
 
 def test_alpha_target_extension():
