@@ -92,7 +92,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    # BSR_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, barrier, all-reduce) with one rank
+    force_dist = os.environ.get("BSR_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
+    multi = world > 1 or force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -120,7 +123,7 @@ def main():
         shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1),
                   "shs": (P, 3) if precomp else (P, M, 3)}
         bufs = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in names}
-    bcast_ms = broadcast_gaussians(bufs, src=0) if world > 1 else 0.0
+    bcast_ms = broadcast_gaussians(bufs, src=0, force=force_dist) if multi else 0.0
     gC, gD = upstream_grads(W, H, seed=1)
     gC, gD = gC.to(dev), gD.to(dev)
     # independent views: rank r looks 0.25*r degrees to the side of the scene-A camera
@@ -143,12 +146,12 @@ def main():
             for v in leaves.values():
                 v.grad = None
             torch.autograd.backward((color, depth), (gC, gD))
-            if args.allreduce_grads and world > 1:
-                state["allreduce_ms"] = state.get("allreduce_ms", 0.0) + allreduce_gradients(leaves)
+            if args.allreduce_grads and multi:
+                state["allreduce_ms"] = state.get("allreduce_ms", 0.0) + allreduce_gradients(leaves, force=force_dist)
         state["radii"] = radii
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +168,7 @@ def main():
     prof = _capi.profile_read()
     _capi.profile_enable(False)
 
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -202,6 +205,7 @@ def main():
         out = {
             "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline"
             if args.config == "c3" and not precomp and not args.gaussians and not args.depth_gradient
+            and not args.allreduce_grads
             else f"Msplats/s ({args.config})",
             "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -222,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd, precomp)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

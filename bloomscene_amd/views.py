@@ -36,12 +36,12 @@ def yawed_camera(width, height, fovx, yaw_deg=0.0, device="cpu") -> MiniCam:
     return make_minicam(R, np.zeros(3), fovx, fovy, width, height, device=device)
 
 
-def broadcast_gaussians(bufs: dict, src: int = 0) -> float:
+def broadcast_gaussians(bufs: dict, src: int = 0, force: bool = False) -> float:
     """Broadcast every tensor of ``bufs`` (already allocated with the right shape on all ranks)
     from ``src``.  Returns the elapsed milliseconds.  The tensors are packed into ONE flat fp32
     buffer so a single large collective crosses the xGMI links (236 MB at 1 M Gaussians, SH 3)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0.0
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        return 0.0   # (force: run the collective even with a single rank -- plumbing checks)
     keys = sorted(bufs)
     dev = bufs[keys[0]].device
     sizes = [bufs[k].numel() for k in keys]
@@ -63,7 +63,7 @@ def broadcast_gaussians(bufs: dict, src: int = 0) -> float:
     return ms
 
 
-def allreduce_gradients(params, average: bool = True) -> float:
+def allreduce_gradients(params, average: bool = True, force: bool = False) -> float:
     """Data-parallel training over views: every rank has run forward+backward
     on ITS view with the same Gaussian buffers; sum (or average) the ``.grad`` of ``params`` (an
     iterable of leaf tensors, or a dict of them) across the ranks.  All gradients travel as ONE flat
@@ -71,7 +71,7 @@ def allreduce_gradients(params, average: bool = True) -> float:
     by the per-link rate, so one large collective beats one per tensor.  A leaf without gradient
     contributes zeros (and receives the other ranks' sum).  Returns the elapsed milliseconds; a
     no-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return 0.0
     leaves = list(params.values()) if isinstance(params, dict) else list(params)
     if not leaves:
