@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
 	float T = T_final;
 	const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
-	float accum_rec0 = 0.f, accum_rec1 = 0.f, accum_rec2 = 0.f;
+	float Srec = 0.f;   // sum_ch accum_rec[ch] * dL_dpixel[ch] (+ the depth channel in the extension)
 	float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
 	if (inside) {
 		dpx0 = dL_dpixels[pix_id];
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
 	const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;
 	// depth extension: d_i = gz * z_i + g1 plays the role of a fourth colour channel
-	float gz = 0.f, g1 = 0.f, Rd = 0.f;
+	float gz = 0.f, g1 = 0.f;
 	if (DEPTH && inside) {
 		const float depth_px = out_depth[pix_id];
 		if (depth_px != 0.0f) {   // the forward's acc > 0.5 decision
@@ -385,18 +385,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// in all but rare cases, so the T chain (hundreds of steps in dense tiles) does not drift.
 				const float qT = T * inv;
 				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);
-				// accum_rec folded eagerly: acc' = alpha*c + (1-alpha)*acc is what the reference computes
-				// lazily at the next processed entry (:529); no last_alpha/last_color state is needed.
-				const float e0 = q2.x - accum_rec0, e1 = q2.y - accum_rec1, e2 = q2.z - accum_rec2;
-				float S = e0 * dpx0 + e1 * dpx1 + e2 * dpx2;
-				if (DEPTH) {
-					const float ed = __builtin_fmaf(gz, q1.w, g1) - Rd;
-					S += ed;
-					Rd = Rd + alpha * ed;
-				}
-				accum_rec0 = accum_rec0 + alpha * e0;
-				accum_rec1 = accum_rec1 + alpha * e1;
-				accum_rec2 = accum_rec2 + alpha * e2;
+				// The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it
+				// only through sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so
+				// the projection Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence
+				// Srec' = alpha * u + (1 - alpha) * Srec with u = sum_ch c[ch] * dL_dpixel[ch]: one scalar
+				// instead of three channels (the depth extension adds its term d_i to u).
+				float u = q2.x * dpx0 + q2.y * dpx1 + q2.z * dpx2;
+				if (DEPTH) u += __builtin_fmaf(gz, q1.w, g1);
+				const float S = u - Srec;
+				Srec = Srec + alpha * S;
 				float dL_dalpha = T * S + neg_Tfinal_bg * inv;
 				dL_dalpha = active ? dL_dalpha : 0.f;
 				const float gd = G * dL_dalpha;          // dL/dopacity term
