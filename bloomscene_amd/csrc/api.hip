@@ -65,7 +65,7 @@ BinState BinState::carve(char* p, size_t R)
 }
 size_t ImgState::bytes(size_t N, size_t T)
 {
-	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + align_up(T * 4, 256) + 256;
+	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + align_up(3 * T * 4, 256) + 256;
 }
 ImgState ImgState::carve(char* p, size_t N, size_t T)
 {
@@ -441,7 +441,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	GeomState geom = GeomState::carve(geom_p, (size_t)P);
 	ImgState img = ImgState::carve(img_p, N, (size_t)T);
 
-	HIP_TRY(hipMemsetAsync(img.flags, 0, 4 * sizeof(int), s));
+	HIP_TRY(hipMemsetAsync(img.flags, 0, 8 * sizeof(int), s));
 
 	{
 		PreArgs a;
@@ -518,7 +518,10 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	}
 	if (!guess || (size_t)R > cap) {
 		// first call of this shape, or more instances than guessed
-		if (guess) HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));   // big-tile count of the discarded pass
+		if (guess) {   // big-tile counts of the discarded pass
+			HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));
+			HIP_TRY(hipMemsetAsync(img.flags + 4, 0, 2 * sizeof(int), s));
+		}
 		if (run_binning((size_t)R)) return 1;
 	}
 	STAGE_CHECK("binning", debug, s);

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 
 // ---- tile ranges: tile_start[t] = first sorted position whose tile id is >= t ----
 // Tiles holding more than BSR_SORT_SMALL instances are also appended (one atomic per wave, order
-// irrelevant) to big_tiles, the work list of the wide sort kernels; flags[1] counts them.
+// irrelevant) to the work list of their size class (see below); flags[1], [4], [5] count them.
 #define BSR_SORT_SMALL 1024
 __device__ __forceinline__ int first_not_below(const BinElem* __restrict__ elems_sorted, int n, uint32_t t)
 {
@@ -277,18 +277,30 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 	if (n < 0) n = 0;
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	bool big = false;
+	int cnt_t = 0;
 	if (t <= T) {
 		const int lo = first_not_below(elems_sorted, n, (uint32_t)t);
 		tile_start[t] = (uint32_t)lo;
-		if (t < T && n - lo > BSR_SORT_SMALL) big = first_not_below(elems_sorted, n, (uint32_t)t + 1u) - lo > BSR_SORT_SMALL;
+		if (t < T && n - lo > BSR_SORT_SMALL) {
+			cnt_t = first_not_below(elems_sorted, n, (uint32_t)t + 1u) - lo;
+			big = cnt_t > BSR_SORT_SMALL;
+		}
 	}
-	const uint64_t b = __ballot(big);
-	if (b == 0) return;
+	// one work list per size class of the wide sort kernels (their grids are bounded per class):
+	// class 0: (1024, 4096] -> big_tiles[0..T), count flags[1]; class 1: (4096, 8192] -> [T..2T), flags[4];
+	// class 2: > 8192 -> [2T..3T), flags[5]
+	int cls = -1;
+	if (big) cls = cnt_t > 8192 ? 2 : (cnt_t > 4096 ? 1 : 0);
 	const int lane = threadIdx.x & 63;
-	int base = 0;
-	if (lane == 0) base = atomicAdd(&flags[1], __popcll(b));
-	base = __shfl(base, 0);
-	if (big) big_tiles[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const uint64_t b = __ballot(cls == k);
+		if (b == 0) continue;
+		int base = 0;
+		if (lane == 0) base = atomicAdd(&flags[k == 0 ? 1 : 3 + k], __popcll(b));
+		base = __shfl(base, 0);
+		if (cls == k) big_tiles[(size_t)k * T + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
+	}
 }
 
 // ---- per-tile bitonic sort of 64-bit keys ----
@@ -373,14 +385,14 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t*
 
 // Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
 template <int CAP, int NT>
-__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ big_tiles,
                                                         const int* __restrict__ flags, const BinElem* __restrict__ elems,
                                                         uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[CAP];
 	const int b = blockIdx.x;
-	if (b >= flags[1]) return;
+	if (b >= flags[count_flag]) return;
 	const uint32_t tile = big_tiles[b];
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
@@ -401,7 +413,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t*
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
 	const int b = blockIdx.x;
-	if (b >= flags[1]) return;
+	if (b >= flags[5]) return;
 	{
 		const uint32_t tile = big_tiles[b];
 		const uint32_t start = tile_start[tile];
@@ -487,16 +499,18 @@ void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t*
                        const BinElem* elems, BinElem* elems_free, uint32_t* point_list, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, tile_start, elems, point_list);
-	const int g1 = min(T, n / BSR_SORT_SMALL), g4 = min(T, n / 4096), g8 = min(T, n / BSR_SORT_CHUNK);
+	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
+	// third: each kernel's grid covers its own list completely
+	const int g1 = min(T, n / (BSR_SORT_SMALL + 1)), g4 = min(T, n / 4097), g8 = min(T, n / (BSR_SORT_CHUNK + 1));
 	if (g1 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, tile_start,
+		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, tile_start,
 		                   big_tiles, flags, elems, point_list);
 	if (g4 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, tile_start, big_tiles,
-		                   flags, elems, point_list);
+		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, 4, tile_start,
+		                   big_tiles + (size_t)T, flags, elems, point_list);
 	if (g8 > 0)
-		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, tile_start, big_tiles, flags, elems,
-		                   reinterpret_cast<uint64_t*>(elems_free), point_list);
+		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, tile_start, big_tiles + 2 * (size_t)T,
+		                   flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 
 }  // namespace bsr

@@ -63,8 +63,10 @@ struct ImgState {
 	float* final_T;        // [N]
 	uint32_t* n_contrib;   // [N]
 	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
-	int* flags;            // [4]: prefiltered violation | #big_tiles | kept instances | rect tiles (= reference num_rendered)
-	uint32_t* big_tiles;   // [T] tiles with more than 1024 instances (any order): work list of the wide sort kernels
+	int* flags;            // [8]: prefiltered violation | #tiles (1024, 4096] | kept instances | rect tiles (= reference
+	                       //      num_rendered) | #tiles (4096, 8192] | #tiles > 8192 | - | -
+	uint32_t* big_tiles;   // [3][T] tiles with more than 1024 instances, one list per size class (any order):
+	                       //        work lists of the wide sort kernels
 	static size_t bytes(size_t N, size_t T);
 	static ImgState carve(char* p, size_t N, size_t T);
 };

@@ -278,6 +278,37 @@ def test_depth_gradient_extension(name):
         np.testing.assert_array_equal(out.grads.colors_precomp, base.grads.colors_precomp)
 
 
+def test_every_size_class_of_the_tile_sort_is_covered():
+    """64 tiles that all hold > 1024 instances, 8 of them > 4096 and 2 of them > 8192: the three wide sort
+    kernels take their tiles from work lists built in atomic order, so each one's grid has to cover its WHOLE
+    list (a grid bounded by n / 4096 over a shared list left such tiles unsorted -- found by
+    tools/stress_gpu.py)."""
+    W = H = 128
+    c = Hh.make_case(P=152000, W=W, H=H, deg=0, seed=23, color_mode="precomp", scale_mul=0.5)
+    g = torch.Generator().manual_seed(5)
+    z = c.means3D[:, 2]
+
+    def cluster(lo, hi, tx, ty):   # move Gaussians lo..hi into tile (tx, ty)
+        k = hi - lo
+        px = tx * 16 + 1.0 + torch.rand(k, generator=g) * 13.0
+        py = ty * 16 + 1.0 + torch.rand(k, generator=g) * 13.0
+        c.means3D[lo:hi, 0] = ((2 * px + 1) / W - 1) * z[lo:hi] * c.tanfovx
+        c.means3D[lo:hi, 1] = ((2 * py + 1) / H - 1) * z[lo:hi] * c.tanfovy
+    pos = 0
+    for i in range(8):                       # 8 tiles with ~4500 extra (class (4096, 8192])
+        cluster(pos, pos + 4500, (5 * i + 3) % 8, i)
+        pos += 4500
+    for i in range(2):                       # 2 tiles with ~12000 extra (class > 8192)
+        cluster(pos, pos + 12000, 6 - 5 * i, 7 - 6 * i)
+        pos += 12000
+    st, _ = Hh.run_oracle(c, backward=False)
+    counts = st.ranges[:, 1] - st.ranges[:, 0]
+    assert (counts > 1300).all() and (counts > 5000).sum() >= 8 and (counts > 12000).sum() >= 2
+    assert st.num_rendered // 4097 < 64          # the old shared-list grid for the second class: short of the 64 tiles
+    for _ in range(3):                           # list order is not deterministic: a few tries
+        _assert_forward_bit_exact(c, st)
+
+
 def test_scratch_size_guess_paths():
     """bsr_forward sizes the binning scratch from the previous call of the same shape and overlaps its one
     read-back with the binning kernels; a guess that is too small must be detected and the stage re-run.
