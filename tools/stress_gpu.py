@@ -50,21 +50,70 @@ def chain_sensitivity(st, g, c, depth_gradient):
     return out
 
 
+def stress_anchors(args, rng):
+    """Random sizes of the fused anchor expansion against its oracle (torch ops on CPU; float64 autograd)."""
+    from bloomscene_amd.neural_gaussians import expand_anchors
+    from oracle import anchors as OA
+    dev = torch.device("cuda")
+    t_end = time.time() + args.seconds
+    n = 0
+    while time.time() < t_end:
+        N = int(rng.choice([0, 1, 3, 100, 1000, 7777, 30000]))
+        K = int(rng.choice([1, 2, 5, 10, 13, 40, 256]))
+        if N * K > 600000:
+            continue
+        inp = OA.synthetic_anchor_inputs(N, K, seed=int(rng.integers(0, 1 << 30)), keep_fraction=float(rng.random()),
+                                         zero_quat_rows=int(rng.integers(0, 3)) if N * K > 3 else 0)
+        ref = OA.expand_anchors_reference(*inp)
+        leaves = [t.to(dev).requires_grad_(True) for t in inp]
+        out = expand_anchors(*leaves)
+        assert torch.equal(out[5].cpu(), ref[5]), (N, K)
+        for i in (0, 1, 2):
+            assert torch.equal(out[i].cpu(), ref[i]), (N, K, i)
+        for i in (3, 4):
+            assert ((out[i].cpu().double() - ref[i].double()).abs() <= 1e-6 * ref[i].double().abs() + 1e-30).all(), (N, K, i)
+        S = ref[0].shape[0]
+        if S:
+            up = [torch.randn(S, w, generator=torch.Generator().manual_seed(n)) for w in (3, 3, 1, 3, 4)]
+            torch.autograd.backward(list(out[:5]), [u.to(dev) for u in up])
+            rl = [t.double().requires_grad_(True) for t in inp]
+            rr = OA.expand_anchors_reference(*rl)
+            torch.autograd.backward(list(rr[:5]), [u.double() for u in up])
+            for a, b in zip(leaves, rl):
+                ga, gb = a.grad.cpu().double(), b.grad
+                sc = float(gb.abs().max()) + 1e-30
+                assert float((ga - gb).abs().max()) <= 1e-5 * sc, (N, K)
+        n += 1
+    print(f"anchor stress ok: {n} random cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "hint", "big", "anchors"],
+                    help="mixed: everything random; hint: ONE (P, W, H), random content per call (exercises the "
+                         "scratch-size guess: short, long, decaying); big: few large cases (0.1-0.5 M Gaussians)")
     args = ap.parse_args()
     assert torch.cuda.is_available()
     rng = np.random.default_rng(args.seed)
+    if args.mode == "anchors":
+        return stress_anchors(args, rng)
     t_end = time.time() + args.seconds
     n = 0
     worst = (0.0, None, None)
     n_cond = 0
     while time.time() < t_end:
-        P = int(rng.choice([1, 7, 300, 2000, 10000, 40000]))
-        W = int(rng.integers(1, 420))
-        H = int(rng.integers(1, 300))
+        if args.mode == "hint":
+            P, W, H = 6000, 233, 141
+        elif args.mode == "big":
+            P = int(rng.choice([100000, 250000, 500000]))
+            W = int(rng.integers(400, 1921))
+            H = int(rng.integers(300, 1081))
+        else:
+            P = int(rng.choice([1, 7, 300, 2000, 10000, 40000]))
+            W = int(rng.integers(1, 420))
+            H = int(rng.integers(1, 300))
         deg = int(rng.integers(0, 4))
         kw = dict(P=P, W=W, H=H, deg=deg, seed=int(rng.integers(0, 1 << 30)),
                   scale_mul=float(np.exp(rng.uniform(np.log(0.3), np.log(25.0)))),
@@ -83,6 +132,9 @@ def main():
             kw["squeeze_xy"] = 0.1     # (splats many times larger than the image make the reference's own
                                        #  mean gradient a 1e-3-conditioned cancellation: not a useful check)
         dg = bool(rng.random() < 0.3)
+        if args.mode == "big":
+            kw["scale_mul"] = float(np.exp(rng.uniform(np.log(0.5), np.log(4.0))))
+            kw.pop("squeeze_xy", None)
         c = Hh.make_case(**kw)
         st, g = Hh.run_oracle(c, depth_gradient=dg)
         out = Hh.run_hip(c, depth_gradient=dg)
