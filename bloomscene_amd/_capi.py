@@ -92,8 +92,9 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {last_error()}")
 
 
-def profile_enable(on: bool):
-    lib().bsr_profile_enable(1 if on else 0)
+def profile_enable(on):
+    """False/0: off; True/1: bracket every stage with events; N > 1: only every Nth forward (+ its backward)."""
+    lib().bsr_profile_enable(int(on))
 
 
 def profile_reset():

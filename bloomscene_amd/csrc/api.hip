@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -191,6 +192,10 @@ struct StageRec {
 	int launches = 0;
 };
 static bool g_prof_on = false;
+static int g_prof_every = 1;                      // sample every Nth forward call (and the backward that follows it)
+static std::atomic<unsigned> g_prof_calls{0};     // forward calls since enable
+static std::atomic<bool> g_prof_this_call{true};  // whether the current forward/backward pair is sampled (process-wide:
+                                                  // PyTorch runs the backward on an autograd worker thread)
 static std::mutex g_prof_mu;
 static std::vector<StageRec> g_stages;
 static std::vector<hipEvent_t> g_free_events;   // recycled events (creating thousands of events is slow)
@@ -241,6 +246,8 @@ struct StageTimer {
 	StageTimer(const char* name, hipStream_t stream) : s(stream)
 	{
 		if (!g_prof_on) return;
+		if (!strcmp(name, "preprocess")) g_prof_this_call = (g_prof_calls.fetch_add(1) % (unsigned)g_prof_every) == 0;
+		if (!g_prof_this_call) return;
 		std::lock_guard<std::mutex> lk(g_prof_mu);
 		for (auto& r : g_stages)
 			if (r.name == name || !strcmp(r.name, name)) rec = &r;
@@ -282,7 +289,12 @@ size_t bsr_image_bytes(int W, int H)
 	return ImgState::bytes((size_t)W * H, gx * gy);
 }
 
-int bsr_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+int bsr_profile_enable(int on)
+{
+	g_prof_on = on != 0;
+	g_prof_every = on > 1 ? on : 1;
+	return 0;
+}
 
 int bsr_profile_reset(void)
 {

@@ -220,7 +220,8 @@ size_t bsr_image_bytes(int width, int height);
 
 /* ---- measurement hooks (no reference counterpart; used by bench.py only) ------------------
  * bsr_profile_enable(1) makes every kernel stage of subsequent calls be bracketed by hipEvents
- * on the call's stream; bsr_profile_read() synchronises those events and returns, per stage
+ * on the call's stream (bsr_profile_enable(N), N > 1: only of every Nth forward call and
+ * of the backward call that follows it -- each event costs a few microseconds of pipeline bubble); bsr_profile_read() synchronises those events and returns, per stage
  * name, the accumulated milliseconds and launch count since the last bsr_profile_reset(). */
 #define BSR_PROFILE_MAX_STAGES 16
 typedef struct bsr_stage_profile {
