@@ -3,11 +3,11 @@
 // Stage order of one forward call (cf. the reference's CudaRasterizer::Rasterizer::forward,
 // cuda_rasterizer/rasterizer_impl.cu:198-339):
 //   k_preprocess (project, cull, SH, exact tile cull, Gaussian-major instance numbering)
-//   -> k_scan_wg (workgroup bases, totals) -> 8-byte D2H read (kept, num_rendered) -> binning alloc
-//   -> k_emit -> radix passes on the tile id -> k_tile_ranges -> k_sort_tiles (per-tile LDS sort)
-//   -> k_render_fwd.  No atomics.
-// Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums
-// to a slab, no global atomics) -> k_preprocess_bwd (gathers them per Gaussian, then the chain).
+//   -> k_scan_wg (workgroup bases, totals) -> 16-byte D2H read (kept, num_rendered), overlapped with:
+//   binning alloc (sized from the previous call) -> k_emit -> radix passes on the tile id -> k_tile_ranges
+//   -> k_sort_tiles_* (per-tile LDS sort) -> k_render_fwd.  No float atomics anywhere.
+// Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums to a Gaussian-major
+// slab, no atomics) -> k_preprocess_bwd (adds each Gaussian's adjacent rows, then the chain).
 #include "../../include/bloomscene_rast.h"
 #include "common.h"
 

@@ -147,34 +147,16 @@ __device__ __forceinline__ float bsr_expf(float x)
 	return __builtin_ldexpf(p, (int)k);
 }
 
-// Branch-free variant for arguments known to be <= 0 (or NaN): bit-identical to bsr_expf there.
-// NaN flows through the fma chain; huge negative arguments are fixed up by the final select.
-__device__ __forceinline__ float bsr_expf_nonpos(float x)
-{
-	const float k = __builtin_rintf(x * 1.44269504088896341f);
-	float r = __builtin_fmaf(-k, 0.693359375f, x);
-	r = __builtin_fmaf(-k, -2.12194440e-4f, r);
-	float p = 1.0f / 5040.0f;
-	p = __builtin_fmaf(p, r, 1.0f / 720.0f);
-	p = __builtin_fmaf(p, r, 1.0f / 120.0f);
-	p = __builtin_fmaf(p, r, 1.0f / 24.0f);
-	p = __builtin_fmaf(p, r, 1.0f / 6.0f);
-	p = __builtin_fmaf(p, r, 0.5f);
-	p = __builtin_fmaf(p, r, 1.0f);
-	p = __builtin_fmaf(p, r, 1.0f);
-	const float v = __builtin_ldexpf(p, (int)k);
-	return (x < -104.0f) ? 0.0f : v;
-}
-
 // Wave-wide vote on a predicate, straight from the compare's lane mask.  (HIP's __ballot(int)
 // materialises the predicate as 0/1 in a VGPR and compares it again: two VALU ops per vote, which
 // matters inside the tile walks.)
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// bsr_expf_nonpos without the final "x < -104 -> 0" select, for the tile walks: there the result is
-// only consumed on lanes whose argument passed `power >= power_cut`, and power_cut = -ln(255 o) - 1e-3
-// is above -104 for every finite opacity (-ln(255 * FLT_MAX) = -94.3), so on those lanes the select
-// never fires; other lanes' results are discarded by the callers' predication.  Bit-identical to
+// Branch-free bsr_expf for the tile walks, without the range checks (NaN flows through the fma chain):
+// there the result is only consumed on lanes whose argument passed `power <= 0` and
+// `power >= power_cut`, and power_cut = -ln(255 o) - 1e-3
+// is above -104 for every finite opacity (-ln(255 * FLT_MAX) = -94.3), so on those lanes bsr_expf's
+// underflow cut never fires; other lanes' results are discarded by the callers' predication.  Bit-identical to
 // bsr_expf on every consumed lane.
 __device__ __forceinline__ float bsr_expf_walk(float x)
 {

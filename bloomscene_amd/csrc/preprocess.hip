@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	if (in_range && a.radii) a.radii[idx] = radius_out;
 	if (!FILTER_ONLY) {
 		// Gaussian-major instance blocks for the backward's gather: exclusive scan of the per-Gaussian
-		// tile counts inside the workgroup + one atomic per workgroup on a running total.  Blocks of
+		// tile counts inside the workgroup; the per-workgroup totals are prefix-summed by k_scan_wg.  Blocks of
 		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
 		__shared__ uint32_t s_wave[4];
 		__shared__ uint32_t s_area[4];

@@ -9,8 +9,8 @@
 // The reference issues 9 lane-scattered float atomicAdds per pair.  On MI355X lane-scattered
 // global float atomics run ~17x below the contiguous rate (~20 G/s chip-wide), which would cap this
 // kernel at ~2 ms for C3.  Instead NO global atomic is issued at all:
-//   * the 9 partials are summed over the wave's 64 pixels with DPP row operations (hand
-//     interleaved so no DPP hazard nops are needed),
+//   * the 9 partials are summed over the wave's 64 pixels by a halving reduction on lane-masked DPP
+//     writes (wave_sums_masked below),
 //   * each wave stores its sums in its own LDS slot (LDS float atomics cost ~16 cycles each on
 //     gfx950 whatever the exec mask); the 4 slots are added in a fixed order at the batch end,
 //   * each instance's 9 sums are written ONCE to its row [12 floats] of a GAUSSIAN-MAJOR slab: the
@@ -25,110 +25,12 @@
 
 namespace bsr {
 
-// 64-lane -> 4 row sums (every lane of a row of 16 ends with its row's sum), 9 values at once.
-// Step-major order: consecutive instructions touch different registers, so the 2-wait-state
-// "VALU write -> DPP read" hazard never arises inside the block (s_nop covers the entry).
-#define BSR_DPP9(ctrl)                                                    \
-	"v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n" \
-	"v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-
-// The last two steps add lane 15 of the previous row (row_bcast15, rows 1 and 3) and lane 31
-// (row_bcast31, rows 2 and 3) in place: rows masked off by row_mask keep their value.
-#define BSR_DPP9M(ctrl, rmask)                                            \
-	"v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:" rmask " bank_mask:0xf\n" \
-	"v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:" rmask " bank_mask:0xf\n"
-
-// Sum of each of the 9 values over the 64 lanes; valid in lane 63 on return.
-__device__ __forceinline__ void wave_sums9(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
-                                           float& v7, float& v8)
-{
-	asm volatile("s_nop 1\n" BSR_DPP9("quad_perm:[1,0,3,2]") BSR_DPP9("quad_perm:[2,3,0,1]") BSR_DPP9("row_half_mirror")
-	                 BSR_DPP9("row_mirror") BSR_DPP9M("row_bcast:15", "0xa") BSR_DPP9M("row_bcast:31", "0xc")
-	             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8));
-}
-
-// ---- butterfly reduction of 9 values over the 64 lanes -------------------------------------
-// Instead of nine independent 6-step reductions (54 cross-lane adds) the values are split between
-// partner lanes at every step, halving the live set: 8 -> 4 -> 2 -> 1 value per lane over the steps
-// lane^1, lane^2, lane+-4, while the ninth value rides on the lanes that step 4 (lane+-8) frees up.
-// After two row swaps every lane holds the 64-lane total of component comp(lane):
-//   lane&8 == 0 :  4*(lane&1) + 2*((lane>>1)&1) + ((lane>>2)&1)      (components 0..7)
-//   lane&8 != 0 :  8
-// 33 VALU instructions instead of 54; one 9-lane LDS store instead of nine 1-lane stores.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-__device__ __forceinline__ float wave_sums9_butterfly(float x0, float x1, float x2, float x3, float x4, float x5,
-                                                      float x6, float x7, float x8, int lane)
-{
-	const bool b1 = (lane & 1) != 0, b2 = (lane & 2) != 0, b4 = (lane & 4) != 0, b8 = (lane & 8) != 0;
-	// step lane^1 (quad_perm [1,0,3,2]): even lanes keep 0..3, odd lanes keep 4..7
-	const float a0 = (b1 ? x4 : x0) + dpp_mov<0xB1>(b1 ? x0 : x4);
-	const float a1 = (b1 ? x5 : x1) + dpp_mov<0xB1>(b1 ? x1 : x5);
-	const float a2 = (b1 ? x6 : x2) + dpp_mov<0xB1>(b1 ? x2 : x6);
-	const float a3 = (b1 ? x7 : x3) + dpp_mov<0xB1>(b1 ? x3 : x7);
-	float y = x8 + dpp_mov<0xB1>(x8);
-	// step lane^2 (quad_perm [2,3,0,1])
-	const float c0 = (b2 ? a2 : a0) + dpp_mov<0x4E>(b2 ? a0 : a2);
-	const float c1 = (b2 ? a3 : a1) + dpp_mov<0x4E>(b2 ? a1 : a3);
-	y = y + dpp_mov<0x4E>(y);
-	// step lane+-4 (row_ror:4: the source lane has the opposite bit 2 and the same low bits)
-	float d = (b4 ? c1 : c0) + dpp_mov<0x124>(b4 ? c0 : c1);
-	y = y + dpp_mov<0x124>(y);
-	// step lane+-8 (row_ror:8): lanes 0..7 of a row take the row total of their component,
-	// lanes 8..15 the row total of the ninth value
-	d = (b8 ? y : d) + dpp_mov<0x128>(b8 ? d : y);
-	// rows 0+1 / 2+3, then halves
-	auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-	d = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
-	auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
-}
-
-// Ten values (depth-gradient extension): the ninth and tenth share a register the way 0..7 do, so on
-// return lanes with lane&8 hold component 8 + (lane&1).  35 VALU instructions.
-__device__ __forceinline__ float wave_sums10_butterfly(float x0, float x1, float x2, float x3, float x4, float x5,
-                                                       float x6, float x7, float x8, float x9, int lane)
-{
-	const bool b1 = (lane & 1) != 0, b2 = (lane & 2) != 0, b4 = (lane & 4) != 0, b8 = (lane & 8) != 0;
-	const float a0 = (b1 ? x4 : x0) + dpp_mov<0xB1>(b1 ? x0 : x4);
-	const float a1 = (b1 ? x5 : x1) + dpp_mov<0xB1>(b1 ? x1 : x5);
-	const float a2 = (b1 ? x6 : x2) + dpp_mov<0xB1>(b1 ? x2 : x6);
-	const float a3 = (b1 ? x7 : x3) + dpp_mov<0xB1>(b1 ? x3 : x7);
-	float y = (b1 ? x9 : x8) + dpp_mov<0xB1>(b1 ? x8 : x9);
-	const float c0 = (b2 ? a2 : a0) + dpp_mov<0x4E>(b2 ? a0 : a2);
-	const float c1 = (b2 ? a3 : a1) + dpp_mov<0x4E>(b2 ? a1 : a3);
-	y = y + dpp_mov<0x4E>(y);
-	float d = (b4 ? c1 : c0) + dpp_mov<0x124>(b4 ? c0 : c1);
-	y = y + dpp_mov<0x124>(y);
-	d = (b8 ? y : d) + dpp_mov<0x128>(b8 ? d : y);
-	auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-	d = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
-	auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d), __float_as_uint(d), false, false);
-	return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
-}
-
-// ---- halving reduction v2: lane-masked DPP writes instead of selects ------------------------
-// Measured on MI355X (tools/microbench/valu_rates.hip, 8 waves/SIMD): v_fma/v_mul issue every ~2.6
-// cycles per SIMD, but v_cndmask (SGPR mask), v_cmp -> SGPR and every DPP add every ~4.3.  The
-// butterfly above spends 2 selects + 1 DPP add per pair; here the halving steps run over the lane
+// ---- halving reduction of 9 (10) values over the 64 lanes: lane-masked DPP writes ------------
+// Nine independent 6-step reductions would be 54 cross-lane adds.  Instead the values are split
+// between partner lanes at every step, halving the live set; a first version selected the kept value
+// per lane (2 selects + 1 DPP add per pair, 33 instructions).  Measured on MI355X
+// (tools/microbench/valu_rates.hip, 8 waves/SIMD): v_fma/v_mul issue every ~2.6 cycles per SIMD, but
+// v_cndmask (SGPR mask), v_cmp -> SGPR and every DPP add every ~4.3.  So the halving steps run over the lane
 // bits whose DPP writes the hardware can mask -- bit 2 and 3 through bank_mask (banks of 4 lanes),
 // bit 4 and 5 through v_permlane16/32_swap of a PAIR (swap, then one add) -- so a pair-step costs 2
 // instructions and no select; the plain steps over bits 0 and 1 come last, on the single survivor.
