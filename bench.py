@@ -158,6 +158,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    import gc
+    gc.collect()
+    gc.disable()   # no collector pauses inside the timed region (the steps create no reference cycles)
     # stage events on every 4th step of the timed region: each hipEvent costs a few microseconds of pipeline
     # bubble, 14 per step were 3 % of the step; the per-launch means below are over the sampled launches
     sample_every = 4 if args.steps >= 8 else 1
@@ -168,6 +171,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     prof = _capi.profile_read()
     _capi.profile_enable(False)
 

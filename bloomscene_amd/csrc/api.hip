@@ -126,9 +126,11 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s);
-void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
-                       const BinElem* elems, BinElem* elems_free, uint32_t* point_list, hipStream_t s);
-void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
+                       const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
+                       uint32_t* point_list, hipStream_t s);
+void launch_render_fwd(int gx, int gy, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+                       const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
@@ -483,11 +485,12 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	// (sum of rect areas, rasterizer_impl.cu:278-282), which sizes the binning scratch -> host: the one
 	// blocking read of the forward pass (the reference has the same one, rasterizer_impl.cu:282).
 	//
-	// The read is overlapped with the binning kernels: they take the instance count from device memory,
-	// so when the previous call on this thread had the same (P, width, height) the scratch is sized
-	// from its num_rendered (+25 %, decaying slowly after a large view) BEFORE the read, the binning stage is enqueued behind the copy,
-	// and the host only waits for the copy's event.  If the guess was too small the stage's kernels
-	// returned without touching anything and it is simply run again with the exact size.
+	// The read is overlapped with the REST of the forward: binning, tile sort and render take the instance
+	// count from device memory, so when the previous call on this thread had the same (P, width, height)
+	// the scratch is sized from its num_rendered (+25 %, decaying slowly after a large view) BEFORE the
+	// read, all remaining kernels are enqueued behind the copy, and the host only waits for the copy's
+	// event (to return num_rendered).  If the guess was too small those kernels returned without touching
+	// anything and the tail is simply run again with the exact size.
 	SyncCache* sc = sync_cache();
 	if (!sc) return 1;
 	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_R > 0;
@@ -495,14 +498,31 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	BinState bin;
 	BinElem* elems_sorted = nullptr;
 	BinElem* elems_free = nullptr;
-	auto run_binning = [&](size_t capacity) -> int {
+	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
+	// from device memory and returns at once if it exceeds the capacity
+	auto run_tail = [&](size_t capacity) -> int {
 		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
 		if (!bin_p) return fail("scratch allocation callback returned null");
 		bin = BinState::carve(bin_p, capacity);
 		cap = capacity;
-		StageTimer t("binning", s);
-		launch_binning(P, T, gx, img.flags + 2, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist,
-		               BSR_HIST_BLOCKS_MAX, img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+		const int* n_ptr = img.flags + 2;
+		{
+			StageTimer t("binning", s);
+			launch_binning(P, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
+			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+		}
+		STAGE_CHECK("binning", debug, s);
+		{
+			StageTimer t("sort_tiles", s);
+			launch_sort_tiles(T, (int)capacity, n_ptr, (int)capacity, img.tile_start, img.big_tiles, img.flags,
+			                  elems_sorted, elems_free, bin.point_list, s);
+		}
+		STAGE_CHECK("sort_tiles", debug, s);
+		{
+			StageTimer t("render_fwd", s);
+			launch_render_fwd(gx, gy, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
+			                  background, img.final_T, img.n_contrib, out_color, out_depth, s);
+		}
 		return 0;
 	};
 	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -510,7 +530,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	if (guess) {
 		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
 		if (c > 0x7fffffffu) c = 0x7fffffffu;
-		if (run_binning(c)) return 1;
+		if (run_tail(c)) return 1;   // the whole rest of the forward is in flight before the host waits
 	}
 	HIP_TRY(hipEventSynchronize(sc->copied));
 	const int h_flag = prefiltered ? sc->pinned[0] : 0;
@@ -518,34 +538,19 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
 	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
 	const int R = (int)h_R;
-	const int n_kept = (int)h_kept;
 	if (num_rendered) *num_rendered = R;
 	// size hint for the next call: this call's count, but decaying only by 1/8 per call after a large view
-	// (training visits views in random order; a short guess costs a second binning pass)
+	// (training visits views in random order; a short guess costs a second pass)
 	{
 		const bool same = sc->last_P == P && sc->last_W == width && sc->last_H == height;
 		const uint32_t decayed = same ? sc->last_R - sc->last_R / 8 : 0u;
 		sc->last_P = P; sc->last_W = width; sc->last_H = height;
 		sc->last_R = h_R > decayed ? h_R : decayed;
 	}
-	if (!guess || (size_t)R > cap) {
-		// first call of this shape, or more instances than guessed
-		if (guess) {   // big-tile counts of the discarded pass
-			HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));
-			HIP_TRY(hipMemsetAsync(img.flags + 4, 0, 2 * sizeof(int), s));
-		}
-		if (run_binning((size_t)R)) return 1;
-	}
-	STAGE_CHECK("binning", debug, s);
-	if (n_kept > 0) {
-		StageTimer t("sort_tiles", s);
-		launch_sort_tiles(T, n_kept, img.tile_start, img.big_tiles, img.flags, elems_sorted, elems_free, bin.point_list, s);
-	}
-	STAGE_CHECK("sort_tiles", debug, s);
-	{
-		StageTimer t("render_fwd", s);
-		launch_render_fwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, background, img.final_T,
-		                  img.n_contrib, out_color, out_depth, s);
+	if (!guess || (size_t)h_kept > cap) {
+		// first call of this shape, or more kept instances than the guessed scratch holds (the kernels of the
+		// first attempt then returned without touching anything)
+		if (run_tail((size_t)R)) return 1;
 	}
 	STAGE_CHECK("render_fwd", debug, s);
 	return 0;

@@ -370,13 +370,14 @@ __device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t star
 }
 
 // Small class: one workgroup per tile, n <= BSR_SORT_SMALL.
-__global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
+                                                          const uint32_t* __restrict__ tile_start,
                                                           const BinElem* __restrict__ elems,
                                                           uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[BSR_SORT_SMALL];
 	const int tile = blockIdx.x;
-	if (tile >= T) return;
+	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n > BSR_SORT_SMALL) return;   // on the big-tile list
@@ -385,14 +386,15 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const uint32_t*
 
 // Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
 template <int CAP, int NT>
-__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag, const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag, const int* __restrict__ n_ptr,
+                                                        int capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ big_tiles,
                                                         const int* __restrict__ flags, const BinElem* __restrict__ elems,
                                                         uint32_t* __restrict__ point_list)
 {
 	__shared__ uint64_t s_keys[CAP];
 	const int b = blockIdx.x;
-	if (b >= flags[count_flag]) return;
+	if (*n_ptr > capacity || b >= flags[count_flag]) return;
 	const uint32_t tile = big_tiles[b];
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
@@ -403,7 +405,8 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
 #define BSR_SORT_CHUNK 8192
 #define BSR_SORT_NT 1024
-__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const int* __restrict__ n_ptr, int capacity,
+                                                                 const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
                                                                  const BinElem* __restrict__ elems, uint64_t* keys,
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const uint32_t*
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
 	const int b = blockIdx.x;
-	if (b >= flags[5]) return;
+	if (*n_ptr > capacity || b >= flags[5]) return;
 	{
 		const uint32_t tile = big_tiles[b];
 		const uint32_t start = tile_start[tile];
@@ -495,22 +498,24 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 // (4096, 8192] -> 64 KB and > 8192 -> hybrid take one entry of the big-tile list per workgroup.  n
 // instances can fill at most n / 1024 such tiles (n / 4096, n / 8192 for the wider classes), which
 // bounds their grids: a frame without long lists pays near-empty launches, not 3 x T idle workgroups.
-void launch_sort_tiles(int T, int n, const uint32_t* tile_start, const uint32_t* big_tiles, const int* flags,
-                       const BinElem* elems, BinElem* elems_free, uint32_t* point_list, hipStream_t s)
+void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
+                       const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
+                       uint32_t* point_list, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, tile_start, elems, point_list);
+	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
-	// third: each kernel's grid covers its own list completely
-	const int g1 = min(T, n / (BSR_SORT_SMALL + 1)), g4 = min(T, n / 4097), g8 = min(T, n / (BSR_SORT_CHUNK + 1));
+	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
+	const int g1 = min(T, n_bound / (BSR_SORT_SMALL + 1)), g4 = min(T, n_bound / 4097),
+	          g8 = min(T, n_bound / (BSR_SORT_CHUNK + 1));
 	if (g1 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, tile_start,
-		                   big_tiles, flags, elems, point_list);
+		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
+		                   tile_start, big_tiles, flags, elems, point_list);
 	if (g4 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, 4, tile_start,
-		                   big_tiles + (size_t)T, flags, elems, point_list);
+		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, 4, n_ptr, capacity,
+		                   tile_start, big_tiles + (size_t)T, flags, elems, point_list);
 	if (g8 > 0)
-		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, tile_start, big_tiles + 2 * (size_t)T,
-		                   flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
+		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, n_ptr, capacity, tile_start,
+		                   big_tiles + 2 * (size_t)T, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 
 }  // namespace bsr

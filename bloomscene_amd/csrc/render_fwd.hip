@@ -18,6 +18,7 @@
 namespace bsr {
 
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int W, int H,
+                                                          const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
                                                           const float4* __restrict__ rec,
@@ -32,6 +33,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
+	if (*n_ptr > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
@@ -133,14 +135,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	}
 }
 
-void launch_render_fwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+void launch_render_fwd(int gx, int gy, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+                       const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
-	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start, point_list, rec,
-	                   bg, final_T, n_contrib, out_color, out_depth);
+	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, n_ptr, capacity, tile_start,
+	                   point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 
 }  // namespace bsr
