@@ -56,10 +56,10 @@ int bsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * a culled Gaussian is an error (the reference printf+__trap()s, auxiliary.h:156-160).
  * Performs one blocking 16-byte device->host read (the reference reads 4 bytes, rasterizer_impl.cu:282);
  * it is overlapped with the rest of the forward (binning, tile sort, render), for which binningBuffer may
- * be called with a size guessed
- * from the calling thread's previous calls of the same (P, width, height) -- and a second time, with
- * the exact size, when that guess was short (it then may also be smaller than bsr_binning_bytes(
- * num_rendered): large enough for the instances actually kept).  The last buffer returned is the one handed to backward.
+ * be called with a size guessed from the calling thread's previous calls of the same (P, width,
+ * height); if that cannot hold the instances actually kept, binningBuffer is called a second time
+ * with the exact size and the tail of the pass is repeated.  (A guess that holds may be smaller than
+ * bsr_binning_bytes(num_rendered): instances culled per tile need no room.) The last buffer returned is the one handed to backward.
  * *num_rendered is the reference's value (sum over Gaussians of the tiles of their bounding rect,
  * rasterizer_impl.cu:278-282); it sizes the binning scratch.  Instances whose tile the splat provably
  * cannot reach with alpha >= 1/255 are not listed internally (no output depends on them).
