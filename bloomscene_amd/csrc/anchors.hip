@@ -53,6 +53,8 @@ __global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_anchor_select(int n_cand, 
 }
 
 // In-place exclusive scan of wg_count[0..n) by one workgroup; the grand total goes to wg_count[n].
+// Eight consecutive values per thread and round (two 16-B loads): 20 k workgroup counts take 3 rounds of
+// barriers instead of 20 -- the kernel is pure latency.
 __global__ void __launch_bounds__(1024) k_anchor_scan(int n, uint32_t* __restrict__ wg_count)
 {
 	__shared__ uint32_t s_wave[16];
@@ -60,10 +62,15 @@ __global__ void __launch_bounds__(1024) k_anchor_scan(int n, uint32_t* __restric
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	if (t == 0) s_carry = 0;
 	__syncthreads();
-	for (int base = 0; base < n; base += 1024) {
-		const int i = base + t;
-		const uint32_t v = i < n ? wg_count[i] : 0u;
-		uint32_t incl = v;
+	for (int base = 0; base < n; base += 8192) {
+		const int i0 = base + t * 8;
+		uint32_t v[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = (i0 + k < n) ? wg_count[i0 + k] : 0u;
+		uint32_t mine = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) mine += v[k];
+		uint32_t incl = mine;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
 			const uint32_t o = __shfl_up(incl, d);
@@ -78,7 +85,12 @@ __global__ void __launch_bounds__(1024) k_anchor_scan(int n, uint32_t* __restric
 			before += (w < wave) ? c : 0u;
 			all += c;
 		}
-		if (i < n) wg_count[i] = before + incl - v;
+		uint32_t run = before + incl - mine;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			if (i0 + k < n) wg_count[i0 + k] = run;
+			run += v[k];
+		}
 		__syncthreads();
 		if (t == 0) s_carry += all;
 		__syncthreads();
