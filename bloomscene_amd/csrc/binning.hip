@@ -278,11 +278,15 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 	const int t = blockIdx.x * 256 + threadIdx.x;
 	bool big = false;
 	int cnt_t = 0;
-	if (t <= T) {
-		const int lo = first_not_below(elems_sorted, n, (uint32_t)t);
-		tile_start[t] = (uint32_t)lo;
-		if (t < T && n - lo > BSR_SORT_SMALL) {
-			cnt_t = first_not_below(elems_sorted, n, (uint32_t)t + 1u) - lo;
+	{
+		// every lane searches its own tile's start; the end is the next lane's start (the last lane of a
+		// wave, whose neighbour sits in another wave, searches twice)
+		const int lo = (t <= T) ? first_not_below(elems_sorted, n, (uint32_t)t) : n;
+		if (t <= T) tile_start[t] = (uint32_t)lo;
+		int hi = __shfl_down(lo, 1, 64);
+		if ((threadIdx.x & 63) == 63 && t < T) hi = first_not_below(elems_sorted, n, (uint32_t)t + 1u);
+		if (t < T) {
+			cnt_t = hi - lo;
 			big = cnt_t > BSR_SORT_SMALL;
 		}
 	}
