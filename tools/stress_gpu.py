@@ -3,10 +3,10 @@
 random sizes, image shapes (incl. non-multiples of 16 and tiny ones), SH degrees, colour / covariance
 modes, scale factors (list lengths from 0 to > 8192 per tile), near-plane fractions, free cameras and
 the depth-gradient extension.  Every case: forward bit-exact; gradients within 1e-5 of each tensor's
-scale, or -- where the reference's per-Gaussian chain is ill-conditioned (splats at the near plane or much
-larger than the image amplify a 1-ulp change of the pixel sums by 1e3 and more) -- within 8x the change
-that a 1-ulp perturbation of those sums produces in the oracle itself; and a second run must reproduce
-the first bit for bit.
+scale, or -- where the sums cancel heavily or the reference's per-Gaussian chain is ill-conditioned (splats
+at the near plane or much larger than the image amplify a rounding-level change of the pixel sums by 1e3 and
+more) -- within 8x the change that a 64*eps*sum|terms| perturbation of those sums produces in the oracle
+itself; and a second run must reproduce the first bit for bit.
 
     python tools/stress_gpu.py [--seconds 120] [--seed 0]
 """
@@ -24,18 +24,32 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as Hh  # noqa: E402
 
 
-def chain_sensitivity(st, g, c, depth_gradient):
-    """Largest change of every output gradient (relative to its scale) when the oracle's pixel sums are
-    perturbed by <= 1 ulp each and its own per-Gaussian chain is re-run (3 trials)."""
+def chain_sensitivity(st, c, depth_gradient):
+    """How much may a correct fp32 implementation differ from the oracle?  The pixel sums (dL_dmean2D,
+    dL_dconic, dL_dopacity, dL_dcolors) are sums of many terms that may cancel: each is perturbed by up to
+    64 * eps * sum|terms| (the oracle reports sum|terms|), the oracle's own per-Gaussian chain is re-run, and
+    the largest change of every output gradient, relative to its scale, is returned (3 trials)."""
     from oracle import oracle as O
+    eps = float(np.finfo(np.float32).eps)
     rng = np.random.default_rng(0)
+    g = O.backward(st, c.gC, c.gD, want_abs_sums=True, depth_gradient=depth_gradient)
     base = Hh.oracle_grads(c, g)
+    S = g.abs_sums.astype(np.float64)   # [P, 9]: mean2D.x,y conic.x,y,w opacity colour r,g,b
+    if depth_gradient:
+        S = S * 2.0                      # (the extension's own terms are not in abs_sums; same order of magnitude)
     out = {}
     for _ in range(3):
         h = O.empty_grads(st)
-        for name in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
-            a = getattr(g, name)
-            getattr(h, name)[:] = a * (1 + rng.uniform(-1, 1, size=a.shape).astype(np.float32) * np.float32(2.0 ** -23))
+        def pert(a, cols):
+            d = rng.uniform(-1, 1, size=(a.shape[0], len(cols))) * 64.0 * eps * S[:, cols]
+            return d.astype(np.float32)
+        h.dL_dmeans2D[:] = g.dL_dmeans2D
+        h.dL_dmeans2D[:, :2] += pert(g.dL_dmeans2D, [0, 1])
+        h.dL_dconic[:] = g.dL_dconic
+        cf = h.dL_dconic.reshape(-1, 4)
+        cf[:, [0, 1, 3]] += pert(cf, [2, 3, 4])
+        h.dL_dopacity[:] = g.dL_dopacity + pert(g.dL_dopacity, [5])
+        h.dL_dcolors[:] = g.dL_dcolors + pert(g.dL_dcolors, [6, 7, 8])
         O.backward_chain(st, h)
         if depth_gradient:
             vm = np.asarray(st.rs.viewmatrix, dtype=np.float32).reshape(-1)
@@ -152,7 +166,7 @@ def main():
             if e > worst[0]:
                 worst = (e, k, dict(kw, depth_gradient=dg))
             if e >= 1e-5:
-                sens = chain_sensitivity(st, g, c, dg)
+                sens = chain_sensitivity(st, c, dg)
                 assert e <= 1e-5 + 8.0 * sens[k], (k, e, sens[k], kw, dg)
                 n_cond += 1
             assert np.array_equal(got, got2), (k, kw)
