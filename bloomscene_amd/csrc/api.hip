@@ -29,6 +29,7 @@ size_t GeomState::bytes(size_t P)
 	s += align_up(P * BSR_REC * sizeof(float4), 256);
 	s += align_up(P * sizeof(uint32_t), 256);
 	s += 2 * align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
+	s += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
 	s += align_up(P * sizeof(uint64_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * 6 * sizeof(float), 256);
@@ -43,6 +44,7 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.inst_offset = (uint32_t*)p; p += align_up(P * sizeof(uint32_t), 256);
 	g.wg_kept = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
 	g.wg_area = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
+	g.hist1 = (uint32_t*)p;       p += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
 	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
@@ -123,6 +125,7 @@ void launch_visible_filter_views(int P, int V, const float* means3D, const float
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
                                  hipStream_t s);
 void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
+void launch_rowscan_hist1(int n_wg, uint32_t* hist1, hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s);
@@ -478,6 +481,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	{
 		StageTimer t("scan_wg", s);
 		launch_scan_wg((P + 255) / 256, geom.wg_kept, geom.wg_area, img.flags, s);
+		launch_rowscan_hist1((P + 255) / 256, geom.hist1, s);
 	}
 	STAGE_CHECK("scan_wg", debug, s);
 

@@ -1,4 +1,4 @@
-// Per-tile binning and depth sort -- no atomics anywhere.
+// Per-tile binning and depth sort -- no global atomics anywhere.
 //
 // The reference emits one 64-bit (tile | depth) key per (Gaussian, tile) instance in Gaussian order
 // and runs a global stable radix sort over all R instances on 32+bit key bits, six 8-bit passes at
@@ -7,17 +7,21 @@
 // (:116-138).  The resulting order is (tile, depth bit pattern, Gaussian id).  Here:
 //   1. k_preprocess decided per (Gaussian, tile) whether the splat can reach the tile at all
 //      (exact conservative ellipse-vs-tile test; ~1/3 of the reference's instances are dropped on the
-//      synthetic scenes, no pixel changes) and numbered the kept instances Gaussian-major inside
-//      its workgroup; k_scan_wg prefix-sums the workgroup totals (one workgroup, <= 20k values),
-//   2. k_emit writes every kept instance as one 12-byte element (tile id, Gaussian id, depth bits)
-//      at its Gaussian-major position (coalesced, one thread per Gaussian),
-//   3. ceil(bits(T)/8) stable LSD radix passes on the TILE ID only (1080p: 2 passes instead of the
-//      reference's 6; elements move as single 12-byte loads/stores): per-workgroup digit histogram
-//      -> 256 parallel row scans -> stable scatter (wave ballots for the in-round rank, stamped
-//      per-wave counters across the 4 waves),
-//   4. k_tile_ranges finds each tile's segment by binary search in the sorted tile ids,
+//      synthetic scenes, no pixel changes), numbered the kept instances inside its workgroup and
+//      counted them per low tile-id byte (`hist1`, an LDS histogram per workgroup); k_scan_wg
+//      prefix-sums the workgroup totals and k_rowscan_hist1 the 256 digit rows of hist1,
+//   2. k_emit_scatter writes every kept instance as one 12-byte element (tile id, Gaussian id,
+//      depth bits) straight to its position after the FIRST radix pass: digit base + the prefix of
+//      the earlier workgroups + an LDS counter.  The order inside one (workgroup, digit) group is
+//      whatever the LDS atomics give -- it does not matter, see 5,
+//   3. the remaining ceil(bits(T)/8) - 1 stable LSD radix passes on the TILE ID only (1080p: one
+//      more pass; the reference does six over 45 key bits; elements move as single 12-byte
+//      loads/stores): per-workgroup digit histogram -> 256 parallel row scans -> stable scatter
+//      (wave ballots for the in-round rank, stamped per-wave counters across the 4 waves),
+//   4. k_tile_ranges finds each tile's segment from neighbouring tile ids,
 //   5. k_sort_tiles sorts each segment by its 64-bit key in LDS (bitonic network), which yields
-//      exactly the reference's stable-sort order because ids are unique within a tile.
+//      exactly the reference's stable-sort order because ids are unique within a tile -- so the
+//      order in which step 2 drops equal-tile elements never reaches the output.
 // The earlier version counted and appended instances with global integer atomics (~20 G/s when
 // lane-scattered on MI355X: 0.2 ms at C3, 1.4 ms at C5); this one is also fully deterministic.
 #include "common.h"
@@ -138,33 +142,97 @@ __global__ void __launch_bounds__(256) k_radix_rowscan(const int* __restrict__ n
 	if (tid == 0) digit_total[blockIdx.x] = s_carry;
 }
 
-// ---- every kept instance at its Gaussian-major position ----
-__global__ void __launch_bounds__(256) k_emit(int P, int gx, const int* __restrict__ n_ptr, int capacity,
-                                              const ushort4* __restrict__ rect,
-                                              const uint64_t* __restrict__ kept_mask,
-                                              const uint32_t* __restrict__ inst_offset,
-                                              const uint32_t* __restrict__ wg_base, const float4* __restrict__ rec,
-                                              BinElem* __restrict__ elems)
+// ---- first radix pass, fused with the instance emit ----
+// The per-workgroup histogram over the low 8 bits of the tile id was counted by k_preprocess (hist1,
+// digit-major, one column per preprocess workgroup).  k_rowscan_hist1 turns every digit's row into
+// exclusive prefixes + the digit total; k_emit_scatter then writes each kept instance straight to its
+// place in the pass-1 order: digit base + its workgroup's prefix + a running LDS counter.  The order
+// inside a (workgroup, digit) bucket is arbitrary -- harmless, the per-tile sort orders by the unique
+// (depth, id) key -- so no Gaussian-major staging array, no separate histogram pass.
+__global__ void __launch_bounds__(256) k_rowscan_hist1(int n_wg, uint32_t* __restrict__ hist1)
 {
-	const int idx = blockIdx.x * 256 + threadIdx.x;
-	if (idx >= P) return;
+	__shared__ uint32_t s_wave[4];
+	__shared__ uint32_t s_carry;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int per = (n_wg + 7) >> 3, n_col = 8 * per;   // multiple of 8: rows are 32-B aligned
+	uint32_t* row = hist1 + (size_t)blockIdx.x * n_col;
+	if (tid == 0) s_carry = 0;
+	__syncthreads();
+	// eight consecutive columns per thread and round: the kernel is latency (barriers), not bandwidth
+	for (int base = 0; base < n_col; base += 2048) {
+		const int i0 = base + tid * 8;
+		uint32_t v[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = (i0 + k < n_col && hist1_wg_of_column(i0 + k, per) < n_wg) ? row[i0 + k] : 0u;
+		uint32_t mine = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) mine += v[k];
+		uint32_t incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+		const uint32_t carry = s_carry;
+		uint32_t run = carry + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - mine;
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			if (i0 + k < n_col) row[i0 + k] = run;
+			run += v[k];
+		}
+		__syncthreads();
+		if (tid == 0) s_carry = carry + w0 + w1 + w2 + w3;
+		__syncthreads();
+	}
+	if (tid == 0) hist1[(size_t)BSR_RADIX_BINS * n_col + blockIdx.x] = s_carry;   // digit totals behind the rows
+}
+
+__global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* __restrict__ n_ptr, int capacity,
+                                                      const ushort4* __restrict__ rect,
+                                                      const uint64_t* __restrict__ kept_mask,
+                                                      const float4* __restrict__ rec,
+                                                      const uint32_t* __restrict__ hist1, BinElem* __restrict__ elems)
+{
+	__shared__ uint32_t s_off[BSR_RADIX_BINS];   // next output position per digit for this workgroup
+	__shared__ uint32_t s_scan[4];
 	{
 		const int n = *n_ptr;
 		if (n <= 0 || n > capacity) return;
 	}
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int n_wg = (int)gridDim.x, per = (n_wg + 7) >> 3, n_col = 8 * per;
+	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this workgroup's prefix
+		const uint32_t v = hist1[(size_t)BSR_RADIX_BINS * n_col + tid];
+		uint32_t incl = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		if (lane == 63) s_scan[wave] = incl;
+		__syncthreads();
+		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
+		s_off[tid] = base + hist1[(size_t)tid * n_col + hist1_column((int)blockIdx.x, per)];
+	}
+	__syncthreads();
+	const int idx = blockIdx.x * 256 + tid;
+	if (idx >= P) return;
 	const ushort4 r = rect[idx];
 	if (r.z <= r.x || r.w <= r.y) return;
 	const uint32_t area = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
 	const uint64_t mask = kept_mask[idx];
 	if (kept_count(area, mask) == 0) return;
 	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
-	uint32_t pos = wg_base[idx >> 8] + inst_offset[idx];
 	uint32_t k = 0;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
 			if (!tile_kept(area, mask, k)) continue;
-			store_elem(elems + pos, BinElem{(uint32_t)(y * gx + x), (uint32_t)idx, depth_bits});   // one 12-B store
-			pos++;
+			const uint32_t tile = (uint32_t)(y * gx + x);
+			const uint32_t pos = atomicAdd(&s_off[tile & (BSR_RADIX_BINS - 1)], 1u);   // LDS
+			store_elem(elems + pos, BinElem{tile, (uint32_t)idx, depth_bits});   // one 12-B store
 		}
 }
 
@@ -467,6 +535,12 @@ void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, 
 	hipLaunchKernelGGL(k_scan_wg, dim3(1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags);
 }
 
+// once per forward call, after k_preprocess (independent of the instance count: runs before the read-back)
+void launch_rowscan_hist1(int n_wg, uint32_t* hist1, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_rowscan_hist1, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_wg, hist1);
+}
+
 // Bins the kept instances (their number is read from *n_ptr on the device): emit -> radix passes on
 // the tile id -> tile ranges.  elems_a / elems_b ping-pong; *elems_sorted is the buffer holding the
 // final order.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
@@ -474,8 +548,9 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect, geom.kept_mask,
-	                   geom.inst_offset, geom.wg_kept, geom.rec, elems_a);
+	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_rowscan_hist1
+	hipLaunchKernelGGL(k_emit_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect,
+	                   geom.kept_mask, geom.rec, geom.hist1, elems_a);
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
 	int max_blocks = (capacity + 1023) / 1024;   // chunk >= 1024
@@ -483,7 +558,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 	if (max_blocks < 1) max_blocks = 1;
 	uint32_t* digit_total = hist + (size_t)BSR_RADIX_BINS * hist_blocks_max;
 	BinElem* ei = elems_a; BinElem* eo = elems_b;
-	for (int shift = 0; shift < bits; shift += BSR_RADIX_BITS) {
+	for (int shift = BSR_RADIX_BITS; shift < bits; shift += BSR_RADIX_BITS) {
 		hipLaunchKernelGGL(k_radix_hist, dim3(max_blocks), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, shift, ei,
 		                   hist);
 		hipLaunchKernelGGL(k_radix_rowscan, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_ptr, capacity, hist_blocks_max, hist,

@@ -25,6 +25,9 @@ struct GeomState {
 	uint32_t* wg_kept;      // [ceil(P/256)] kept instances per preprocess workgroup; exclusive-scanned in place
 	                        //               into the workgroup's base by k_scan_tiles (-> "wg_base")
 	uint32_t* wg_area;      // [ceil(P/256)] rect tiles per preprocess workgroup (sum = reference num_rendered)
+	uint32_t* hist1;        // [256][8 * ceil(n_wg / 8)] + [256]: kept instances per (low 8 bits of the tile id, preprocess
+	                        //   workgroup), digit-major, row-scanned in place by k_rowscan_fixed; then the digit totals.
+	                        //   First radix pass = k_emit_scatter: instances are written straight to their pass-1 place.
 	uint64_t* kept_mask;    // [P] see q3 above
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
 	float* cov3D;       // [P][6]
@@ -187,6 +190,13 @@ __device__ __forceinline__ uint32_t kept_count(uint32_t area, uint64_t mask)
 {
 	return area > 64u ? area : (uint32_t)__popcll(mask);
 }
+
+// Column of preprocess workgroup `wg` in the digit-major pass-1 histogram: workgroups that run on the
+// same XCD (wg, wg + 8, wg + 16, ...) are neighbours, so the 4-byte entries they write into one 64-byte
+// sector merge in that XCD's L2.  (Any fixed order works: it only decides in which order the workgroups'
+// buckets are laid out.)  `per` = ceil(n_wg / 8); columns whose workgroup does not exist count as zero.
+__device__ __forceinline__ int hist1_column(int wg, int per) { return (wg & 7) * per + (wg >> 3); }
+__device__ __forceinline__ int hist1_wg_of_column(int c, int per) { return (c % per) * 8 + c / per; }
 
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a
 // contiguous band of tiles; neighbouring tiles gather many of the same splat records.

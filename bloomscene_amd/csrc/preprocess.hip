@@ -100,6 +100,14 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	const bool in_range = idx < a.P;
 	if (FILTER_ONLY && !in_range) return;   // the full kernel keeps every thread for the workgroup scan below
 
+	// histogram of the kept instances over the low 8 bits of their tile id = the per-workgroup histogram of
+	// the first radix pass of the binning (k_emit_scatter), counted while the tiles are being tested anyway
+	__shared__ uint32_t s_hist[256];
+	if (!FILTER_ONLY) {
+		s_hist[threadIdx.x] = 0;
+		__syncthreads();
+	}
+
 	int radius_out = 0;
 	ushort4 rect_out = make_ushort4(0, 0, 0, 0);
 	uint64_t kept_mask = 0;
@@ -204,9 +212,14 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 						for (int y = y0; y < y1; y++)
 							for (int x = x0; x < x1; x++) {
 								if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
-								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE)))
+								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
 									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
+									atomicAdd(&s_hist[(uint32_t)(y * a.gx + x) & 255u], 1u);
+								}
 							}
+					} else {
+						for (int y = rmin[1]; y < rmax[1]; y++)
+							for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&s_hist[(uint32_t)(y * a.gx + x) & 255u], 1u);
 					}
 					rq2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
 				}
@@ -240,7 +253,11 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		}
 		__syncthreads();
 		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-		if (threadIdx.x == 0) {   // no atomics: k_scan_tiles prefix-sums these per-workgroup totals
+		{
+			const int per = ((int)gridDim.x + 7) >> 3;
+			a.geom.hist1[(size_t)threadIdx.x * (8 * per) + hist1_column((int)blockIdx.x, per)] = s_hist[threadIdx.x];
+		}
+		if (threadIdx.x == 0) {   // no global atomics: k_scan_wg prefix-sums these per-workgroup totals
 			a.geom.wg_kept[blockIdx.x] = w0 + w1 + w2 + w3;
 			a.geom.wg_area[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 		}
