@@ -309,6 +309,23 @@ def test_every_size_class_of_the_tile_sort_is_covered():
         _assert_forward_bit_exact(c, st)
 
 
+def test_tile_counts_on_both_sides_of_every_radix_pass():
+    """The binning sorts by tile id in 8-bit passes, the first fused with the emit: <= 256 tiles need no further
+    pass, <= 65536 one, a 4112x4112 image (257 x 257 tiles) two.  Forward bit-exact and autograd parity on each."""
+    for kw in (dict(P=4000, W=256, H=256, deg=1, seed=31, scale_mul=2.0),            # 256 tiles: exactly one digit
+               dict(P=4000, W=257, H=256, deg=1, seed=32, scale_mul=2.0),            # 272 tiles: second pass
+               dict(P=12000, W=4112, H=4112, deg=0, seed=33, scale_mul=1.5, color_mode="precomp")):   # 66049 tiles
+        c = Hh.make_case(**kw)
+        st, g = Hh.run_oracle(c)
+        assert st.num_rendered > 0
+        _assert_forward_bit_exact(c, st)
+        out = Hh.run_hip(c)
+        np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+        og = Hh.oracle_grads(c, g)
+        for k in ("means3D", "opacities", "scales", "rotations"):
+            assert Hh.max_err_over_scale(getattr(out.grads, k), getattr(og, k)) < 1e-5, (kw["W"], k)
+
+
 def test_scratch_size_guess_paths():
     """bsr_forward sizes the binning scratch from the previous call of the same shape and overlaps its one
     read-back with the binning kernels; a guess that is too small must be detected and the stage re-run.
