@@ -166,12 +166,20 @@ def main():
     sample_every = 4 if args.steps >= 8 else 1
     _capi.profile_enable(0 if os.environ.get("BSR_BENCH_NO_STAGE_EVENTS") == "1" else sample_every)
     _capi.profile_reset()
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    host_marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        host_marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
     gc.enable()
+    # diagnostics: hipMalloc calls inside the timed region (0 in steady state) and the slowest host-side step
+    device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
+    host_step_ms = [1e3 * (b - a) for a, b in zip([t0] + host_marks[:-1], host_marks)]
+    if os.environ.get("BSR_BENCH_STEP_TIMES") == "1":
+        print("host ms per step:", " ".join("%.2f" % v for v in host_step_ms), file=sys.stderr)
     prof = _capi.profile_read()
     _capi.profile_enable(False)
 
@@ -230,6 +238,8 @@ def main():
             "roofline_step": {"algorithmic_bytes": sb, "achieved": round(whole, 2),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "host": {"device_allocs_in_timed_region": int(device_allocs),
+                     "max_host_ms_per_step": round(max(host_step_ms), 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd, precomp)

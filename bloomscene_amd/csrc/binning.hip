@@ -394,9 +394,9 @@ __device__ __forceinline__ void cmp_exchange(KeyPtr k, int lo, int hi)
 template <int NT, typename KeyPtr>
 __device__ __forceinline__ void merge_mirror_step(KeyPtr k, int n, int n2, int size, int tid)
 {
-	const int half = size >> 1;
+	const int half = size >> 1, sh = __builtin_ctz(half);
 	for (int i = tid; i < (n2 >> 1); i += NT) {
-		const int blk = i / half, off = i - blk * half;
+		const int blk = i >> sh, off = i & (half - 1);
 		const int hi = blk * size + size - 1 - off;
 		if (hi < n) cmp_exchange(k, blk * size + off, hi);
 	}
@@ -412,17 +412,87 @@ __device__ __forceinline__ void merge_stride_step(KeyPtr k, int n, int n2, int s
 	}
 }
 
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
+__device__ __forceinline__ void cx(uint64_t& a, uint64_t& b)
+{
+	const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+	a = lo;
+	b = hi;
+}
+
+// Two network steps per LDS round trip: a thread holds the four keys that the two steps connect (pads beyond n
+// are +infinity and never move, so a compare-exchange with a pad is the no-op the network needs).  The sort is
+// instruction-issue bound (PMC: ~30 instructions per wave and step, 8 workgroups per CU), so the LDS classes
+// store their pads (PADDED: the array holds n2 keys) and run without any bounds test.
+#define BSR_PAD_KEY 0xFFFFFFFFFFFFFFFFull
+template <bool PADDED, typename KeyPtr>
+__device__ __forceinline__ void quad_steps(KeyPtr k, int n, int i0, int i1, int i2, int i3, bool mirror)
+{
+	if (PADDED) {
+		uint64_t e0 = k[i0], e1 = k[i1], e2 = k[i2], e3 = k[i3];
+		if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
+		cx(e0, e1);
+		cx(e2, e3);
+		k[i0] = e0; k[i1] = e1; k[i2] = e2; k[i3] = e3;
+		return;
+	}
+	if (i0 >= n) return;
+	const uint64_t o0 = k[i0], o1 = i1 < n ? k[i1] : BSR_PAD_KEY, o2 = i2 < n ? k[i2] : BSR_PAD_KEY,
+	               o3 = i3 < n ? k[i3] : BSR_PAD_KEY;
+	uint64_t e0 = o0, e1 = o1, e2 = o2, e3 = o3;
+	if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
+	cx(e0, e1);
+	cx(e2, e3);
+	if (e0 != o0) k[i0] = e0;
+	if (i1 < n && e1 != o1) k[i1] = e1;
+	if (i2 < n && e2 != o2) k[i2] = e2;
+	if (i3 < n && e3 != o3) k[i3] = e3;
+}
+
+// mirrored first step of the merge that builds runs of `size` (>= 4) + its stride size/4 step
+template <int NT, bool PADDED, typename KeyPtr>
+__device__ __forceinline__ void merge_mirror_pair(KeyPtr k, int n, int n2, int size, int tid)
+{
+	const int q = size >> 2, sh = __builtin_ctz(q);
+	for (int i = tid; i < (n2 >> 2); i += NT) {
+		const int blk = i >> sh, off = i & (q - 1), base = blk * size;
+		quad_steps<PADDED>(k, n, base + off, base + off + q, base + size - 1 - off - q, base + size - 1 - off, true);
+	}
+}
+
+// stride steps s and s/2 (s >= 2)
+template <int NT, bool PADDED, typename KeyPtr>
+__device__ __forceinline__ void merge_stride_pair(KeyPtr k, int n, int n2, int s, int tid)
+{
+	const int h = s >> 1;
+	for (int i = tid; i < (n2 >> 2); i += NT) {
+		const int lo = ((i & ~(h - 1)) << 2) | (i & (h - 1));
+		quad_steps<PADDED>(k, n, lo, lo | h, lo | s, lo | s | h, false);
+	}
+}
+
+// Runs of first_size / 2 are already sorted on entry (first_size = 2: nothing is).  PADDED: k[n .. n2) hold
+// BSR_PAD_KEY (n2 = n rounded up to a power of two).
+template <int NT, bool PADDED = false, typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid, int first_size = 2)
 {
 	int n2 = 1;
 	while (n2 < n) n2 <<= 1;
-	for (int size = 2; size <= n2; size <<= 1) {
+	const int nb = PADDED ? n2 : n;   // padded arrays: every index below n2 is real
+	for (int size = first_size; size <= n2; size <<= 1) {
 		__syncthreads();
-		merge_mirror_step<NT>(k, n, n2, size, tid);
-		for (int stride = size >> 2; stride > 0; stride >>= 1) {
+		if (size == 2) {
+			merge_mirror_step<NT>(k, nb, n2, size, tid);
+			continue;
+		}
+		merge_mirror_pair<NT, PADDED>(k, nb, n2, size, tid);
+		int stride = size >> 3;
+		for (; stride >= 2; stride >>= 2) {
 			__syncthreads();
-			merge_stride_step<NT>(k, n, n2, stride, tid);
+			merge_stride_pair<NT, PADDED>(k, nb, n2, stride, tid);
+		}
+		if (stride == 1) {
+			__syncthreads();
+			merge_stride_step<NT>(k, nb, n2, 1, tid);
 		}
 	}
 	__syncthreads();
@@ -430,14 +500,26 @@ __device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid)
 
 __device__ __forceinline__ uint64_t elem_key(const BinElem e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
 
-// LDS sort of one segment (n <= CAP)
+// LDS sort of one segment (n <= CAP, CAP a power of two >= 4): runs of four are sorted in registers on the way
+// in and the pads up to the next power of two are stored with them
 template <int CAP, int NT>
 __device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t start, int n, const BinElem* __restrict__ elems,
                                                  uint32_t* __restrict__ point_list)
 {
 	const int tid = threadIdx.x;
-	for (int i = tid; i < n; i += NT) s_keys[i] = elem_key(load_elem(elems + start + i));
-	bitonic_sort_asc<NT>(s_keys, n, tid);
+	int n2 = 4;
+	while (n2 < n) n2 <<= 1;
+	for (int i = tid * 4; i < n2; i += NT * 4) {
+		uint64_t e0 = i + 0 < n ? elem_key(load_elem(elems + start + i)) : BSR_PAD_KEY;
+		uint64_t e1 = i + 1 < n ? elem_key(load_elem(elems + start + i + 1)) : BSR_PAD_KEY;
+		uint64_t e2 = i + 2 < n ? elem_key(load_elem(elems + start + i + 2)) : BSR_PAD_KEY;
+		uint64_t e3 = i + 3 < n ? elem_key(load_elem(elems + start + i + 3)) : BSR_PAD_KEY;
+		cx(e0, e1); cx(e2, e3);
+		cx(e0, e3); cx(e1, e2);
+		cx(e0, e1); cx(e2, e3);
+		s_keys[i] = e0; s_keys[i + 1] = e1; s_keys[i + 2] = e2; s_keys[i + 3] = e3;
+	}
+	bitonic_sort_asc<NT, true>(s_keys, n, tid, 8);
 	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)s_keys[i];
 }
 

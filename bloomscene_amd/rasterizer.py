@@ -65,11 +65,14 @@ class _Scratch:
     resizeFunctional (RP:27-33)."""
 
     def __init__(self, device):
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.tensor = tensor
 
+        # the closure must not capture `self`: self -> callback -> closure -> self would be a reference cycle that
+        # keeps the scratch tensors (hundreds of MB per call) alive until the cycle collector runs
         def _resize(_user, nbytes):
-            self.tensor.resize_(int(nbytes))
-            return self.tensor.data_ptr()
+            tensor.resize_(int(nbytes))
+            return tensor.data_ptr()
 
         self.callback = _capi.ALLOC_FN(_resize)
 

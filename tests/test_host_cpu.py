@@ -224,3 +224,22 @@ def test_algorithmic_byte_model_is_consistent():
     total = fwd + a["render_bwd"] + a["preprocess_bwd"]
     assert abs(total - bench.step_bytes(P, M, R, N, True)) / total < 0.01
     assert abs(bench.step_bytes(P, M, R, N, True) - 1.40e9) / 1.40e9 < 0.01
+
+
+def test_scratch_buffers_die_without_the_cycle_collector():
+    """The resize callback must not form a reference cycle with its owner: a cycle kept three scratch tensors
+    (hundreds of MB at C3) per call alive until the collector ran, i.e. a hipMalloc per step in steady state."""
+    import gc
+    import weakref
+    from bloomscene_amd import rasterizer as RZ
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        s = RZ._Scratch(torch.device("cpu"))
+        assert s.callback(None, 4096) == s.tensor.data_ptr() and s.tensor.numel() == 4096
+        w = weakref.ref(s.tensor)
+        del s
+        assert w() is None
+    finally:
+        if was:
+            gc.enable()
