@@ -216,6 +216,9 @@ def main():
                         "launches_timed": int(prof[dom][1])}
         if roofline is not None:
             roofline["traffic"] = measured_traffic(args.config, dom)
+            # what actually bounds the tile renderers (from the same committed PMC passes): VALU instructions
+            # issued per SIMD and core-clock cycle; ~0.29 with this instruction mix is a saturated VALU port
+            roofline["valu_insts_per_simd_cycle"] = measured_traffic(args.config, dom, "valu_insts_per_simd_cycle")
         sb = step_bytes(P, M, R, N, do_bwd) + (36 * P if precomp and do_bwd else 12 * P if precomp else 0)
         whole = sb / (ms_per_step * 1e-3) / 1e9
         out = {
@@ -249,14 +252,14 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(config, stage):
+def measured_traffic(config, stage, key="hbm_bytes"):
     """HBM bytes per launch of `stage` from the committed rocprofv3 --pmc passes of this workload
     (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE
     doubled as the MI355X guide prescribes for wide coalesced reads on gfx950), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh)[config][stage]["hbm_bytes"]
+            return json.load(fh)[config][stage][key]
     except (OSError, KeyError, ValueError):
         return None
 

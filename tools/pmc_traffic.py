@@ -12,12 +12,14 @@ import sys
 
 STAGE_OF = {   # kernel name prefix (template arguments stripped) -> bench stage
     "bsr::k_preprocess_bwd": "preprocess_bwd", "bsr::k_preprocess": "preprocess", "bsr::k_scan_wg": "scan_wg",
-    "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
+    "bsr::k_rowscan_hist1": "scan_wg", "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
     "bsr::k_radix_scatter": "binning", "bsr::k_tile_ranges": "binning", "bsr::k_sort_tiles": "sort_tiles",
     "bsr::k_render_fwd": "render_fwd", "bsr::k_render_bwd": "render_bwd",
 }
-# kernels launched more than once per step: launches per step (radix passes at 1080p: 2)
-PER_STEP = {"bsr::k_radix_hist": 2, "bsr::k_radix_rowscan": 2, "bsr::k_radix_scatter": 2}
+# kernels launched more than once per step: launches per step (radix passes at 1080p after the one fused
+# with the emit: 1)
+PER_STEP = {"bsr::k_radix_hist": 1, "bsr::k_radix_rowscan": 1, "bsr::k_radix_scatter": 1}
+SIMDS = 1024   # 256 CUs x 4
 
 
 def main():
@@ -35,6 +37,11 @@ def main():
         wr = r.get("WRITE_SIZE", 0.0) * 1024.0 * mult
         st = stages.setdefault(stage, {"hbm_bytes": 0, "read_bytes_2xFETCH_SIZE": 0, "write_bytes": 0,
                                        "profiled_us": 0.0})
+        if stage in ("render_fwd", "render_bwd") and r.get("GRBM_GUI_ACTIVE") and r.get("SQ_INSTS_VALU"):
+            # one kernel per stage; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles -> core clock during the kernel
+            cycles = r["GRBM_GUI_ACTIVE"] / 8.0
+            st["core_clock_mhz"] = round(cycles / r["dur_us(profiled)"])
+            st["valu_insts_per_simd_cycle"] = round(r["SQ_INSTS_VALU"] / (SIMDS * cycles), 4)
         st["hbm_bytes"] += int(rd + wr)
         st["read_bytes_2xFETCH_SIZE"] += int(rd)
         st["write_bytes"] += int(wr)
@@ -44,7 +51,10 @@ def main():
                     "--warmup 1` (config " + config + ") on MI355X; bytes per launch = mean over launches, summed "
                     "over the kernels of a stage; read bytes = 2 x FETCH_SIZE KiB (gfx950 reports half of wide "
                     "coalesced reads, MI355X_MICROARCH.md section HBM) -- an upper bound for kernels whose reads are "
-                    "narrow gathers (the tile renderers); Infinity-Cache hits are included in FETCH_SIZE; source: "
+                    "narrow gathers (the tile renderers); Infinity-Cache hits are included in FETCH_SIZE; "
+                    "valu_insts_per_simd_cycle = SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the tile renderers "
+                    "issue one VALU instruction per ~3.5 cycles and SIMD, which with the measured issue costs of their "
+                    "instruction mix (tools/microbench/valu_rates.hip: 2.6 .. 4.25 cycles) is a saturated VALU port; source: "
                     + src}
     json.dump(out, sys.stdout, indent=1)
     print()
