@@ -3,7 +3,7 @@
 // Stage order of one forward call (cf. the reference's CudaRasterizer::Rasterizer::forward,
 // cuda_rasterizer/rasterizer_impl.cu:198-339):
 //   k_preprocess (project, cull, SH, exact tile cull, Gaussian-major instance numbering)
-//   -> k_scan_wg (workgroup bases, totals) -> 16-byte D2H read (kept, num_rendered), overlapped with:
+//   -> k_scans (workgroup bases, totals, pass-1 histogram rows) -> 16-byte D2H read (kept, num_rendered), overlapped with:
 //   binning alloc (sized from the previous call) -> k_emit -> radix passes on the tile id -> k_tile_ranges
 //   -> k_sort_tiles_* (per-tile LDS sort) -> k_render_fwd.  No float atomics anywhere.
 // Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums to a Gaussian-major
@@ -34,6 +34,7 @@ size_t GeomState::bytes(size_t P)
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * 6 * sizeof(float), 256);
 	s += align_up(P * sizeof(uint8_t), 256);
+	s += align_up(P * sizeof(float), 256);
 	return s + 256;
 }
 GeomState GeomState::carve(char* p, size_t P)
@@ -48,7 +49,8 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
-	g.clamped = (uint8_t*)p;
+	g.clamped = (uint8_t*)p; p += align_up(P * sizeof(uint8_t), 256);
+	g.depth = (float*)p;
 	return g;
 }
 size_t BinState::bytes(size_t R)
@@ -124,8 +126,7 @@ void launch_visible_filter_views(int P, int V, const float* means3D, const float
                                  const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
                                  hipStream_t s);
-void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s);
-void launch_rowscan_hist1(int n_wg, uint32_t* hist1, hipStream_t s);
+void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s);
@@ -480,8 +481,7 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	}
 	{
 		StageTimer t("scan_wg", s);
-		launch_scan_wg((P + 255) / 256, geom.wg_kept, geom.wg_area, img.flags, s);
-		launch_rowscan_hist1((P + 255) / 256, geom.hist1, s);
+		launch_scans((P + 255) / 256, geom.wg_kept, geom.wg_area, img.flags, geom.hist1, s);
 	}
 	STAGE_CHECK("scan_wg", debug, s);
 

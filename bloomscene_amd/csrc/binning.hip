@@ -8,8 +8,8 @@
 //   1. k_preprocess decided per (Gaussian, tile) whether the splat can reach the tile at all
 //      (exact conservative ellipse-vs-tile test; ~1/3 of the reference's instances are dropped on the
 //      synthetic scenes, no pixel changes), numbered the kept instances inside its workgroup and
-//      counted them per low tile-id byte (`hist1`, an LDS histogram per workgroup); k_scan_wg
-//      prefix-sums the workgroup totals and k_rowscan_hist1 the 256 digit rows of hist1,
+//      counted them per low tile-id byte (`hist1`, an LDS histogram per workgroup); k_scans
+//      prefix-sums the workgroup totals and the 256 digit rows of hist1 (one launch),
 //   2. k_emit_scatter writes every kept instance as one 12-byte element (tile id, Gaussian id,
 //      depth bits) straight to its position after the FIRST radix pass: digit base + the prefix of
 //      the earlier workgroups + an LDS counter.  The order inside one (workgroup, digit) group is
@@ -33,8 +33,10 @@ namespace bsr {
 
 // Exclusive scan of n uint32 in place by ONE 1024-thread workgroup, 4 values per thread and step.
 // Returns the total to every thread.
+struct AllValid { __device__ __forceinline__ bool operator()(int) const { return true; } };
+template <typename Valid = AllValid>
 __device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, uint32_t* s_wave, uint32_t* s_carry,
-                                                         bool write)
+                                                         bool write, Valid valid = Valid())
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	if (tid == 0) *s_carry = 0;
@@ -43,7 +45,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, 
 		const int i = base + tid * 4;
 		uint32_t v[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) v[k] = (i + k < n) ? data[i + k] : 0u;
+		for (int k = 0; k < 4; k++) v[k] = (i + k < n && valid(i + k)) ? data[i + k] : 0u;
 		const uint32_t mine = v[0] + v[1] + v[2] + v[3];
 		uint32_t incl = mine;
 #pragma unroll
@@ -71,24 +73,40 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, 
 	return *s_carry;
 }
 
-// Per-preprocess-workgroup totals: kept instances -> workgroup bases (in place) and flags[2] = total
-// kept; rect tiles -> flags[3] = the reference's num_rendered.
-__global__ void __launch_bounds__(1024) k_scan_wg(int n_wg, uint32_t* __restrict__ wg_kept,
-                                                  uint32_t* __restrict__ wg_area, int* __restrict__ flags)
+// The two scans between k_preprocess and the binning, in one launch:
+//  workgroup 256     : per-preprocess-workgroup totals: kept instances -> workgroup bases (in place) and
+//                      flags[2] = total kept; rect tiles -> flags[3] = the reference's num_rendered,
+//  workgroups 0..255 : digit d's row of hist1 (the pass-1 histogram counted by k_preprocess, digit-major, one
+//                      column per preprocess workgroup, XCD-grouped) -> exclusive prefixes in place + the digit
+//                      total behind the rows.  Pad columns (no workgroup) are never written and count as 0.
+struct Hist1ColumnValid {
+	int per, n_wg;
+	__device__ __forceinline__ bool operator()(int col) const { return hist1_wg_of_column(col, per) < n_wg; }
+};
+__global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__ wg_kept,
+                                                uint32_t* __restrict__ wg_area, int* __restrict__ flags,
+                                                uint32_t* __restrict__ hist1)
 {
 	__shared__ uint32_t s_w[16];
 	__shared__ uint32_t s_c;
-	const uint32_t kept = block_exclusive_scan(n_wg, wg_kept, s_w, &s_c, true);
-	__syncthreads();
-	const uint32_t area = block_exclusive_scan(n_wg, wg_area, s_w, &s_c, false);
-	if (threadIdx.x == 0) {
-		flags[2] = (int)kept;
-		flags[3] = (int)area;
+	if (blockIdx.x == BSR_RADIX_BINS) {
+		const uint32_t kept = block_exclusive_scan(n_wg, wg_kept, s_w, &s_c, true);
+		__syncthreads();
+		const uint32_t area = block_exclusive_scan(n_wg, wg_area, s_w, &s_c, false);
+		if (threadIdx.x == 0) {
+			flags[2] = (int)kept;
+			flags[3] = (int)area;
+		}
+		return;
 	}
+	const int per = (n_wg + 7) >> 3, n_col = 8 * per;
+	const uint32_t total = block_exclusive_scan(n_col, hist1 + (size_t)blockIdx.x * n_col, s_w, &s_c, true,
+	                                            Hist1ColumnValid{per, n_wg});
+	if (threadIdx.x == 0) hist1[(size_t)BSR_RADIX_BINS * n_col + blockIdx.x] = total;   // digit totals behind the rows
 }
 
 // The binning kernels take the number of kept instances from DEVICE memory (flags[2], written by
-// k_scan_wg) and derive their work partition from it themselves, so the host can enqueue the whole
+// k_scans) and derive their work partition from it themselves, so the host can enqueue the whole
 // binning stage before it has read that number back (bsr_forward overlaps its one blocking read with
 // these kernels).  `capacity` is the number of instances the scratch buffers were sized for; if more
 // were kept, every kernel returns at once and the host re-runs the stage with the right size.
@@ -144,56 +162,15 @@ __global__ void __launch_bounds__(256) k_radix_rowscan(const int* __restrict__ n
 
 // ---- first radix pass, fused with the instance emit ----
 // The per-workgroup histogram over the low 8 bits of the tile id was counted by k_preprocess (hist1,
-// digit-major, one column per preprocess workgroup).  k_rowscan_hist1 turns every digit's row into
+// digit-major, one column per preprocess workgroup).  k_scans turns every digit's row into
 // exclusive prefixes + the digit total; k_emit_scatter then writes each kept instance straight to its
 // place in the pass-1 order: digit base + its workgroup's prefix + a running LDS counter.  The order
 // inside a (workgroup, digit) bucket is arbitrary -- harmless, the per-tile sort orders by the unique
 // (depth, id) key -- so no Gaussian-major staging array, no separate histogram pass.
-__global__ void __launch_bounds__(256) k_rowscan_hist1(int n_wg, uint32_t* __restrict__ hist1)
-{
-	__shared__ uint32_t s_wave[4];
-	__shared__ uint32_t s_carry;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int per = (n_wg + 7) >> 3, n_col = 8 * per;   // multiple of 8: rows are 32-B aligned
-	uint32_t* row = hist1 + (size_t)blockIdx.x * n_col;
-	if (tid == 0) s_carry = 0;
-	__syncthreads();
-	// eight consecutive columns per thread and round: the kernel is latency (barriers), not bandwidth
-	for (int base = 0; base < n_col; base += 2048) {
-		const int i0 = base + tid * 8;
-		uint32_t v[8];
-#pragma unroll
-		for (int k = 0; k < 8; k++) v[k] = (i0 + k < n_col && hist1_wg_of_column(i0 + k, per) < n_wg) ? row[i0 + k] : 0u;
-		uint32_t mine = 0;
-#pragma unroll
-		for (int k = 0; k < 8; k++) mine += v[k];
-		uint32_t incl = mine;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += t;
-		}
-		if (lane == 63) s_wave[wave] = incl;
-		__syncthreads();
-		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-		const uint32_t carry = s_carry;
-		uint32_t run = carry + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - mine;
-#pragma unroll
-		for (int k = 0; k < 8; k++) {
-			if (i0 + k < n_col) row[i0 + k] = run;
-			run += v[k];
-		}
-		__syncthreads();
-		if (tid == 0) s_carry = carry + w0 + w1 + w2 + w3;
-		__syncthreads();
-	}
-	if (tid == 0) hist1[(size_t)BSR_RADIX_BINS * n_col + blockIdx.x] = s_carry;   // digit totals behind the rows
-}
-
 __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* __restrict__ n_ptr, int capacity,
                                                       const ushort4* __restrict__ rect,
                                                       const uint64_t* __restrict__ kept_mask,
-                                                      const float4* __restrict__ rec,
+                                                      const float* __restrict__ depth,
                                                       const uint32_t* __restrict__ hist1, BinElem* __restrict__ elems)
 {
 	__shared__ uint32_t s_off[BSR_RADIX_BINS];   // next output position per digit for this workgroup
@@ -225,7 +202,7 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 	const uint32_t area = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
 	const uint64_t mask = kept_mask[idx];
 	if (kept_count(area, mask) == 0) return;
-	const uint32_t depth_bits = __float_as_uint(rec[(size_t)idx * BSR_REC + 1].w);
+	const uint32_t depth_bits = __float_as_uint(depth[idx]);
 	uint32_t k = 0;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
@@ -612,15 +589,10 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const int* __re
 	}
 }
 
-void launch_scan_wg(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, hipStream_t s)
+// once per forward call, right after k_preprocess (independent of the instance count: runs before the read-back)
+void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_scan_wg, dim3(1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags);
-}
-
-// once per forward call, after k_preprocess (independent of the instance count: runs before the read-back)
-void launch_rowscan_hist1(int n_wg, uint32_t* hist1, hipStream_t s)
-{
-	hipLaunchKernelGGL(k_rowscan_hist1, dim3(BSR_RADIX_BINS), dim3(256), 0, s, n_wg, hist1);
+	hipLaunchKernelGGL(k_scans, dim3(BSR_RADIX_BINS + 1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags, hist1);
 }
 
 // Bins the kept instances (their number is read from *n_ptr on the device): emit -> radix passes on
@@ -630,9 +602,9 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s)
 {
-	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_rowscan_hist1
+	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_scans
 	hipLaunchKernelGGL(k_emit_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect,
-	                   geom.kept_mask, geom.rec, geom.hist1, elems_a);
+	                   geom.kept_mask, geom.depth, geom.hist1, elems_a);
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
 	int max_blocks = (capacity + 1023) / 1024;   // chunk >= 1024

@@ -32,6 +32,7 @@ struct GeomState {
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
 	float* cov3D;       // [P][6]
 	uint8_t* clamped;   // [P] bit ch = SH colour channel ch was clamped at 0
+	float* depth;           // [P] view-space depth again, compact: k_emit_scatter needs nothing else of the 64-B record
 	static size_t bytes(size_t P);
 	static GeomState carve(char* p, size_t P);
 };
@@ -94,7 +95,7 @@ struct PreArgs {
 	int prefiltered;
 	int* radii;          // may be NULL
 	GeomState geom;
-	int* flags;            // [0] prefiltered violation, [2] kept instances, [3] rect tiles (both set by k_scan_wg)
+	int* flags;            // [0] prefiltered violation, [2] kept instances, [3] rect tiles (both set by k_scans)
 };
 
 struct BwdArgs {

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	if (in_range && a.radii) a.radii[idx] = radius_out;
 	if (!FILTER_ONLY) {
 		// Gaussian-major instance blocks for the backward's gather: exclusive scan of the per-Gaussian
-		// tile counts inside the workgroup; the per-workgroup totals are prefix-summed by k_scan_wg.  Blocks of
+		// tile counts inside the workgroup; the per-workgroup totals are prefix-summed by k_scans.  Blocks of
 		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
 		__shared__ uint32_t s_wave[4];
 		__shared__ uint32_t s_area[4];
@@ -257,13 +257,14 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			const int per = ((int)gridDim.x + 7) >> 3;
 			a.geom.hist1[(size_t)threadIdx.x * (8 * per) + hist1_column((int)blockIdx.x, per)] = s_hist[threadIdx.x];
 		}
-		if (threadIdx.x == 0) {   // no global atomics: k_scan_wg prefix-sums these per-workgroup totals
+		if (threadIdx.x == 0) {   // no global atomics: k_scans prefix-sums these per-workgroup totals
 			a.geom.wg_kept[blockIdx.x] = w0 + w1 + w2 + w3;
 			a.geom.wg_area[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 		}
 		if (in_range) {
 			const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
 			a.geom.rect[idx] = rect_out;
+			a.geom.depth[idx] = rq1.w;
 			a.geom.inst_offset[idx] = off;
 			a.geom.kept_mask[idx] = kept_mask;
 			if (radius_out > 0) {

@@ -11,8 +11,7 @@ import json
 import sys
 
 STAGE_OF = {   # kernel name prefix (template arguments stripped) -> bench stage
-    "bsr::k_preprocess_bwd": "preprocess_bwd", "bsr::k_preprocess": "preprocess", "bsr::k_scan_wg": "scan_wg",
-    "bsr::k_rowscan_hist1": "scan_wg", "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
+    "bsr::k_preprocess_bwd": "preprocess_bwd", "bsr::k_preprocess": "preprocess", "bsr::k_scans": "scan_wg", "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
     "bsr::k_radix_scatter": "binning", "bsr::k_tile_ranges": "binning", "bsr::k_sort_tiles": "sort_tiles",
     "bsr::k_render_fwd": "render_fwd", "bsr::k_render_bwd": "render_bwd",
 }
