@@ -536,7 +536,10 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
 #define BSR_SORT_CHUNK 8192
 #define BSR_SORT_NT 1024
-__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const int* __restrict__ n_ptr, int capacity,
+// One launch for the two rare classes: workgroups [0, g4) take the (4096, 8192] list (big_tiles[T..2T), count
+// flags[4]) and sort in LDS; workgroups [g4, g4 + g8) take the > 8192 list (big_tiles[2T..3T), flags[5]).
+__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, const int* __restrict__ n_ptr,
+                                                                 int capacity,
                                                                  const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
@@ -546,10 +549,21 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(const int* __re
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
-	const int b = blockIdx.x;
-	if (*n_ptr > capacity || b >= flags[5]) return;
+	int b = blockIdx.x;
+	if (*n_ptr > capacity) return;
+	if (b < g4) {
+		if (b >= flags[4]) return;
+		const uint32_t tile = big_tiles[(size_t)T + b];
+		const uint32_t start = tile_start[tile];
+		const int n = (int)(tile_start[tile + 1] - start);
+		if (n <= 4096 || n > CH) return;   // (uniform over the workgroup)
+		sort_segment_lds<CH, NT>(s_keys, start, n, elems, point_list);
+		return;
+	}
+	b -= g4;
+	if (b >= flags[5]) return;
 	{
-		const uint32_t tile = big_tiles[b];
+		const uint32_t tile = big_tiles[2 * (size_t)T + b];
 		const uint32_t start = tile_start[tile];
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= CH) return;
@@ -643,12 +657,9 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	if (g1 > 0)
 		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
 		                   tile_start, big_tiles, flags, elems, point_list);
-	if (g4 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<8192, 1024>), dim3(g4), dim3(1024), 0, s, 4096, 4, n_ptr, capacity,
-		                   tile_start, big_tiles + (size_t)T, flags, elems, point_list);
-	if (g8 > 0)
-		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g8), dim3(BSR_SORT_NT), 0, s, n_ptr, capacity, tile_start,
-		                   big_tiles + 2 * (size_t)T, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
+	if (g4 + g8 > 0)
+		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g4 + g8), dim3(BSR_SORT_NT), 0, s, T, g4, n_ptr, capacity, tile_start,
+		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
 }
 
 }  // namespace bsr
