@@ -33,6 +33,10 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, C.c_float, _F, _F,
                               _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int, C.c_void_p,
                               C.POINTER(C.c_int)]),
+    "bsr_forward_views": (C.c_int, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F,
+                                    C.c_float, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int,
+                                    C.c_void_p, C.POINTER(C.c_int)]),
     "bsr_visible_filter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                      C.c_float, C.c_float, C.c_int, _F, C.c_int, C.c_void_p]),
     "bsr_visible_filter_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,

@@ -92,7 +92,7 @@ struct SyncCache {
 	int* pinned = nullptr;       // [4] = flags[0..3]
 	hipEvent_t copied = nullptr;
 	int device = -1;
-	int last_P = -1, last_W = -1, last_H = -1;
+	int last_P = -1, last_W = -1, last_H = -1, last_V = -1;
 	uint32_t last_R = 0;
 };
 static SyncCache* sync_cache()
@@ -133,7 +133,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s);
-void launch_render_fwd(int gx, int gy, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s);
@@ -282,6 +282,161 @@ struct StageTimer {
 
 using namespace bsr;
 
+static int check_common(int P, int width, int height, const float* means3D, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix);
+// One or several views of the same Gaussians.  V = 1 is bsr_forward (scratch layouts as the backward expects them);
+// V > 1 stacks the views into one virtual image of V * gy tile rows (see PreArgs::n_views) so that every kernel
+// after k_preprocess runs unchanged over V * T tiles -- the sparse views of a camera sweep are launch/latency
+// bound one by one.
+static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer,
+                        void* binning_user, bsr_alloc_fn imageBuffer, void* image_user, int P, int D, int M,
+                        const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
+                int debug, void* stream, int* num_rendered)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (num_rendered) *num_rendered = 0;
+	if (P == 0) {   // reference rasterize_points.cu:68-82: zero images, no scratch, num_rendered = 0
+		if (width <= 0 || height <= 0 || !out_color || !out_depth) return fail("invalid image outputs");
+		HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)V * 3 * width * height * sizeof(float), s));
+		HIP_TRY(hipMemsetAsync(out_depth, 0, (size_t)V * width * height * sizeof(float), s));
+		return 0;
+	}
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
+	if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail("scratch allocation callback is null");
+	if (!out_color || !out_depth || !background) return fail("out_color/out_depth/background is null");
+	if (P > 0) {
+		if (!opacities) return fail("opacities is null");
+		if ((shs == nullptr) == (colors_precomp == nullptr))
+			return fail("Please provide excatly one of either SHs or precomputed colors!");
+		if (shs && (!cam_pos || M <= 0)) return fail("SH colours need cam_pos and M > 0");
+		if (shs && D >= 0 && (D + 1) * (D + 1) > M && D <= 3)
+			return fail("sh_degree %d needs %d coefficients but M = %d", D, (D + 1) * (D + 1), M);
+	}
+	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
+	if ((long long)V * gy > 65535 || (long long)V * gx * gy > 0x3fffffff) return fail("too many views for one call");
+	const int T = gx * gy * V;   // tiles of the stacked virtual image
+	const size_t N = (size_t)width * height * (size_t)V;
+	const int n_wg = ((P + 255) / 256) * V;
+	// geometry rows: P for one view (what the backward carves), V * P_pad virtual ids for several
+	const size_t P_rows = V == 1 ? (size_t)P : (size_t)n_wg * 256;
+	if (P_rows > 0x7fffffffu) return fail("too many (view, Gaussian) pairs for one call");
+
+	char* geom_p = geometryBuffer(geometry_user, GeomState::bytes(P_rows));
+	char* img_p = imageBuffer(image_user, ImgState::bytes(N, (size_t)T));
+	if (!geom_p || !img_p) return fail("scratch allocation callback returned null");
+	GeomState geom = GeomState::carve(geom_p, P_rows);
+	ImgState img = ImgState::carve(img_p, N, (size_t)T);
+
+	HIP_TRY(hipMemsetAsync(img.flags, 0, 8 * sizeof(int), s));
+
+	{
+		PreArgs a;
+		memset(&a, 0, sizeof(a));
+		a.P = P; a.D = D; a.M = M;
+		a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
+		a.opacities = opacities; a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+		a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
+		a.W = width; a.H = height; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+		a.focal_y = height / (2.0f * tan_fovy);   // reference rasterizer_impl.cu:223-224
+		a.focal_x = width / (2.0f * tan_fovx);
+		a.gx = gx; a.gy = gy; a.prefiltered = prefiltered; a.radii = radii; a.geom = geom;
+		a.flags = img.flags;
+		a.n_views = V;
+		if (V > 1)   // sparse views: k_preprocess then writes only the non-zero bins of its pass-1 histogram
+			HIP_TRY(hipMemsetAsync(geom.hist1, 0, (size_t)256 * ((size_t)(n_wg + 7) / 8 * 8) * sizeof(uint32_t), s));
+		{
+			StageTimer t("preprocess", s);
+			launch_preprocess(a, false, s);
+		}
+		STAGE_CHECK("preprocess", debug, s);
+	}
+	{
+		StageTimer t("scan_wg", s);
+		launch_scans(n_wg, geom.wg_kept, geom.wg_area, img.flags, geom.hist1, s);
+	}
+	STAGE_CHECK("scan_wg", debug, s);
+
+	// flags[2] = instances kept after the exact tile cull, flags[3] = the reference's num_rendered
+	// (sum of rect areas, rasterizer_impl.cu:278-282), which sizes the binning scratch -> host: the one
+	// blocking read of the forward pass (the reference has the same one, rasterizer_impl.cu:282).
+	//
+	// The read is overlapped with the REST of the forward: binning, tile sort and render take the instance
+	// count from device memory, so when the previous call on this thread had the same (P, width, height)
+	// the scratch is sized from its num_rendered (+25 %, decaying slowly after a large view) BEFORE the
+	// read, all remaining kernels are enqueued behind the copy, and the host only waits for the copy's
+	// event (to return num_rendered).  If the guess was too small those kernels returned without touching
+	// anything and the tail is simply run again with the exact size.
+	SyncCache* sc = sync_cache();
+	if (!sc) return 1;
+	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_V == V && sc->last_R > 0;
+	size_t cap = 0;
+	BinState bin;
+	BinElem* elems_sorted = nullptr;
+	BinElem* elems_free = nullptr;
+	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
+	// from device memory and returns at once if it exceeds the capacity
+	auto run_tail = [&](size_t capacity) -> int {
+		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
+		if (!bin_p) return fail("scratch allocation callback returned null");
+		bin = BinState::carve(bin_p, capacity);
+		cap = capacity;
+		const int* n_ptr = img.flags + 2;
+		{
+			StageTimer t("binning", s);
+			launch_binning((int)P_rows, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
+			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+		}
+		STAGE_CHECK("binning", debug, s);
+		{
+			StageTimer t("sort_tiles", s);
+			launch_sort_tiles(T, (int)capacity, n_ptr, (int)capacity, img.tile_start, img.big_tiles, img.flags,
+			                  elems_sorted, elems_free, bin.point_list, s);
+		}
+		STAGE_CHECK("sort_tiles", debug, s);
+		{
+			StageTimer t("render_fwd", s);
+			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
+			                  background, img.final_T, img.n_contrib, out_color, out_depth, s);
+		}
+		return 0;
+	};
+	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+	HIP_TRY(hipEventRecord(sc->copied, s));
+	if (guess) {
+		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
+		if (c > 0x7fffffffu) c = 0x7fffffffu;
+		if (run_tail(c)) return 1;   // the whole rest of the forward is in flight before the host waits
+	}
+	HIP_TRY(hipEventSynchronize(sc->copied));
+	const int h_flag = prefiltered ? sc->pinned[0] : 0;
+	const uint32_t h_kept = (uint32_t)sc->pinned[2], h_R = (uint32_t)sc->pinned[3];
+	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
+	const int R = (int)h_R;
+	if (num_rendered) *num_rendered = R;
+	// size hint for the next call: this call's count, but decaying only by 1/8 per call after a large view
+	// (training visits views in random order; a short guess costs a second pass)
+	{
+		const bool same = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_V == V;
+		const uint32_t decayed = same ? sc->last_R - sc->last_R / 8 : 0u;
+		sc->last_P = P; sc->last_W = width; sc->last_H = height; sc->last_V = V;
+		sc->last_R = h_R > decayed ? h_R : decayed;
+	}
+	if (!guess || (size_t)h_kept > cap) {
+		// first call of this shape, or more kept instances than the guessed scratch holds (the kernels of the
+		// first attempt then returned without touching anything)
+		if (run_tail((size_t)R)) return 1;
+	}
+	STAGE_CHECK("render_fwd", debug, s);
+	return 0;
+}
+
+
 extern "C" {
 
 int bsr_version(void) { return BSR_VERSION; }
@@ -429,135 +584,29 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
                 int debug, void* stream, int* num_rendered)
 {
+	return forward_impl(1, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D, M,
+	                    background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+	                    rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+	                    out_color, out_depth, radii, debug, stream, num_rendered);
+}
+
+int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer, void* binning_user,
+                      bsr_alloc_fn imageBuffer, void* image_user, int P, int D, int M, int n_views,
+                      const float* background, int width, int height, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                      const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
+                      const float* projmatrices, const float* cam_positions, float tan_fovx, float tan_fovy,
+                      int prefiltered, float* out_color, float* out_depth, int* radii, int debug, void* stream,
+                      int* num_rendered)
+{
 	g_err[0] = 0;
-	hipStream_t s = (hipStream_t)stream;
 	if (num_rendered) *num_rendered = 0;
-	if (P == 0) {   // reference rasterize_points.cu:68-82: zero images, no scratch, num_rendered = 0
-		if (width <= 0 || height <= 0 || !out_color || !out_depth) return fail("invalid image outputs");
-		HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)3 * width * height * sizeof(float), s));
-		HIP_TRY(hipMemsetAsync(out_depth, 0, (size_t)width * height * sizeof(float), s));
-		return 0;
-	}
-	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
-	if (!geometryBuffer || !binningBuffer || !imageBuffer) return fail("scratch allocation callback is null");
-	if (!out_color || !out_depth || !background) return fail("out_color/out_depth/background is null");
-	if (P > 0) {
-		if (!opacities) return fail("opacities is null");
-		if ((shs == nullptr) == (colors_precomp == nullptr))
-			return fail("Please provide excatly one of either SHs or precomputed colors!");
-		if (shs && (!cam_pos || M <= 0)) return fail("SH colours need cam_pos and M > 0");
-		if (shs && D >= 0 && (D + 1) * (D + 1) > M && D <= 3)
-			return fail("sh_degree %d needs %d coefficients but M = %d", D, (D + 1) * (D + 1), M);
-	}
-	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
-	const int T = gx * gy;
-	const size_t N = (size_t)width * height;
-
-	char* geom_p = geometryBuffer(geometry_user, GeomState::bytes((size_t)P));
-	char* img_p = imageBuffer(image_user, ImgState::bytes(N, (size_t)T));
-	if (!geom_p || !img_p) return fail("scratch allocation callback returned null");
-	GeomState geom = GeomState::carve(geom_p, (size_t)P);
-	ImgState img = ImgState::carve(img_p, N, (size_t)T);
-
-	HIP_TRY(hipMemsetAsync(img.flags, 0, 8 * sizeof(int), s));
-
-	{
-		PreArgs a;
-		memset(&a, 0, sizeof(a));
-		a.P = P; a.D = D; a.M = M;
-		a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
-		a.opacities = opacities; a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
-		a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
-		a.W = width; a.H = height; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-		a.focal_y = height / (2.0f * tan_fovy);   // reference rasterizer_impl.cu:223-224
-		a.focal_x = width / (2.0f * tan_fovx);
-		a.gx = gx; a.gy = gy; a.prefiltered = prefiltered; a.radii = radii; a.geom = geom;
-		a.flags = img.flags;
-		{
-			StageTimer t("preprocess", s);
-			launch_preprocess(a, false, s);
-		}
-		STAGE_CHECK("preprocess", debug, s);
-	}
-	{
-		StageTimer t("scan_wg", s);
-		launch_scans((P + 255) / 256, geom.wg_kept, geom.wg_area, img.flags, geom.hist1, s);
-	}
-	STAGE_CHECK("scan_wg", debug, s);
-
-	// flags[2] = instances kept after the exact tile cull, flags[3] = the reference's num_rendered
-	// (sum of rect areas, rasterizer_impl.cu:278-282), which sizes the binning scratch -> host: the one
-	// blocking read of the forward pass (the reference has the same one, rasterizer_impl.cu:282).
-	//
-	// The read is overlapped with the REST of the forward: binning, tile sort and render take the instance
-	// count from device memory, so when the previous call on this thread had the same (P, width, height)
-	// the scratch is sized from its num_rendered (+25 %, decaying slowly after a large view) BEFORE the
-	// read, all remaining kernels are enqueued behind the copy, and the host only waits for the copy's
-	// event (to return num_rendered).  If the guess was too small those kernels returned without touching
-	// anything and the tail is simply run again with the exact size.
-	SyncCache* sc = sync_cache();
-	if (!sc) return 1;
-	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_R > 0;
-	size_t cap = 0;
-	BinState bin;
-	BinElem* elems_sorted = nullptr;
-	BinElem* elems_free = nullptr;
-	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
-	// from device memory and returns at once if it exceeds the capacity
-	auto run_tail = [&](size_t capacity) -> int {
-		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
-		if (!bin_p) return fail("scratch allocation callback returned null");
-		bin = BinState::carve(bin_p, capacity);
-		cap = capacity;
-		const int* n_ptr = img.flags + 2;
-		{
-			StageTimer t("binning", s);
-			launch_binning(P, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
-			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
-		}
-		STAGE_CHECK("binning", debug, s);
-		{
-			StageTimer t("sort_tiles", s);
-			launch_sort_tiles(T, (int)capacity, n_ptr, (int)capacity, img.tile_start, img.big_tiles, img.flags,
-			                  elems_sorted, elems_free, bin.point_list, s);
-		}
-		STAGE_CHECK("sort_tiles", debug, s);
-		{
-			StageTimer t("render_fwd", s);
-			launch_render_fwd(gx, gy, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
-			                  background, img.final_T, img.n_contrib, out_color, out_depth, s);
-		}
-		return 0;
-	};
-	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipEventRecord(sc->copied, s));
-	if (guess) {
-		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
-		if (c > 0x7fffffffu) c = 0x7fffffffu;
-		if (run_tail(c)) return 1;   // the whole rest of the forward is in flight before the host waits
-	}
-	HIP_TRY(hipEventSynchronize(sc->copied));
-	const int h_flag = prefiltered ? sc->pinned[0] : 0;
-	const uint32_t h_kept = (uint32_t)sc->pinned[2], h_R = (uint32_t)sc->pinned[3];
-	if (h_flag) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-	if (h_R > 0x7fffffffu) return fail("too many tile instances (%u)", h_R);
-	const int R = (int)h_R;
-	if (num_rendered) *num_rendered = R;
-	// size hint for the next call: this call's count, but decaying only by 1/8 per call after a large view
-	// (training visits views in random order; a short guess costs a second pass)
-	{
-		const bool same = sc->last_P == P && sc->last_W == width && sc->last_H == height;
-		const uint32_t decayed = same ? sc->last_R - sc->last_R / 8 : 0u;
-		sc->last_P = P; sc->last_W = width; sc->last_H = height;
-		sc->last_R = h_R > decayed ? h_R : decayed;
-	}
-	if (!guess || (size_t)h_kept > cap) {
-		// first call of this shape, or more kept instances than the guessed scratch holds (the kernels of the
-		// first attempt then returned without touching anything)
-		if (run_tail((size_t)R)) return 1;
-	}
-	STAGE_CHECK("render_fwd", debug, s);
-	return 0;
+	if (n_views < 0) return fail("n_views must be >= 0");
+	if (n_views == 0) return 0;
+	return forward_impl(n_views, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D,
+	                    M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+	                    rotations, cov3D_precomp, viewmatrices, projmatrices, cam_positions, tan_fovx, tan_fovy,
+	                    prefiltered, out_color, out_depth, radii, debug, stream, num_rendered);
 }
 
 }  // extern "C"

@@ -93,7 +93,11 @@ struct PreArgs {
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	int gx, gy;
 	int prefiltered;
-	int* radii;          // may be NULL
+	int* radii;          // may be NULL; [n_views][P]
+	int n_views;         // >= 1.  View-batched forward (bsr_forward_views): grid.y = view, viewmatrix / projmatrix /
+	                     // cam_pos hold n_views entries, every geometry row is indexed by the virtual id
+	                     // view * P_pad + idx (P_pad = P rounded up to 256) and tile rows are offset by view * gy:
+	                     // the views are stacked into one virtual image of n_views * gy tile rows
 	GeomState geom;
 	int* flags;            // [0] prefiltered violation, [2] kept instances, [3] rect tiles (both set by k_scans)
 };

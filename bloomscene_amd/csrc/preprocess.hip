@@ -99,6 +99,11 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const bool in_range = idx < a.P;
 	if (FILTER_ONLY && !in_range) return;   // the full kernel keeps every thread for the workgroup scan below
+	// view-batched call: grid.y = view; `id` indexes the geometry rows (== idx for a single view)
+	const int view = (int)blockIdx.y;
+	const int wg = view * (int)gridDim.x + (int)blockIdx.x;
+	const int id = wg * 256 + (int)threadIdx.x;
+	const int ty_off = view * a.gy;   // tile rows of this view in the stacked virtual image
 
 	// histogram of the kept instances over the low 8 bits of their tile id = the per-workgroup histogram of
 	// the first radix pass of the binning (k_emit_scatter), counted while the tiles are being tested anyway
@@ -115,8 +120,8 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 
 	const int ld = in_range ? idx : 0;
 	const float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
-	const float* vm = a.viewmatrix;
-	const float* pm = a.projmatrix;
+	const float* vm = a.viewmatrix + 16 * view;
+	const float* pm = a.projmatrix + 16 * view;
 	const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
 	bool alive = in_range && !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
 	if (in_range && !alive && a.prefiltered) a.flags[0] = 1;
@@ -136,10 +141,6 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			const float sc[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
 			const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
 			cov3d_from_scale_rot(sc, a.scale_modifier, q, cov3D);
-		}
-		if (!FILTER_ONLY) {
-#pragma unroll
-			for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)idx * 6 + k] = cov3D[k];
 		}
 
 		Cov2DTerms tt;
@@ -161,12 +162,16 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) != 0) {
 				radius_out = (int)my_radius;
 				if (!FILTER_ONLY) {
-					rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)rmin[1],
-					                        (unsigned short)rmax[0], (unsigned short)rmax[1]);
+					rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)(rmin[1] + ty_off),
+					                        (unsigned short)rmax[0], (unsigned short)(rmax[1] + ty_off));
+					// kept for the backward, which only visits Gaussians with radius > 0 (the reference stores it for
+					// every Gaussian in front of the camera, rasterizer_impl.cu / forward.cu:208-214)
+#pragma unroll
+					for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)id * 6 + k] = cov3D[k];
 					float rgb[3];
 					uint8_t clamp_bits = 0;
 					if (a.colors_precomp == nullptr) {
-						sh_to_rgb(a.D, a.M, p, a.cam_pos, a.shs + (size_t)idx * a.M * 3, rgb, clamp_bits);
+						sh_to_rgb(a.D, a.M, p, a.cam_pos + 3 * view, a.shs + (size_t)idx * a.M * 3, rgb, clamp_bits);
 					} else {
 						rgb[0] = a.colors_precomp[3 * idx];
 						rgb[1] = a.colors_precomp[3 * idx + 1];
@@ -178,7 +183,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
 					rq0 = make_float4(pix_x, pix_y, conic_a, conic_b);
 					rq1 = make_float4(conic_c, power_cut, opacity, pvz);
-					a.geom.clamped[idx] = clamp_bits;
+					a.geom.clamped[id] = clamp_bits;
 					// Keep one instance per tile of the rect the splat can actually reach: the reference
 					// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
 					// alpha < 1/255 everywhere only ever `continue` in its render loops, so dropping them
@@ -214,19 +219,20 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 								if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
 								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
 									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
-									atomicAdd(&s_hist[(uint32_t)(y * a.gx + x) & 255u], 1u);
+									atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
 								}
 							}
 					} else {
 						for (int y = rmin[1]; y < rmax[1]; y++)
-							for (int x = rmin[0]; x < rmax[0]; x++) atomicAdd(&s_hist[(uint32_t)(y * a.gx + x) & 255u], 1u);
+							for (int x = rmin[0]; x < rmax[0]; x++)
+								atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
 					}
 					rq2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
 				}
 			}
 		}
 	}
-	if (in_range && a.radii) a.radii[idx] = radius_out;
+	if (in_range && a.radii) a.radii[(size_t)view * a.P + idx] = radius_out;
 	if (!FILTER_ONLY) {
 		// Gaussian-major instance blocks for the backward's gather: exclusive scan of the per-Gaussian
 		// tile counts inside the workgroup; the per-workgroup totals are prefix-summed by k_scans.  Blocks of
@@ -254,24 +260,29 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		__syncthreads();
 		const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
 		{
-			const int per = ((int)gridDim.x + 7) >> 3;
-			a.geom.hist1[(size_t)threadIdx.x * (8 * per) + hist1_column((int)blockIdx.x, per)] = s_hist[threadIdx.x];
+			const int per = ((int)(gridDim.x * gridDim.y) + 7) >> 3;
+			// (view-batched calls: hist1 was zero-filled and most workgroups of a sparse view have nothing to add)
+			if (a.n_views <= 1 || s_hist[threadIdx.x] != 0u)
+				a.geom.hist1[(size_t)threadIdx.x * (8 * per) + hist1_column(wg, per)] = s_hist[threadIdx.x];
 		}
 		if (threadIdx.x == 0) {   // no global atomics: k_scans prefix-sums these per-workgroup totals
-			a.geom.wg_kept[blockIdx.x] = w0 + w1 + w2 + w3;
-			a.geom.wg_area[blockIdx.x] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
+			a.geom.wg_kept[wg] = w0 + w1 + w2 + w3;
+			a.geom.wg_area[wg] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 		}
+		if (!in_range && a.n_views > 1) a.geom.rect[id] = rect_out;   // padding rows between the views: empty rect
 		if (in_range) {
 			const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
-			a.geom.rect[idx] = rect_out;
-			a.geom.depth[idx] = rq1.w;
-			a.geom.inst_offset[idx] = off;
-			a.geom.kept_mask[idx] = kept_mask;
+			a.geom.rect[id] = rect_out;
+			if (area_all != 0u) {   // readers look at the rect first: culled rows need nothing else (sparse views)
+				a.geom.depth[id] = rq1.w;
+				a.geom.inst_offset[id] = off;
+				a.geom.kept_mask[id] = kept_mask;
+			}
 			if (radius_out > 0) {
 				// the whole 64-B splat record in four back-to-back stores: each cache line is written once,
 				// completely (written piecemeal across the kernel, partially filled lines were evicted and
 				// re-written: 181 MB of HBM writes for 113 MB of data at C3)
-				float4* rec = a.geom.rec + (size_t)idx * BSR_REC;
+				float4* rec = a.geom.rec + (size_t)id * BSR_REC;
 				rec[0] = rq0;
 				rec[1] = rq1;
 				rec[2] = rq2;
@@ -366,7 +377,7 @@ void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s)
 	if (filter_only)
 		hipLaunchKernelGGL(k_preprocess<true>, dim3(blocks), dim3(256), 0, s, a);
 	else
-		hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_preprocess<false>, dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s)

@@ -17,7 +17,9 @@
 
 namespace bsr {
 
-__global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int W, int H,
+// View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
+// row tyv belongs to view tyv / gy; pixel coordinates, image outputs and the per-pixel state are per view.
+__global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
@@ -36,7 +38,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	if (*n_ptr > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
-	const int tx = tile % gx, ty = tile / gx;
+	const int tx = tile % gx, tyv = tile / gx;
+	const int view = tyv / gy, ty = tyv - view * gy;
 	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
 	const bool inside = px < W && py < H;
@@ -124,25 +127,26 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	}
 
 	if (inside) {
-		const size_t pix_id = (size_t)W * py + px;
 		const size_t plane = (size_t)H * W;
-		final_T[pix_id] = T;
-		n_contrib[pix_id] = last16 >> 4;
-		out_color[pix_id] = C0 + T * bg_color[0];
-		out_color[plane + pix_id] = C1 + T * bg_color[1];
-		out_color[2 * plane + pix_id] = C2 + T * bg_color[2];
-		out_depth[pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
+		const size_t pix_id = (size_t)W * py + px, img = (size_t)view * plane;
+		final_T[img + pix_id] = T;
+		n_contrib[img + pix_id] = last16 >> 4;
+		float* oc = out_color + 3 * img;
+		oc[pix_id] = C0 + T * bg_color[0];
+		oc[plane + pix_id] = C1 + T * bg_color[1];
+		oc[2 * plane + pix_id] = C2 + T * bg_color[2];
+		out_depth[img + pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
 	}
 }
 
-void launch_render_fwd(int gx, int gy, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, hipStream_t s)
 {
-	const int n_tiles = gx * gy;
+	const int n_tiles = gx * gy * n_views;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
-	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, n_ptr, capacity, tile_start,
+	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, gy, W, H, n_ptr, capacity, tile_start,
 	                   point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 

@@ -116,6 +116,47 @@ def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations,
     return num_rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 
+def _rasterize_gaussians_views_native(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                      viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh,
+                                      degree, camposes, prefiltered, debug):
+    """Forward of V views in one native call (bsr_forward_views; no reference counterpart -- the reference renders a
+    camera sweep view by view): returns (num_rendered summed over the views, color [V,3,H,W], depth [V,1,H,W],
+    radii [V,P]), view by view bit-identical to `_rasterize_gaussians_native`.  Forward only."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+    view = _dev_f32(viewmatrices, "viewmatrices", dev)
+    proj = _dev_f32(projmatrices, "projmatrices", dev)
+    campos = _dev_f32(camposes, "camposes", dev)
+    if view.dim() != 3 or tuple(view.shape[1:]) != (4, 4) or proj.shape != view.shape:
+        raise RuntimeError("viewmatrices / projmatrices must have dimensions (num_views, 4, 4)")
+    V = view.size(0)
+    if campos is None or tuple(campos.shape) != (V, 3):
+        raise RuntimeError("camposes must have dimensions (num_views, 3)")
+    out_color = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((V, 1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+    M = sh.size(1) if (sh is not None and sh.numel() != 0) else 0
+    t = dict(bg=_dev_f32(bg, "bg", dev), means3D=_dev_f32(means3D, "means3D", dev),
+             colors=_dev_f32(colors, "colors_precomp", dev), opacity=_dev_f32(opacity, "opacities", dev),
+             scales=_dev_f32(scales, "scales", dev), rotations=_dev_f32(rotations, "rotations", dev),
+             cov3D=_dev_f32(cov3D_precomp, "cov3D_precomp", dev), sh=_dev_f32(sh, "shs", dev))
+    num_rendered = C.c_int(0)
+    with torch.cuda.device(dev):
+        rc = _capi.lib().bsr_forward_views(
+            geom.callback, None, binning.callback, None, img.callback, None,
+            P, int(degree), int(M), int(V), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]), _ptr(t["colors"]),
+            _ptr(t["opacity"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
+            _ptr(view), _ptr(proj), _ptr(campos), float(tan_fovx), float(tan_fovy),
+            int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr() if P and V else None,
+            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered))
+    _capi.check(rc, "rasterize_gaussians_views")
+    return num_rendered.value, out_color, out_depth, radii
+
+
 def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rotations, scale_modifier,
                                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                          dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer,

@@ -197,18 +197,62 @@ def prefilter_views(cams, means3D, scales, rotations, scaling_modifier=1.0, debu
     return radii > 0
 
 
-def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, world=None, keep_outputs=False):
+def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_modifier=1.0, debug=False):
+    """Inference forward of several cameras in ONE native call (bsr_forward_views): returns
+    (frames [V,3,H,W], depths [V,1,H,W], radii [V,P]), view by view bit-identical to ``render_view``.
+    The views of a camera sweep see few Gaussians each, so one at a time they are launch/latency bound; batched,
+    binning, per-tile sort and render run once over all of them.  Cameras must share image size and field of view
+    (they do in the rotate360 sweep: utils/trajectory.py:110-121).  No gradients."""
+    from .rasterizer import _rasterize_gaussians_views_native
+    xyz = gaussians["means3D"]
+    dev = xyz.device
+    if not cams:
+        raise ValueError("render_views_batched needs at least one camera")
+    c0 = cams[0]
+    for c in cams:
+        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx \
+                or c.FoVy != c0.FoVy:
+            raise ValueError("render_views_batched needs cameras of one image size and field of view")
+    if (gaussians.get("shs") is None) == (gaussians.get("colors_precomp") is None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    e = torch.Tensor([])
+
+    def opt(k):
+        v = gaussians.get(k)
+        return e if v is None else v
+    vms = torch.stack([c.world_view_transform.to(dev) for c in cams]).contiguous()
+    pms = torch.stack([c.full_proj_transform.to(dev) for c in cams]).contiguous()
+    cps = torch.stack([c.camera_center.to(dev) for c in cams]).contiguous()
+    with torch.no_grad():
+        _, color, depth, radii = _rasterize_gaussians_views_native(
+            bg_color, xyz, opt("colors_precomp"), gaussians["opacities"], opt("scales"), opt("rotations"),
+            scaling_modifier, opt("cov3D_precomp"), vms, pms, math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5),
+            int(c0.image_height), int(c0.image_width), opt("shs"), sh_degree, cps, False, debug)
+    return color, depth, radii
+
+
+def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, world=None, keep_outputs=False,
+                         batch=1):
     """The rotate360 loop of BloomScene.render_video (reference bloomscene.py:191-211), sharded:
     this rank renders its round-robin share of ``cams`` with torch.no_grad() and returns
-    {view index: (frame [3,H,W], depth [1,H,W])} (or only the indices when not keeping outputs)."""
+    {view index: (frame [3,H,W], depth [1,H,W])} (or only the indices when not keeping outputs).
+    ``batch`` > 1 renders that many of the rank's views per native call (``render_views_batched``)."""
     if rank is None:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     if world is None:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     out = {}
     dev = gaussians["means3D"].device
+    mine = list(shard_views(len(cams), rank, world))
     with torch.no_grad():
-        for i in shard_views(len(cams), rank, world):
+        if batch > 1:
+            for b0 in range(0, len(mine), batch):
+                idx = mine[b0:b0 + batch]
+                color, depth, _ = render_views_batched([cams[i].to(dev) for i in idx], gaussians, bg_color, sh_degree)
+                for k, i in enumerate(idx):
+                    out[i] = (color[k], depth[k]) if keep_outputs else None
+            return out
+        for i in mine:
             cam = cams[i].to(dev)
             res = render_view(cam, gaussians, bg_color, sh_degree)
             out[i] = (res["render"], res["depth"]) if keep_outputs else None

@@ -112,6 +112,41 @@ int bsr_visible_filter(int P, int M,
                        int debug,
                        void* stream);
 
+/* bsr_forward for n_views cameras of one image size and field of view in ONE call (forward only: the
+ * scratch it leaves is not a valid input of bsr_backward).  out_color[n_views,3,H,W], out_depth[n_views,1,H,W]
+ * and radii[n_views,P] hold, view by view, exactly (bit for bit) what n_views calls of bsr_forward with
+ * viewmatrices + 16*v, projmatrices + 16*v, cam_positions + 3*v (DEVICE float[n_views,16] / [n_views,16] /
+ * [n_views,3]) write; *num_rendered is the sum of their num_rendered.  The views are stacked into one virtual
+ * image of n_views * ceil(H/16) tile rows, so binning, per-tile sort and render run once over all of them:
+ * the sparse views of a camera sweep (few visible Gaussians each) are launch/latency bound one at a time.
+ * Scratch grows with n_views (geometry: n_views * P rows).  No reference counterpart: the reference renders
+ * the rotate360 sweep view by view (bloomscene.py:191-193 -> gaussian_renderer/__init__.py:224-262). */
+int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user,
+                      bsr_alloc_fn binningBuffer, void* binning_user,
+                      bsr_alloc_fn imageBuffer, void* image_user,
+                      int P, int D, int M, int n_views,
+                      const float* background,
+                      int width, int height,
+                      const float* means3D,
+                      const float* shs,
+                      const float* colors_precomp,
+                      const float* opacities,
+                      const float* scales,
+                      float scale_modifier,
+                      const float* rotations,
+                      const float* cov3D_precomp,
+                      const float* viewmatrices,
+                      const float* projmatrices,
+                      const float* cam_positions,
+                      float tan_fovx, float tan_fovy,
+                      int prefiltered,
+                      float* out_color,
+                      float* out_depth,
+                      int* radii,
+                      int debug,
+                      void* stream,
+                      int* num_rendered);
+
 /* bsr_visible_filter for n_views cameras of one image size and field of view in ONE pass over the
  * Gaussians: radii[v*P + i] is exactly what bsr_visible_filter writes to radii[i] with
  * viewmatrices + 16*v / projmatrices + 16*v (DEVICE float[n_views,16] each).  Each Gaussian is read,

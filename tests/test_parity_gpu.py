@@ -551,3 +551,57 @@ def test_full_size_c3_properties_and_parity():
     rast = GaussianRasterizer(Hh.hip_settings(c, dev))
     rf = rast.visible_filter(c.means3D.to(dev), c.scales.to(dev), c.rotations.to(dev))
     np.testing.assert_array_equal(rf.cpu().numpy(), out.radii)
+
+
+def test_view_batched_forward_equals_per_view_calls():
+    """bsr_forward_views: V cameras in one call, stacked into one virtual image.  Every view must be bit-identical
+    to its own bsr_forward call (colour, depth, radii), num_rendered must be the sum; P is not a multiple of 256
+    (padding rows between the views), the views differ (empty one included), SH and precomputed colours."""
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    e = torch.Tensor([])
+    for kw in (dict(P=3000, W=200, H=120, deg=3, seed=41, scale_mul=3.0),
+               dict(P=70001, W=333, H=190, deg=1, seed=42, scale_mul=2.0, scene="b"),
+               dict(P=2500, W=97, H=61, deg=0, seed=43, scale_mul=4.0, color_mode="precomp", cov_mode="precomp")):
+        c = Hh.make_case(**kw)
+        rs = Hh.hip_settings(c, dev)
+        from bloomscene_amd.views import yawed_camera
+        # yaw 180 looks away from the scene: an empty view in the middle of the batch
+        cams = [yawed_camera(c.W, c.H, c.cam.FoVx, yaw_deg=y) for y in (0.0, 8.0, -15.0, 180.0, 2.0)]
+        cams = [cm.to(dev) for cm in cams]
+        tfx, tfy = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
+
+        def d(t):
+            return e if t is None else t.to(dev)
+        t = dict(means3D=c.means3D.to(dev), colors=d(c.colors_precomp), opac=c.opacities.to(dev), scales=d(c.scales),
+                 rot=d(c.rotations), cov=d(c.cov3D_precomp), shs=d(c.shs))
+        singles = []
+        for cm in cams:
+            R1, color, depth, radii, _, _, _ = RZ._rasterize_gaussians_native(
+                rs.bg, t["means3D"], t["colors"], t["opac"], t["scales"], t["rot"], rs.scale_modifier, t["cov"],
+                cm.world_view_transform, cm.full_proj_transform, tfx, tfy, c.H, c.W, t["shs"], c.deg,
+                cm.camera_center, False, False)
+            singles.append((R1, color.cpu().numpy(), depth.cpu().numpy(), radii.cpu().numpy()))
+        vms = torch.stack([cm.world_view_transform for cm in cams])
+        pms = torch.stack([cm.full_proj_transform for cm in cams])
+        cps = torch.stack([cm.camera_center for cm in cams])
+        for _ in range(2):   # second call: scratch sized from the first one's count
+            Rv, colors, depths, radiis = RZ._rasterize_gaussians_views_native(
+                rs.bg, t["means3D"], t["colors"], t["opac"], t["scales"], t["rot"], rs.scale_modifier, t["cov"], vms, pms,
+                tfx, tfy, c.H, c.W, t["shs"], c.deg, cps, False, False)
+            torch.cuda.synchronize()
+            assert Rv == sum(s[0] for s in singles)
+            assert any(s[0] > 0 for s in singles)
+            if kw.get("scene", "a") == "a":
+                assert singles[3][0] == 0   # (scene B is a shell around the camera: no empty direction)
+            for v, (R1, color, depth, radii) in enumerate(singles):
+                np.testing.assert_array_equal(radiis[v].cpu().numpy(), radii)
+                np.testing.assert_array_equal(colors[v].cpu().numpy().view(np.uint32), color.view(np.uint32))
+                np.testing.assert_array_equal(depths[v].cpu().numpy().view(np.uint32), depth.view(np.uint32))
+    # the python-level helper and its argument checks
+    from bloomscene_amd import views as V
+    g = dict(means3D=t["means3D"], opacities=t["opac"], colors_precomp=t["colors"], cov3D_precomp=t["cov"])
+    color, depth, radii = V.render_views_batched(cams[:2], g, rs.bg, 0)
+    np.testing.assert_array_equal(color[1].cpu().numpy().view(np.uint32), singles[1][1].view(np.uint32))
+    with pytest.raises(ValueError):
+        V.render_views_batched([], g, rs.bg, 0)

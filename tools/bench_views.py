@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="views per native call (bsr_forward_views; 1 = the reference's one call per view)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,7 +66,7 @@ def main():
     mine = views.shard_views(len(cams), rank, world)
 
     def sweep():
-        return views.render_views_sharded(cams, bufs, bg, deg, rank=rank, world=world)
+        return views.render_views_sharded(cams, bufs, bg, deg, rank=rank, world=world, batch=args.batch)
 
     sweep()   # warm-up (allocator, first-touch)
     from bloomscene_amd import _capi
@@ -72,7 +74,8 @@ def main():
     _capi.profile_reset()
     sweep()
     torch.cuda.synchronize()
-    stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in _capi.profile_read().items()}   # mean per view
+    # mean per view (a batched call covers args.batch views)
+    stage_ms = {k: round(v[0] / max(v[1], 1) / max(args.batch, 1), 4) for k, v in _capi.profile_read().items()}
     _capi.profile_enable(False)
     times = []
     for _ in range(args.repeats):
