@@ -14,6 +14,7 @@ python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null 
 python bench.py --colors precomp --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_c3_precomp_colors.json"
 python bench.py --depth-gradient --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_c3_depth_gradient.json"
 python tools/bench_views.py 2>/dev/null | tail -1 > "$OUT/bench_c4_views_1gpu.json"
+python tools/bench_views.py --batch 16 2>/dev/null | tail -1 > "$OUT/bench_c4_views_1gpu_batch16.json"
 python tools/bench_anchors.py 2>/dev/null | tail -1 > "$OUT/bench_anchors.json"
 python tools/sweep_c5.py 2>/dev/null > "$OUT/sweep_c5.jsonl"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1 )

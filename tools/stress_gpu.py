@@ -101,11 +101,58 @@ def stress_anchors(args, rng):
     print(f"anchor stress ok: {n} random cases")
 
 
+def stress_views(args, rng):
+    """bsr_forward_views against per-view bsr_forward calls: bit-identical colour, depth, radii; summed count."""
+    import math
+    from bloomscene_amd import rasterizer as RZ
+    from bloomscene_amd.views import yawed_camera
+    dev = torch.device("cuda")
+    e = torch.Tensor([])
+    t_end = time.time() + args.seconds
+    n = 0
+    while time.time() < t_end:
+        kw = dict(P=int(rng.choice([1, 255, 256, 257, 3000, 40000, 150000])), W=int(rng.integers(1, 700)),
+                  H=int(rng.integers(1, 400)), deg=int(rng.integers(0, 4)), seed=int(rng.integers(0, 1 << 30)),
+                  scale_mul=float(np.exp(rng.uniform(np.log(0.3), np.log(20.0)))), scene=str(rng.choice(["a", "b"])),
+                  near_fraction=float(rng.choice([0.0, 0.1])))
+        if rng.random() < 0.3:
+            kw["color_mode"] = "precomp"
+        if rng.random() < 0.25:
+            kw["cov_mode"] = "precomp"
+        c = Hh.make_case(**kw)
+        V = int(rng.integers(1, 9))
+        cams = [yawed_camera(c.W, c.H, c.cam.FoVx, yaw_deg=float(rng.uniform(-180, 180))).to(dev) for _ in range(V)]
+        tfx, tfy = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
+        bg = c.bg.to(dev)
+
+        def d(t):
+            return e if t is None else t.to(dev)
+        t = dict(means3D=c.means3D.to(dev), colors=d(c.colors_precomp), opac=c.opacities.to(dev), scales=d(c.scales),
+                 rot=d(c.rotations), cov=d(c.cov3D_precomp), shs=d(c.shs))
+        Rv, colors, depths, radiis = RZ._rasterize_gaussians_views_native(
+            bg, t["means3D"], t["colors"], t["opac"], t["scales"], t["rot"], c.scale_modifier, t["cov"],
+            torch.stack([cm.world_view_transform for cm in cams]), torch.stack([cm.full_proj_transform for cm in cams]),
+            tfx, tfy, c.H, c.W, t["shs"], c.deg, torch.stack([cm.camera_center for cm in cams]), False, False)
+        total = 0
+        for v, cm in enumerate(cams):
+            R1, color, depth, radii, _, _, _ = RZ._rasterize_gaussians_native(
+                bg, t["means3D"], t["colors"], t["opac"], t["scales"], t["rot"], c.scale_modifier, t["cov"],
+                cm.world_view_transform, cm.full_proj_transform, tfx, tfy, c.H, c.W, t["shs"], c.deg, cm.camera_center,
+                False, False)
+            total += R1
+            assert torch.equal(radiis[v], radii), (kw, V, v)
+            assert torch.equal(colors[v].view(torch.int32), color.view(torch.int32)), (kw, V, v)
+            assert torch.equal(depths[v].view(torch.int32), depth.view(torch.int32)), (kw, V, v)
+        assert Rv == total, (kw, V)
+        n += 1
+    print(f"view-batch stress ok: {n} random cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mode", default="mixed", choices=["mixed", "hint", "big", "anchors"],
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "hint", "big", "anchors", "views"],
                     help="mixed: everything random; hint: ONE (P, W, H), random content per call (exercises the "
                          "scratch-size guess: short, long, decaying); big: few large cases (0.1-0.5 M Gaussians)")
     args = ap.parse_args()
@@ -113,6 +160,8 @@ def main():
     rng = np.random.default_rng(args.seed)
     if args.mode == "anchors":
         return stress_anchors(args, rng)
+    if args.mode == "views":
+        return stress_views(args, rng)
     t_end = time.time() + args.seconds
     n = 0
     worst = (0.0, None, None)
