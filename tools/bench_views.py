@@ -114,7 +114,9 @@ def main():
     if rank == 0:
         t = sorted(times)[len(times) // 2]
         print(json.dumps({
-            "workload": f"c4: {P} Gaussians scene B, SH deg {deg}, {W}x{H}, {args.views}-view rotate360 sweep, fwd only",
+            "workload": f"c4: {P} Gaussians scene B, SH deg {deg}, {W}x{H}, {args.views}-view rotate360 sweep, fwd only"
+                        + (f", {args.batch} views per native call (bsr_forward_views)" if args.batch > 1 else ""),
+            "views_per_call": args.batch,
             "n_gpus": world, "views": args.views, "views_rank0": len(mine), "seconds": round(t, 5),
             "ms_per_view": round(t / len(mine) * 1e3, 4), "value": round(args.views * P / t / 1e6, 2),
             "unit": "Msplats/s", "broadcast_ms": round(bcast_ms, 3), "visible_first_view": visible,
