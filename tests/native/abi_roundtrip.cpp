@@ -1,0 +1,149 @@
+// A consumer of the C ABI that knows nothing about torch or python: plain hipMalloc'd buffers, C callbacks for
+// the three scratch buffers, bsr_forward + bsr_backward through include/bloomscene_rast.h.  This is the shape
+// of the binding a maintainer of the reference would write in rasterize_points.cu (option B).
+// tests/test_abi_native_gpu.py feeds it a seeded scene and compares what it writes with the CPU oracle.
+//
+//   abi_roundtrip <inputs.bin> <outputs.bin>
+//
+// inputs.bin : int32 P, D, M, W, H, use_sh; float tan_fovx, tan_fovy, scale_modifier; then float arrays
+//              bg[3] means3D[3P] colour[use_sh ? 3MP : 3P] opacities[P] scales[3P] rotations[4P] view[16] proj[16]
+//              campos[3] dL_dcolor[3HW] dL_ddepth[HW]
+// outputs.bin: int32 num_rendered; float color[3HW] depth[HW]; int32 radii[P]; float dL_dmean3D[3P] dL_dmean2D[3P]
+//              dL_dopacity[P] dL_dcolour[3P] dL_dsh[3MP if use_sh] dL_dscale[3P] dL_drot[4P]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bloomscene_rast.h"
+
+#define HIP_OK(x)                                                                      \
+	do {                                                                               \
+		hipError_t e_ = (x);                                                           \
+		if (e_ != hipSuccess) {                                                        \
+			fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                    \
+			return 2;                                                                  \
+		}                                                                              \
+	} while (0)
+
+struct Scratch {   // what resizeFunctional(torch::Tensor&) is in the reference: a growable device buffer
+	char* ptr = nullptr;
+	size_t cap = 0;
+	int calls = 0;
+};
+static char* grow(void* user, size_t bytes)
+{
+	Scratch* s = static_cast<Scratch*>(user);
+	s->calls++;
+	if (bytes > s->cap) {
+		if (s->ptr) (void)hipFree(s->ptr);
+		if (hipMalloc((void**)&s->ptr, bytes ? bytes : 1) != hipSuccess) return nullptr;
+		s->cap = bytes;
+	}
+	return s->ptr;
+}
+
+template <typename T>
+static bool read_vec(FILE* f, std::vector<T>& v, size_t n)
+{
+	v.resize(n);
+	return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+template <typename T>
+static T* to_device(const std::vector<T>& v)
+{
+	T* d = nullptr;
+	if (hipMalloc((void**)&d, v.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+	if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+	return d;
+}
+template <typename T>
+static T* device_out(size_t n)
+{
+	T* d = nullptr;
+	if (hipMalloc((void**)&d, n * sizeof(T) + 16) != hipSuccess) return nullptr;
+	(void)hipMemset(d, 0xff, n * sizeof(T));   // NaN / -1 patterns: the library must overwrite everything
+	return d;
+}
+template <typename T>
+static bool write_from_device(FILE* f, const T* d, size_t n)
+{
+	std::vector<T> h(n);
+	if (n && hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess) return false;
+	return n == 0 || fwrite(h.data(), sizeof(T), n, f) == n;
+}
+
+int main(int argc, char** argv)
+{
+	if (argc != 3) {
+		fprintf(stderr, "usage: %s inputs.bin outputs.bin\n", argv[0]);
+		return 2;
+	}
+	FILE* fi = fopen(argv[1], "rb");
+	if (!fi) { perror(argv[1]); return 2; }
+	int32_t hdr[6];
+	float fl[3];
+	if (fread(hdr, 4, 6, fi) != 6 || fread(fl, 4, 3, fi) != 3) { fprintf(stderr, "short header\n"); return 2; }
+	const int P = hdr[0], D = hdr[1], M = hdr[2], W = hdr[3], H = hdr[4], use_sh = hdr[5];
+	const size_t N = (size_t)W * H;
+	std::vector<float> bg, means, colour, opac, scales, rots, view, proj, campos, gC, gD;
+	bool ok = read_vec(fi, bg, 3) && read_vec(fi, means, (size_t)3 * P) &&
+	          read_vec(fi, colour, use_sh ? (size_t)3 * M * P : (size_t)3 * P) && read_vec(fi, opac, (size_t)P) &&
+	          read_vec(fi, scales, (size_t)3 * P) && read_vec(fi, rots, (size_t)4 * P) && read_vec(fi, view, 16) &&
+	          read_vec(fi, proj, 16) && read_vec(fi, campos, 3) && read_vec(fi, gC, 3 * N) && read_vec(fi, gD, N);
+	fclose(fi);
+	if (!ok) { fprintf(stderr, "short input file\n"); return 2; }
+	if (bsr_version() != BSR_VERSION) { fprintf(stderr, "header / library version mismatch\n"); return 2; }
+
+	hipStream_t stream;
+	HIP_OK(hipStreamCreate(&stream));   // deliberately not the null stream
+	float *d_bg = to_device(bg), *d_means = to_device(means), *d_col = to_device(colour), *d_op = to_device(opac),
+	      *d_sc = to_device(scales), *d_rot = to_device(rots), *d_view = to_device(view), *d_proj = to_device(proj),
+	      *d_cam = to_device(campos), *d_gC = to_device(gC), *d_gD = to_device(gD);
+	float* out_color = device_out<float>(3 * N);
+	float* out_depth = device_out<float>(N);
+	int* radii = device_out<int>((size_t)P);
+	if (!d_bg || !d_means || !d_col || !d_op || !d_sc || !d_rot || !d_view || !d_proj || !d_cam || !d_gC || !d_gD ||
+	    !out_color || !out_depth || !radii) {
+		fprintf(stderr, "device allocation failed\n");
+		return 2;
+	}
+	Scratch geom, binning, img;
+	int num_rendered = -1;
+	int rc = bsr_forward(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
+	                     use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view,
+	                     d_proj, d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &num_rendered);
+	if (rc != 0) { fprintf(stderr, "bsr_forward: %s\n", bsr_last_error()); return 1; }
+
+	float* g_mean2D = device_out<float>((size_t)3 * P);
+	float* g_conic = device_out<float>((size_t)4 * P);
+	float* g_opac = device_out<float>((size_t)P);
+	float* g_col = device_out<float>((size_t)3 * P);
+	float* g_mean3D = device_out<float>((size_t)3 * P);
+	float* g_cov3D = device_out<float>((size_t)6 * P);
+	float* g_sh = device_out<float>(use_sh ? (size_t)3 * M * P : 1);
+	float* g_scale = device_out<float>((size_t)3 * P);
+	float* g_rot = device_out<float>((size_t)4 * P);
+	rc = bsr_backward(P, D, use_sh ? M : 0, num_rendered, d_bg, W, H, d_means, use_sh ? d_col : nullptr,
+	                  use_sh ? nullptr : d_col, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, d_cam, fl[0], fl[1], radii,
+	                  geom.ptr, binning.ptr, img.ptr, d_gC, d_gD, g_mean2D, g_conic, g_opac, g_col, g_mean3D, g_cov3D,
+	                  use_sh ? g_sh : nullptr, g_scale, g_rot, 0, stream);
+	if (rc != 0) { fprintf(stderr, "bsr_backward: %s\n", bsr_last_error()); return 1; }
+	HIP_OK(hipStreamSynchronize(stream));
+
+	FILE* fo = fopen(argv[2], "wb");
+	if (!fo) { perror(argv[2]); return 2; }
+	int32_t nr = num_rendered;
+	ok = fwrite(&nr, 4, 1, fo) == 1 && write_from_device(fo, out_color, 3 * N) && write_from_device(fo, out_depth, N) &&
+	     write_from_device(fo, radii, (size_t)P) && write_from_device(fo, g_mean3D, (size_t)3 * P) &&
+	     write_from_device(fo, g_mean2D, (size_t)3 * P) && write_from_device(fo, g_opac, (size_t)P) &&
+	     write_from_device(fo, g_col, (size_t)3 * P) && write_from_device(fo, g_sh, use_sh ? (size_t)3 * M * P : 0) &&
+	     write_from_device(fo, g_scale, (size_t)3 * P) && write_from_device(fo, g_rot, (size_t)4 * P);
+	fclose(fo);
+	if (!ok) { fprintf(stderr, "writing outputs failed\n"); return 2; }
+	printf("abi_roundtrip ok: P=%d num_rendered=%d scratch callbacks geom/binning/image = %d/%d/%d\n", P, num_rendered,
+	       geom.calls, binning.calls, img.calls);
+	return 0;
+}
