@@ -605,3 +605,15 @@ def test_view_batched_forward_equals_per_view_calls():
     np.testing.assert_array_equal(color[1].cpu().numpy().view(np.uint32), singles[1][1].view(np.uint32))
     with pytest.raises(ValueError):
         V.render_views_batched([], g, rs.bg, 0)
+    # one view through the batched entry point == the plain call; no Gaussians: zero images; too many views: error
+    color1, depth1, radii1 = V.render_views_batched(cams[2:3], g, rs.bg, 0)
+    np.testing.assert_array_equal(color1[0].cpu().numpy().view(np.uint32), singles[2][1].view(np.uint32))
+    np.testing.assert_array_equal(radii1[0].cpu().numpy(), singles[2][3])
+    g0 = dict(means3D=t["means3D"][:0], opacities=t["opac"][:0], colors_precomp=t["colors"][:0],
+              cov3D_precomp=t["cov"][:0])
+    color0, depth0, radii0 = V.render_views_batched(cams[:3], g0, rs.bg, 0)
+    assert tuple(color0.shape) == (3, 3, c.H, c.W) and not color0.any() and not depth0.any() and radii0.shape == (3, 0)
+    from bloomscene_amd.views import yawed_camera as _yc
+    many = [_yc(16, 16 * 70, 1.0).to(dev)] * 1000   # 70 tile rows x 1000 views > 65535 stacked tile rows
+    with pytest.raises(RuntimeError, match="too many views"):
+        V.render_views_batched(many, g, rs.bg, 0)
