@@ -83,10 +83,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		if (!wave_done) {
 			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
 			// candidate) is one ballot; the slow path is fully predicated -- no per-lane branches.
-			const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+			int n_lim = __builtin_amdgcn_readfirstlane(n_mine);   // set to 0 to leave (single loop exit)
 			const uint32_t base16 = (uint32_t)(base + 1) << 4;
-			for (int i = 0; i < n_u; i++) {
-				const unsigned int joff = st.list[wave][i];
+			auto visit = [&](const unsigned int joff) {
 				const char* rec = stage_rec(st, joff);
 				const float4 q0 = rec_q0<BSR_BLOCK>(rec);      // x, y, conic a, conic b
 				const float2 ct = rec_q1lo<BSR_BLOCK>(rec);    // conic c, power cut
@@ -95,7 +94,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !(power > 0.0f) && !(power < ct.y);
-				if (wave_ballot(cand) == 0ull) continue;
+				if (wave_ballot(cand) == 0ull) return;
 				const float2 od = rec_q1hi<BSR_BLOCK>(rec);    // opacity, depth
 				const float4 q2 = rec_q2<BSR_BLOCK>(rec);
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
@@ -120,8 +119,16 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				if (wave_ballot(stop) != 0ull) {   // rare
 					pixfx = stop ? 1.0e15f : pixfx;
 					done = done || stop;
-					if (wave_ballot(!done) == 0ull) i = n_u;   // every pixel of the quadrant is done: leave (single loop exit)
+					if (wave_ballot(!done) == 0ull) n_lim = 0;   // every pixel of the quadrant is done: leave
 				}
+			};
+			// four list entries per trip: one address computation and the four 16-bit list reads up front
+			for (int i = 0; i < n_lim; i += 4) {
+				const uint4 l = *reinterpret_cast<const uint4*>(&st.list[wave][i]);   // (reads past the end stay inside st.list)
+				visit(l.x);
+				if (i + 1 < n_lim) visit(l.y);
+				if (i + 2 < n_lim) visit(l.z);
+				if (i + 3 < n_lim) visit(l.w);
 			}
 		}
 	}

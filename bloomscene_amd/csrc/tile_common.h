@@ -47,7 +47,8 @@ struct TileStageT {
 	float4 q0[BATCH];                // x, y, conic a, conic b
 	float4 q1[BATCH];                // conic c, power cut, opacity, depth
 	float4 q2[BATCH];                // r, g, b, -
-	unsigned short list[4][BATCH];   // per quadrant: BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
+	unsigned int list[4][BATCH];     // per quadrant: BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
+	                                 // (32-bit: the walks fetch four entries with one 16-byte read, no unpacking)
 	unsigned int cnt[4][4];          // [staging wave][quadrant]
 };
 using TileStage = TileStageT<BSR_BLOCK>;
@@ -89,7 +90,7 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 		if (h[q]) {
 			const unsigned int off = (wave > 0 ? st.cnt[0][q] : 0u) + (wave > 1 ? st.cnt[1][q] : 0u) +
 			                         (wave > 2 ? st.cnt[2][q] : 0u);
-			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned short)(tid << 4);
+			st.list[q][off + (unsigned int)__popcll(m[q] & lt)] = (unsigned int)(tid << 4);
 		}
 	}
 	const int total = (int)(st.cnt[0][wave] + st.cnt[1][wave] + st.cnt[2][wave] + st.cnt[3][wave]);
