@@ -252,8 +252,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
 		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
 		const int joff_min = (top - (int)last_contributor) * 16;
-		for (int i = 0; i < n_u; i++) {
-			const unsigned int joff = sh.st.list[wave][i];
+		auto visit = [&](const unsigned int joff) {
 			const char* rec = stage_rec(sh.st, joff);
 			const float4 q0 = rec_q0<BSR_BWD_BATCH>(rec);
 			const float4 q1 = rec_q1<BSR_BWD_BATCH>(rec);   // conic c, power cut, opacity, depth
@@ -261,7 +260,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float dy = q0.y - pixfy;
 			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
 			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
-			if (wave_ballot(cand) == 0ull) continue;   // wave-uniform
+			if (wave_ballot(cand) == 0ull) return;   // wave-uniform
 
 			// slow path: fully predicated
 			const float4 q2 = rec_q2<BSR_BWD_BATCH>(rec);
@@ -272,7 +271,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// nine contributions exactly 0 (G itself may be anything finite there).
 			const float alpha_c = cand ? fminf(0.99f, q1.z * G) : 0.f;
 			const bool active = !(alpha_c < 1.0f / 255.0f);
-			if (wave_ballot(active) == 0ull) continue;
+			if (wave_ballot(active) == 0ull) return;
 			const float alpha = active ? alpha_c : 0.f;
 			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
 			{
@@ -317,6 +316,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			}
 			const float tot = wave_sums_masked<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
 			if (stores) *reinterpret_cast<float*>(reinterpret_cast<char*>(part_mine) + (joff >> 2)) = tot;   // part_mine[j]
+		};
+		// four list entries per trip: one address computation and one 16-byte LDS read for the list
+		for (int i = 0; i < n_u; i += 4) {
+			const uint4 l = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i]);   // (reads past the end stay inside the list)
+			visit(l.x);
+			if (i + 1 < n_u) visit(l.y);
+			if (i + 2 < n_u) visit(l.z);
+			if (i + 3 < n_u) visit(l.w);
 		}
 		__syncthreads();
 		if (valid) {
