@@ -628,8 +628,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
 	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("scratch buffer is null");
 	if (!dL_dpix || !background) return fail("dL_dpix/background is null");
-	if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
-		return fail("gradient output is null");
+	if (!dL_dmean2D || !dL_dopacity || !dL_dmean3D) return fail("gradient output is null");
+	// intermediate results may be declined (NULL) -- unless they are the gradient of an input that was given
+	if (!shs && !dL_dcolor) return fail("dL_dcolor is null but colors_precomp is the colour input");
+	if (!scales && !dL_dcov3D) return fail("dL_dcov3D is null but cov3D_precomp is the covariance input");
 	if (shs && (M <= 0 || !dL_dsh || !campos)) return fail("SH backward needs M > 0, dL_dsh and campos");
 	if (scales && (!dL_dscale || !dL_drot)) return fail("dL_dscale/dL_drot is null");
 

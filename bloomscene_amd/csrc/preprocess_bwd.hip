@@ -187,11 +187,15 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		a.dL_dmean2D[3 * idx] = g[0];
 		a.dL_dmean2D[3 * idx + 1] = g[1];
 		a.dL_dmean2D[3 * idx + 2] = 0.f;
-		reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g[2], g[3], 0.f, g[4]);
+		// dL_dconic, dL_dcolor and dL_dcov3D are intermediate results whenever SH / scale+rotation inputs are
+		// used: a caller that does not want them passes NULL and saves their HBM writes (52 B per Gaussian)
+		if (a.dL_dconic) reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(g[2], g[3], 0.f, g[4]);
 		a.dL_dopacity[idx] = g[5];
-		a.dL_dcolor[3 * idx] = g[6];
-		a.dL_dcolor[3 * idx + 1] = g[7];
-		a.dL_dcolor[3 * idx + 2] = g[8];
+		if (a.dL_dcolor) {
+			a.dL_dcolor[3 * idx] = g[6];
+			a.dL_dcolor[3 * idx + 1] = g[7];
+			a.dL_dcolor[3 * idx + 2] = g[8];
+		}
 	}
 
 	float dmean[3] = {0.f, 0.f, 0.f};
@@ -365,8 +369,10 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	a.dL_dmean3D[3 * idx] = dmean[0];
 	a.dL_dmean3D[3 * idx + 1] = dmean[1];
 	a.dL_dmean3D[3 * idx + 2] = dmean[2];
+	if (a.dL_dcov3D) {
 #pragma unroll
-	for (int k = 0; k < 6; k++) a.dL_dcov3D[(size_t)idx * 6 + k] = dcov[k];
+		for (int k = 0; k < 6; k++) a.dL_dcov3D[(size_t)idx * 6 + k] = dcov[k];
+	}
 	if (a.scales) {
 		a.dL_dscale[3 * idx] = dscale[0];
 		a.dL_dscale[3 * idx + 1] = dscale[1];

@@ -160,9 +160,12 @@ def _rasterize_gaussians_views_native(bg, means3D, colors, opacity, scales, rota
 def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rotations, scale_modifier,
                                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                          dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                         imageBuffer, debug, out_depth=None):
+                                         imageBuffer, debug, out_depth=None, all_outputs=False):
     """Counterpart of `_C.rasterize_gaussians_backward` = RasterizeGaussiansBackwardCUDA (RP:119-200).
-    ``out_depth`` (the forward's depth image) selects the depth-gradient extension bsr_backward_depth."""
+    ``out_depth`` (the forward's depth image) selects the depth-gradient extension bsr_backward_depth.
+    The reference also materialises dL_dconic, and dL_dcolors / dL_dcov3D even when SH / scale+rotation inputs make
+    them intermediate results nobody reads (RP:154-162); here those are declined (None is returned in their place)
+    unless ``all_outputs`` asks for the reference's full set."""
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -171,10 +174,12 @@ def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rot
     # every output is fully written by bsr_backward (rows of culled Gaussians = 0): no zero-fill pass
     dL_dmeans3D = torch.empty((P, 3), **o)
     dL_dmeans2D = torch.empty((P, 3), **o)
-    dL_dcolors = torch.empty((P, 3), **o)
-    dL_dconic = torch.empty((P, 2, 2), **o)
+    has_colors = colors is not None and colors.numel() != 0
+    has_cov = cov3D_precomp is not None and cov3D_precomp.numel() != 0
+    dL_dcolors = torch.empty((P, 3), **o) if (all_outputs or has_colors) else None
+    dL_dconic = torch.empty((P, 2, 2), **o) if all_outputs else None
     dL_dopacity = torch.empty((P, 1), **o)
-    dL_dcov3D = torch.empty((P, 6), **o)
+    dL_dcov3D = torch.empty((P, 6), **o) if (all_outputs or has_cov) else None
     dL_dsh = torch.empty((P, M, 3), **o)
     has_sr = scales is not None and scales.numel() != 0
     dL_dscales = torch.empty((P, 3), **o) if has_sr else torch.zeros((P, 3), **o)
@@ -193,8 +198,8 @@ def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rot
                 radii_c.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr() if binningBuffer.numel() else None,
                 imageBuffer.data_ptr())
         tail = (_ptr(t["gcol"]), _ptr(t["gdep"]), dL_dmeans2D.data_ptr(),
-                dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(),
-                dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
+                _ptr(dL_dconic), dL_dopacity.data_ptr(), _ptr(dL_dcolors), dL_dmeans3D.data_ptr(),
+                _ptr(dL_dcov3D), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
                 dL_drotations.data_ptr(), int(bool(debug)), _stream_handle(dev))
         with torch.cuda.device(dev):
             if out_depth is None:
@@ -357,7 +362,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # Absent optional inputs were empty tensors: their gradient must have the input's (empty)
         # shape for autograd's shape check; the reference relies on older, laxer torch here.
         def _fit(g, inp):
-            return g if inp.numel() != 0 else None
+            return g if (inp.numel() != 0 and g is not None) else None
 
         grads = (
             grad_means3D,

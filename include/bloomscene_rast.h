@@ -173,7 +173,9 @@ int bsr_visible_filter_views(int P, int n_views,
  * needed): dL_dmean2D[P,3], dL_dconic[P,2,2] (internal, but part of the reference signature),
  * dL_dopacity[P,1], dL_dcolor[P,3], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3],
  * dL_dscale[P,3], dL_drot[P,4]; rows of culled Gaussians are zero.  dL_dsh may be NULL when
- * M == 0; dL_dscale/dL_drot are written only when scales != NULL.
+ * M == 0; dL_dscale/dL_drot are written only when scales != NULL.  dL_dconic may be NULL, and so may
+ * dL_dcolor when shs != NULL and dL_dcov3D when scales != NULL: they are then intermediate results the
+ * reference materialises (rasterize_points.cu:154-162) but nobody reads, and are simply not written.
  * Replaces CudaRasterizer::Rasterizer::backward, cuda_rasterizer/rasterizer.h:75-105
  * (= rasterizer_impl.cu:403-504); bound by `_C.rasterize_gaussians_backward`, ext.cpp:17 /
  * rasterize_points.cu:119-200. */

@@ -617,3 +617,41 @@ def test_view_batched_forward_equals_per_view_calls():
     many = [_yc(16, 16 * 70, 1.0).to(dev)] * 1000   # 70 tile rows x 1000 views > 65535 stacked tile rows
     with pytest.raises(RuntimeError, match="too many views"):
         V.render_views_batched(many, g, rs.bg, 0)
+
+
+def test_declined_intermediate_gradients_change_nothing_else():
+    """dL_dconic, and dL_dcolor / dL_dcov3D when SH / scale+rotation are the inputs, are intermediate results: the
+    python host passes NULL for them (the reference materialises them, RP:154-162).  Everything else must be bit-equal
+    with and without them; a NULL for the gradient of an input that WAS given is an error."""
+    from bloomscene_amd import rasterizer as RZ
+    for name in ("sh3", "precomp_color", "precomp_cov"):
+        c = Hh.make_case(**CASES[name])
+        rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+        dev = _dev()
+        args = (rs.bg, t["means3D"], radii, t["colors"], t["scales"], t["rot"], rs.scale_modifier, t["cov"], rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, c.gC.to(dev), c.gD.to(dev), t["shs"], c.deg, rs.campos, gb, R, bb, ib,
+                False)
+        full = RZ._rasterize_gaussians_backward_native(*args, all_outputs=True)
+        lean = RZ._rasterize_gaussians_backward_native(*args)
+        torch.cuda.synchronize()
+        assert all(g is not None for g in full)
+        # (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+        assert (lean[1] is None) == (c.colors_precomp is None) and (lean[4] is None) == (c.cov3D_precomp is None)
+        for a, b in zip(full, lean):
+            if b is not None:
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    lib = RZ._capi.lib()
+    c = Hh.make_case(**CASES["precomp_color"])
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+    P = c.P
+    o = dict(device=_dev(), dtype=torch.float32)
+    g3, g1, g6, g4 = (torch.empty((P, 3), **o) for _ in range(4)), torch.empty((P, 1), **o), torch.empty((P, 6), **o), \
+        torch.empty((P, 4), **o)
+    g3 = list(g3)
+    rc = lib.bsr_backward(P, c.deg, 0, R, rs.bg.data_ptr(), c.W, c.H, t["means3D"].data_ptr(), None, t["colors"].data_ptr(),
+                          t["scales"].data_ptr(), float(rs.scale_modifier), t["rot"].data_ptr(), None,
+                          rs.viewmatrix.data_ptr(), rs.projmatrix.data_ptr(), rs.campos.data_ptr(), float(rs.tanfovx),
+                          float(rs.tanfovy), radii.data_ptr(), gb.data_ptr(), bb.data_ptr(), ib.data_ptr(),
+                          c.gC.to(_dev()).data_ptr(), None, g3[0].data_ptr(), None, g1.data_ptr(), None, g3[1].data_ptr(),
+                          None, None, g3[2].data_ptr(), g4.data_ptr(), 0, None)
+    assert rc != 0 and b"dL_dcolor is null" in lib.bsr_last_error()
