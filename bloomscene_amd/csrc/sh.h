@@ -66,6 +66,63 @@ __device__ __forceinline__ void sh_eval(const float* c, float x, float y, float 
 	}
 }
 
+// Degree 3 with M = 16 (the C3 shape), streamed: the 48 floats of a Gaussian come in as three groups of four
+// 16-byte loads and every group is consumed before the next one is requested, so 16 instead of 48 coefficient
+// registers are live (k_preprocess: 92 -> occupancy 5; this path aims at fewer).  The sums run in exactly the
+// order of sh_eval<3> (term k of channel ch is added k-th): bit-identical results.
+__device__ __forceinline__ float sh3_basis(int k, float x, float y, float z, float xx, float yy, float zz, float xy,
+                                           float yz, float xz)
+{
+	switch (k) {
+	case 0: return SH_C0;
+	case 1: return SH_C1 * y;
+	case 2: return SH_C1 * z;
+	case 3: return SH_C1 * x;
+	case 4: return SH_C2[0] * xy;
+	case 5: return SH_C2[1] * yz;
+	case 6: return SH_C2[2] * (2.0f * zz - xx - yy);
+	case 7: return SH_C2[3] * xz;
+	case 8: return SH_C2[4] * (xx - yy);
+	case 9: return SH_C3[0] * y * (3.0f * xx - yy);
+	case 10: return SH_C3[1] * xy * z;
+	case 11: return SH_C3[2] * y * (4.0f * zz - xx - yy);
+	case 12: return SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+	case 13: return SH_C3[4] * x * (4.0f * zz - xx - yy);
+	case 14: return SH_C3[5] * z * (xx - yy);
+	default: return SH_C3[6] * x * (xx - 3.0f * yy);
+	}
+}
+
+__device__ __forceinline__ void sh_eval3_stream(const float* __restrict__ sh, float x, float y, float z, float* res)
+{
+	const float xx = x * x, yy = y * y, zz = z * z;
+	const float xy = x * y, yz = y * z, xz = x * z;
+	const float4* s4 = reinterpret_cast<const float4*>(sh);
+	float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+	for (int g = 0; g < 3; g++) {
+		// the next group's address is made to depend on this point of the sums, or the compiler hoists all twelve
+		// loads to the top again
+		if (g > 0) asm volatile("" : "+v"(s4), "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
+		float v[16];
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const float4 q = s4[4 * g + i];
+			v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+		}
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const int p = 16 * g + j, k = p / 3, ch = p % 3;
+			const float b = sh3_basis(k, x, y, z, xx, yy, zz, xy, yz, xz);
+			if (k == 0) r[ch] = b * v[j];
+			else if (k == 1 || k == 3) r[ch] = r[ch] - b * v[j];
+			else r[ch] = r[ch] + b * v[j];
+		}
+	}
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) res[ch] = r[ch] + 0.5f;
+}
+
 // forward: rgb = max(0, 0.5 + sum basis*coef); clamp_bits bit ch set where the raw value was < 0
 __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float3 pos, const float* __restrict__ campos,
                                           const float* __restrict__ sh, float* rgb, uint8_t& clamp_bits)
@@ -91,6 +148,23 @@ __device__ __forceinline__ void sh_to_rgb(int deg, int M, const float3 pos, cons
 		load_sh<16>(sh, M, c);
 		sh_eval<3>(c, dx, dy, dz, raw);
 	}
+	clamp_bits = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ch++) {
+		if (raw[ch] < 0) clamp_bits |= (uint8_t)(1u << ch);
+		rgb[ch] = fmaxf(raw[ch], 0.0f);
+	}
+}
+
+// forward colour for the one shape the streamed evaluation serves: active degree 3, M = 16
+__device__ __forceinline__ void sh3_to_rgb_stream(const float3 pos, const float* __restrict__ campos,
+                                                  const float* __restrict__ sh, float* rgb, uint8_t& clamp_bits)
+{
+	float dx = pos.x - campos[0], dy = pos.y - campos[1], dz = pos.z - campos[2];
+	const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+	dx = dx / len; dy = dy / len; dz = dz / len;
+	float raw[3];
+	sh_eval3_stream(sh, dx, dy, dz, raw);
 	clamp_bits = 0;
 #pragma unroll
 	for (int ch = 0; ch < 3; ch++) {
