@@ -93,8 +93,10 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
 }
 
 
-// SH3: the kernel only serves SH colours of active degree 3 with M = 16 (streamed evaluation, sh.h)
-template <bool FILTER_ONLY, bool SH3 = false>
+// COLOR: 0 = any SH shape or precomputed colours; 1 = only SH of active degree 3 with M = 16 (streamed evaluation,
+// sh.h); 2 = only precomputed colours (BloomScene's call shape).  The specialised instantiations exist for their
+// register count: the generic kernel carries the 48-coefficient path (92 VGPRs, 5 waves per SIMD), they run at 8.
+template <bool FILTER_ONLY, int COLOR = 0>
 __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -171,9 +173,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 					for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)id * 6 + k] = cov3D[k];
 					float rgb[3];
 					uint8_t clamp_bits = 0;
-					if (SH3) {
+					if (COLOR == 1) {
 						sh3_to_rgb_stream(p, a.cam_pos + 3 * view, a.shs + (size_t)idx * 48, rgb, clamp_bits);
-					} else if (a.colors_precomp == nullptr) {
+					} else if (COLOR == 0 && a.colors_precomp == nullptr) {
 						sh_to_rgb(a.D, a.M, p, a.cam_pos + 3 * view, a.shs + (size_t)idx * a.M * 3, rgb, clamp_bits);
 					} else {
 						rgb[0] = a.colors_precomp[3 * idx];
@@ -378,11 +380,13 @@ void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s)
 {
 	const int blocks = (a.P + 255) / 256;
 	if (filter_only)
-		hipLaunchKernelGGL((k_preprocess<true, false>), dim3(blocks), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_preprocess<true, 0>), dim3(blocks), dim3(256), 0, s, a);
 	else if (a.colors_precomp == nullptr && a.D == 3 && a.M == 16)
-		hipLaunchKernelGGL((k_preprocess<false, true>), dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_preprocess<false, 1>), dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
+	else if (a.colors_precomp != nullptr)
+		hipLaunchKernelGGL((k_preprocess<false, 2>), dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
 	else
-		hipLaunchKernelGGL((k_preprocess<false, false>), dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_preprocess<false, 0>), dim3(blocks, a.n_views > 1 ? a.n_views : 1), dim3(256), 0, s, a);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s)
