@@ -155,13 +155,15 @@ __device__ __forceinline__ void sh_bwd_coop(const BwdArgs& a, int idx, bool visi
 	}
 }
 
-// ROW_F4 = 0: per-thread SH access (any M); 3 / 12: wave-cooperative LDS-transposed access (M = 4 / 16)
+// ROW_F4 = 0: per-thread SH access (any M); 3 / 12: wave-cooperative LDS-transposed access (M = 4 / 16);
+// -1: no SH at all (precomputed colours, BloomScene's call shape): without the SH code the kernel needs 40 % fewer
+// registers and nothing spills
 template <int ROW_F4>
 __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(const BwdArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const bool in_range = idx < a.P;
-	if (ROW_F4 == 0 && !in_range) return;   // the cooperative variants keep whole waves alive
+	if (ROW_F4 <= 0 && !in_range) return;   // the cooperative variants keep whole waves alive
 	const ushort4 rc = in_range ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
 	const bool visible = in_range && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
 
@@ -345,16 +347,16 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		zero_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M);
 	}
 
-	if (ROW_F4 != 0) {
+	if (ROW_F4 > 0) {
 		// SH part for the whole wave at once (the reference adds it to dL_dmean after the projection
 		// part, backward.cu:387-391; the cov3D part above does not touch dL_dmean, so the order holds)
-		__shared__ ShTile<(ROW_F4 ? ROW_F4 : 1)> s_tile[4];
+		__shared__ ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)> s_tile[4];
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int g0 = blockIdx.x * 256 + wave * 64;
 		const int n_valid = min(64, max(0, a.P - g0));
-		ShTile<(ROW_F4 ? ROW_F4 : 1)>& tile = s_tile[wave];
-		if (a.D <= 0) sh_bwd_coop<0, (ROW_F4 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
-		else if (a.D == 1) sh_bwd_coop<1, (ROW_F4 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>& tile = s_tile[wave];
+		if (a.D <= 0) sh_bwd_coop<0, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		else if (a.D == 1) sh_bwd_coop<1, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
 		else if (ROW_F4 < 12) { /* degree > 1 needs M >= 9: not reachable with M = 4 (checked by the host) */ }
 		else if (a.D == 2) sh_bwd_coop<2, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
 		else sh_bwd_coop<3, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
@@ -388,6 +390,8 @@ void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s)
 		hipLaunchKernelGGL(k_preprocess_bwd<12>, grid, block, 0, s, a);
 	else if (a.shs && a.M == 4)
 		hipLaunchKernelGGL(k_preprocess_bwd<3>, grid, block, 0, s, a);
+	else if (!a.shs)
+		hipLaunchKernelGGL(k_preprocess_bwd<-1>, grid, block, 0, s, a);
 	else
 		hipLaunchKernelGGL(k_preprocess_bwd<0>, grid, block, 0, s, a);
 }
