@@ -655,3 +655,35 @@ def test_declined_intermediate_gradients_change_nothing_else():
                           c.gC.to(_dev()).data_ptr(), None, g3[0].data_ptr(), None, g1.data_ptr(), None, g3[1].data_ptr(),
                           None, None, g3[2].data_ptr(), g4.data_ptr(), 0, None)
     assert rc != 0 and b"dL_dcolor is null" in lib.bsr_last_error()
+
+
+def test_two_host_threads_on_their_own_streams():
+    """Two python threads, each on its own torch stream, run forward + backward of different scenes at the same time:
+    the per-thread read-back state (pinned buffer, event, size hint) and the stream-ordered backward scratch must
+    not interfere.  Every result must equal the single-threaded one bit for bit."""
+    import threading
+    dev = _dev()
+    cases = [Hh.make_case(**CASES["sh3"]), Hh.make_case(**CASES["free_camera_sh3"])]
+    ref = [Hh.run_hip(c) for c in cases]
+    errors = []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(12):
+                    o = Hh.run_hip(cases[i])
+                    s.synchronize()
+                    assert np.array_equal(o.color.view(np.uint32), ref[i].color.view(np.uint32))
+                    assert np.array_equal(o.depth.view(np.uint32), ref[i].depth.view(np.uint32))
+                    for k in ("means3D", "shs", "scales", "rotations", "opacities"):
+                        assert np.array_equal(getattr(o.grads, k), getattr(ref[i].grads, k)), k
+        except Exception as ex:   # noqa: BLE001  (reported by the main thread)
+            errors.append((i, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
