@@ -181,8 +181,19 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 	}
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int n_wg = (int)gridDim.x, per = (n_wg + 7) >> 3, n_col = 8 * per;
+	const int idx = blockIdx.x * 256 + tid;
+	// Everything this thread needs from global memory is requested up front: the kernel is a chain of dependent
+	// round trips otherwise (totals -> barrier -> column -> barrier -> rect -> mask / depth), and loads do not move
+	// across barriers on their own.  Rows of culled Gaussians hold an empty rect; their mask / depth are never
+	// written, whatever is read there is not used.
+	const bool in_range = idx < P;
+	const int ld = in_range ? idx : 0;
+	const uint32_t v = hist1[(size_t)BSR_RADIX_BINS * n_col + tid];
+	const uint32_t col = hist1[(size_t)tid * n_col + hist1_column((int)blockIdx.x, per)];
+	const ushort4 r = rect[ld];
+	const uint64_t mask = kept_mask[ld];
+	const uint32_t depth_bits = __float_as_uint(depth[ld]);
 	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this workgroup's prefix
-		const uint32_t v = hist1[(size_t)BSR_RADIX_BINS * n_col + tid];
 		uint32_t incl = v;
 #pragma unroll
 		for (int d = 1; d < 64; d <<= 1) {
@@ -192,17 +203,13 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 		if (lane == 63) s_scan[wave] = incl;
 		__syncthreads();
 		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
-		s_off[tid] = base + hist1[(size_t)tid * n_col + hist1_column((int)blockIdx.x, per)];
+		s_off[tid] = base + col;
 	}
 	__syncthreads();
-	const int idx = blockIdx.x * 256 + tid;
-	if (idx >= P) return;
-	const ushort4 r = rect[idx];
+	if (!in_range) return;
 	if (r.z <= r.x || r.w <= r.y) return;
 	const uint32_t area = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
-	const uint64_t mask = kept_mask[idx];
 	if (kept_count(area, mask) == 0) return;
-	const uint32_t depth_bits = __float_as_uint(depth[idx]);
 	uint32_t k = 0;
 	for (int y = r.y; y < r.w; y++)
 		for (int x = r.x; x < r.z; x++, k++) {
