@@ -234,7 +234,14 @@ __global__ void __launch_bounds__(256) k_radix_hist(const int* __restrict__ n_pt
 	s_hist[tid] = 0;
 	__syncthreads();
 	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
-	for (int i = beg + tid; i < end; i += 256) atomicAdd(&s_hist[(elems[i].x >> shift) & (BSR_RADIX_BINS - 1)], 1u);
+	for (int i = beg + tid; i < end; i += 1024) {   // four loads in flight per trip (the kernel is load latency)
+		uint32_t t[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) t[k] = (i + 256 * k < end) ? elems[i + 256 * k].x : 0u;
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			if (i + 256 * k < end) atomicAdd(&s_hist[(t[k] >> shift) & (BSR_RADIX_BINS - 1)], 1u);
+	}
 	__syncthreads();
 	hist[(size_t)tid * n_blocks + blockIdx.x] = s_hist[tid];
 }
@@ -253,6 +260,12 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 	if ((int)blockIdx.x >= part.n_blocks) return;
 	const int n = part.n, chunk = part.chunk, n_blocks = part.n_blocks;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
+	// requested before the first barrier (loads do not move across barriers on their own): this block's row of
+	// prefixes and the first round's element; inside the loop the next round's element is always in flight
+	const uint32_t row_prefix = hist[(size_t)tid * n_blocks + blockIdx.x];
+	BinElem e_next = BinElem{0u, 0u, 0u};
+	if (beg + tid < end) e_next = load_elem(elems_in + beg + tid);
 	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this block's row prefix
 		const uint32_t v = digit_total[tid];
 		uint32_t incl = v;
@@ -264,19 +277,18 @@ __global__ void __launch_bounds__(256) k_radix_scatter(const int* __restrict__ n
 		if (lane == 63) s_scan[wave] = incl;
 		__syncthreads();
 		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
-		s_off[tid] = base + hist[(size_t)tid * n_blocks + blockIdx.x];
+		s_off[tid] = base + row_prefix;
 	}
 #pragma unroll
 	for (int w = 0; w < 4; w++) s_wcnt[w][tid] = 0;
 	__syncthreads();
-	const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	uint32_t round = 1;
 	for (int base = beg; base < end; base += 256, round++) {
 		const int i = base + tid;
 		const bool valid = i < end;
-		BinElem e = BinElem{0u, 0u, 0u};
-		if (valid) e = load_elem(elems_in + i);
+		const BinElem e = e_next;
+		if (i + 256 < end) e_next = load_elem(elems_in + i + 256);
 		const uint32_t d = (e.x >> shift) & (BSR_RADIX_BINS - 1);
 		// lanes of this wave with the same digit (invalid lanes match nobody)
 		unsigned long long peers = __ballot(valid);
