@@ -243,3 +243,21 @@ def test_scratch_buffers_die_without_the_cycle_collector():
     finally:
         if was:
             gc.enable()
+
+
+def test_render_views_batched_argument_checks_need_no_gpu():
+    """The batched sweep validates its cameras and colour inputs before it touches the device."""
+    from bloomscene_amd.views import render_views_batched, yawed_camera
+    g = dict(means3D=torch.zeros(4, 3), opacities=torch.ones(4, 1), colors_precomp=torch.zeros(4, 3),
+             scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    bg = torch.zeros(3)
+    with pytest.raises(ValueError, match="at least one camera"):
+        render_views_batched([], g, bg, 0)
+    a, b = yawed_camera(64, 48, 1.0, 0.0), yawed_camera(80, 48, 1.0, 5.0)
+    with pytest.raises(ValueError, match="one image size and field of view"):
+        render_views_batched([a, b], g, bg, 0)
+    both = dict(g, shs=torch.zeros(4, 1, 3))
+    with pytest.raises(Exception, match="exactly one|excatly one"):
+        render_views_batched([a], both, bg, 0)
+    with pytest.raises(RuntimeError, match="GPU tensor"):   # CPU tensors: there is no CPU path
+        render_views_batched([a], g, bg, 0)
