@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbloomscene_rast.so")
+# BSR_LIB_PATH: development only (A/B runs of two builds on one GPU box, tools/walk_stats.py's diagnostic build)
+LIB_PATH = os.environ.get("BSR_LIB_PATH") or os.path.join(_HERE, "libbloomscene_rast.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

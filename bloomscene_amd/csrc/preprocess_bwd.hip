@@ -5,7 +5,8 @@
 // streaming pass: dL_dmean3D is assigned by the cov2D part and then incremented by the projection
 // and SH parts in the reference's order, without the round trip through HBM.  It also performs the
 // gather half of the atomic-free accumulation (see render_bwd.hip): the Gaussian's per-instance
-// partial sums are fetched through the instance->slot map and added in a fixed order.  Every
+// partial sums are adjacent rows of the Gaussian-major slab (one per kept tile of its rect, at
+// wg_base[g / 256] + inst_offset[g]) and are added in that fixed order.  Every
 // output row is written here (zeros for culled Gaussians), so callers need no 300 MB memset
 // (rasterize_points.cu:154-162 zero-fills everything up front).
 #include "common.h"

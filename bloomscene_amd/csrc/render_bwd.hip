@@ -25,6 +25,17 @@
 
 namespace bsr {
 
+// ---- diagnostic build only (make stats -> libbsr_rast_stats.so, read by tools/walk_stats.py): per-wave counters of the
+// walk (visits, votes passed, live lanes) and a per-workgroup timeline.  No stamp or counter exists in the product build.
+#ifdef BSR_WALK_STATS
+#define BSR_NSTAT 24
+__device__ unsigned long long g_walk_stats[BSR_NSTAT];
+__device__ unsigned long long g_wg_times[4 * 70000];   // per workgroup: start, end (s_memrealtime, 100 MHz), XCC id, tile
+#define STAT_ADD(i, v) (wstat[i] += (unsigned long long)(v))
+#else
+#define STAT_ADD(i, v) ((void)0)
+#endif
+
 // ---- halving reduction of 9 (10) values over the 64 lanes: lane-masked DPP writes ------------
 // Nine independent 6-step reductions would be 54 cross-lane adds.  Instead the values are split
 // between partner lanes at every step, halving the live set; a first version selected the kept value
@@ -142,10 +153,18 @@ __device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ 
 }
 
 #define BSR_BWD_BATCH 128
+#ifndef BSR_BWD_PAD
+#define BSR_BWD_PAD 1
+#endif
+// Row stride of the per-wave partial sums: the 9 (10) storing lanes of one entry write part[wave][k][j] for
+// k = 0..NV-1 with ONE ds_write_b32 (bank = dword address mod 32, lanes of a 32-lane half conflict).  With rows of
+// 128 floats all of them hit one bank (up to 9-way: SQ_LDS_BANK_CONFLICT was 21 % of the kernel's LDS cycles);
+// 129 puts component k on bank (k + j) mod 32.
+#define BSR_BWD_ROW (BSR_BWD_BATCH + BSR_BWD_PAD)
 template <int NV>
 struct BwdShared {
 	TileStageT<BSR_BWD_BATCH> st;
-	float part[4][NV][BSR_BWD_BATCH];   // per-wave partial sums of the current batch (plain stores)
+	float part[4][NV][BSR_BWD_ROW];   // per-wave partial sums of the current batch (plain stores)
 	uint32_t max_contrib[4];
 };
 
@@ -174,6 +193,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	if (tile >= n_tiles) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
+#ifdef BSR_WALK_STATS
+	unsigned long long wstat[BSR_NSTAT] = {};
+	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 	const int tx = tile % gx, ty = tile / gx;
 	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
@@ -229,7 +252,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	__syncthreads();
 	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
 
-	// LDS byte address of acc[0][0] for the native ds_add_f32 path
 	for (int base = 0; base < n_walk; base += BSR_BWD_BATCH) {
 		const int cnt = min(BSR_BWD_BATCH, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
@@ -249,6 +271,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+		STAT_ADD(6, 1);        // batches (per wave)
+		STAT_ADD(7, cnt);      // staged entries (per wave: every wave sees the batch)
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
 		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
 		const int joff_min = (top - (int)last_contributor) * 16;
@@ -260,19 +284,47 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float dy = q0.y - pixfy;
 			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
 			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
+			STAT_ADD(0, 1);                                  // visits
 			if (wave_ballot(cand) == 0ull) return;   // wave-uniform
+			STAT_ADD(1, 1);                                  // ... with a candidate lane
+			STAT_ADD(4, __popcll(wave_ballot(cand)));        // candidate lanes
 
 			// slow path: fully predicated
 			const float4 q2 = rec_q2<BSR_BWD_BATCH>(rec);
-			const float G = bsr_expf_walk(power);           // same pinned exp as the forward: identical decisions
-			// Lanes that are not candidates take alpha = 0 before the 1/255 test (so one compare decides
-			// `active`), and inactive lanes keep alpha = 0: every recurrence below then leaves their state
-			// unchanged (T*1 = T, acc + 0*(c-acc) = acc); their dL_dalpha is zeroed below, which makes all
-			// nine contributions exactly 0 (G itself may be anything finite there).
-			const float alpha_c = cand ? fminf(0.99f, q1.z * G) : 0.f;
-			const bool active = !(alpha_c < 1.0f / 255.0f);
-			if (wave_ballot(active) == 0ull) return;
-			const float alpha = active ? alpha_c : 0.f;
+			// The forward decided `alpha >= 1/255` on alpha = min(0.99, o * E(power)) with the pinned exp E
+			// (bsr_expf); the backward must take the same decision on every pair (the T chain divides by the
+			// same factors the forward multiplied).  power_cut = -ln(255 o) - 1e-3 proves alpha < 1/255 below it;
+			// symmetrically, power >= power_cut + 2e-3 proves alpha >= 1/255 (E is within 1 ulp of exp, logf within
+			// 2 ulp: margins of 1e-3 in the exponent = 0.1 % of alpha against 1e-6 of rounding).  Only a wave with a
+			// candidate inside that 2e-3 wide band evaluates E to decide; everywhere else the VALUE of exp(power) is
+			// all that is needed, and gradients are compared with a tolerance (the reference's sums are unordered),
+			// so it comes from v_exp_f32: 2 issue slots instead of 13.
+			// "inside the band" is voted on |power - (cut + 1e-3)| < 1.1e-3 over ALL lanes (a vote on an AND with `cand`
+			// makes hipcc materialise the mask in a VGPR): a lane that is not a candidate can only add a harmless
+			// trip through the pinned exp.
+			const bool in_band = wave_ballot(fabsf(power - (q1.y + 1.0e-3f)) < 1.1e-3f) != 0ull;   // rare: ~1 % of the visits
+			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
+			if (in_band) Gx = bsr_expf_walk(power);
+			// Lanes that must not blend carry G = 0, hence alpha = 0: every recurrence below then leaves their state
+			// unchanged (T / 1 = T, Srec + 0 * S = Srec) and all nine contributions are exactly 0 (G * dL_dalpha and
+			// alpha * T; dL_dalpha itself is finite there).
+			float G = cand ? Gx : 0.f;
+			float alpha = fminf(0.99f, q1.z * G);
+			if (in_band) {
+				STAT_ADD(2, 1);                                 // ... decided by the pinned exp
+				const bool active = !(alpha < 1.0f / 255.0f);
+				if (wave_ballot(active) == 0ull) return;
+				G = active ? G : 0.f;
+				alpha = active ? alpha : 0.f;
+			}
+#ifdef BSR_WALK_STATS
+			{
+				const int live = __popcll(wave_ballot(G != 0.f));
+				STAT_ADD(3, 1);                                 // visits that reach the reduction
+				STAT_ADD(5, live);                              // lanes that blend
+				STAT_ADD(8 + ((live - 1) >> 3), 1);             // histogram of live lanes: 1-8, 9-16, ..., 57-64
+			}
+#endif
 			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
 			{
 				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
@@ -280,10 +332,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// instead of the reference's two IEEE divisions (:521,:557).
 #pragma clang fp contract(fast)
 				const float om = 1.f - alpha;
-				float inv = __builtin_amdgcn_rcpf(om);
-				inv = __builtin_fmaf(__builtin_fmaf(-om, inv, 1.0f), inv, inv);
-				// T/(1-alpha): quotient estimate + one residual correction = the correctly rounded quotient
-				// in all but rare cases, so the T chain (hundreds of steps in dense tiles) does not drift.
+				const float inv = __builtin_amdgcn_rcpf(om);   // 1 ulp
+				// T/(1-alpha): quotient estimate + one residual correction (the residual T - om * qT is exact in the
+				// fma, so the 1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare
+				// cases: the T chain (hundreds of steps in dense tiles) does not drift.
 				const float qT = T * inv;
 				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);
 				// The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it
@@ -295,18 +347,21 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				if (DEPTH) u += __builtin_fmaf(gz, q1.w, g1);
 				const float S = u - Srec;
 				Srec = Srec + alpha * S;
-				float dL_dalpha = T * S + neg_Tfinal_bg * inv;
-				dL_dalpha = active ? dL_dalpha : 0.f;
-				const float gd = G * dL_dalpha;          // dL/dopacity term
-				const float w = q1.z * gd;               // G * dL_dG
-				const float h = -0.5f * w;
-				const float hx = h * dx, hy = h * dy;
-				const float wnx = -w * ddelx_dx, wny = -w * ddely_dy;
-				v0 = wnx * (q0.z * dx + q0.w * dy);
-				v1 = wny * (q1.x * dy + q0.w * dx);
-				v2 = hx * dx;
-				v3 = hx * dy;
-				v4 = hy * dy;
+				const float dL_dalpha = T * S + neg_Tfinal_bg * inv;
+				// Per pair the reference adds (:574-583), with gd = G * dL_dalpha and w = o * gd:
+				//   dL_dmean2D.x += -w * ddelx_dx * (a dx + b dy)      dL_dconic.x += -0.5 w dx dx
+				//   dL_dmean2D.y += -w * ddely_dy * (c dy + b dx)      dL_dconic.y += -0.5 w dx dy
+				//   dL_dopacity  += gd                                  dL_dconic.w += -0.5 w dy dy
+				// o, a, b, c and the two scale factors are constants of the ENTRY, so the wave sums only the six
+				// moments of gd over its pixels (1, dx, dy, dx dx, dx dy, dy dy); the entry's row is assembled from
+				// the four quadrants' moments once, when it is written (5 multiplies per pair instead of 13).
+				const float gd = G * dL_dalpha;
+				const float gx = gd * dx, gy = gd * dy;
+				v0 = gx;
+				v1 = gy;
+				v2 = gx * dx;
+				v3 = gx * dy;
+				v4 = gy * dy;
 				v5 = gd;
 				const float aT = alpha * T;
 				v6 = aT * dpx0;
@@ -337,9 +392,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				sh.part[2][k][tid] = 0.f;
 				sh.part[3][k][tid] = 0.f;
 			}
+			// moments -> the reference's sums (see the walk); this thread staged entry `tid` itself
+			const float4 e0 = sh.st.q0[tid], e1 = sh.st.q1[tid];   // (x, y, a, b), (c, cut, o, depth)
+			const float no = -e1.z;
+			const float h = 0.5f * no;
 			float4* row = slab + (size_t)my_row * 3;
-			row[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
-			row[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+			row[0] = make_float4(no * ddelx_dx * (e0.z * a9[0] + e0.w * a9[1]), no * ddely_dy * (e1.x * a9[1] + e0.w * a9[0]),
+			                     h * a9[2], h * a9[3]);
+			row[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
 			row[2] = make_float4(a9[8], a9[9], 0.f, 0.f);
 		}
 		__syncthreads();
@@ -356,6 +416,22 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		row[1] = z;
 		row[2] = z;
 	}
+#ifdef BSR_WALK_STATS
+	if (lane == 0) {
+		for (int i = 0; i < BSR_NSTAT; i++)
+			if (wstat[i]) atomicAdd(&g_walk_stats[i], wstat[i]);
+		if (wave == 0 && blockIdx.x < 70000) {
+			unsigned long long* t = g_wg_times + 4 * (size_t)blockIdx.x;
+			t[0] = t_start;
+			t[1] = __builtin_amdgcn_s_memrealtime();
+			uint32_t xcc, hwid;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+			t[2] = (unsigned long long)xcc | ((unsigned long long)hwid << 32);
+			t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
+		}
+	}
+#endif
 }
 
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
@@ -374,3 +450,19 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 }
 
 }  // namespace bsr
+
+#ifdef BSR_WALK_STATS
+// Diagnostic build only: copies (and clears) the counters / the timeline.  which = 0: g_walk_stats, 1: g_wg_times.
+extern "C" int bsr_debug_walk_stats(int which, void* out, size_t bytes)
+{
+	hipError_t e = hipDeviceSynchronize();
+	if (e == hipSuccess)
+		e = which == 0 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_walk_stats), bytes)
+		               : hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_wg_times), bytes);
+	if (e == hipSuccess && which == 0) {
+		static unsigned long long zeros[BSR_NSTAT];
+		e = hipMemcpyToSymbol(HIP_SYMBOL(bsr::g_walk_stats), zeros, sizeof(zeros));
+	}
+	return e == hipSuccess ? 0 : 1;
+}
+#endif

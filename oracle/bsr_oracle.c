@@ -501,6 +501,15 @@ void bsro_render_forward(const uint32_t* ranges, const uint32_t* point_list, int
  * dL_dopacity [P], dL_dcolors [P,3]; all must be zeroed by the caller (RAST/rasterize_points.cu:154-158).
  * dL_depths is accepted and ignored, as in the reference (:457-463,539-554 are commented out).
  */
+/* Sum mode of bsro_render_backward.  0 (default): binary64 partial sums, rounded once -- the order-free
+ * definition the goldens and the parity tests use.  1: every add is a binary32 add, slot by slot in pixel order
+ * and then Gaussian by Gaussian in list order = what the reference's float atomicAdds (:537,574-583) produce when
+ * they happen to execute in that order; ONE legal outcome of the reference, used only to measure how far two legal
+ * outcomes of the reference lie apart (tools/parity_report.py, tests: the floor of any elementwise comparison). */
+static int g_sum_f32 = 0;
+void bsro_set_sum_mode(int f32) { g_sum_f32 = f32; }
+#define ACC(dst, v) do { if (g_sum_f32) (dst) = (double)((float)(dst) + (float)(v)); else (dst) += (v); } while (0)
+
 void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* point_list, int W, int H,
                           const float* bg_color, const float* points_xy_image, const float* conic_opacity,
                           const float* colors, const float* final_Ts, const uint32_t* n_contrib,
@@ -557,7 +566,7 @@ void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* 
 						const float dL_dchannel = dL_dpixel[ch];
 						dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
 						const float v = dchannel_dcolor * dL_dchannel;
-						sl[6 + ch] += v;
+						ACC(sl[6 + ch], v);
 						if (asl) asl[6 + ch] += fabs((double)v);
 					}
 					dL_dalpha *= T;
@@ -576,7 +585,7 @@ void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* 
 					const float v3 = -0.5f * gdx * dy * dL_dG;
 					const float v4 = -0.5f * gdy * dy * dL_dG;
 					const float v5 = G * dL_dalpha;
-					sl[0] += v0; sl[1] += v1; sl[2] += v2; sl[3] += v3; sl[4] += v4; sl[5] += v5;
+					ACC(sl[0], v0); ACC(sl[1], v1); ACC(sl[2], v2); ACC(sl[3], v3); ACC(sl[4], v4); ACC(sl[5], v5);
 					if (asl) {
 						asl[0] += fabs((double)v0); asl[1] += fabs((double)v1); asl[2] += fabs((double)v2);
 						asl[3] += fabs((double)v3); asl[4] += fabs((double)v4); asl[5] += fabs((double)v5);
@@ -588,7 +597,7 @@ void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* 
 	double* aacc = abs_sums ? (double*)calloc((size_t)(P > 0 ? P : 1) * 9, sizeof(double)) : NULL;
 	for (int s = 0; s < R; s++) {
 		const uint32_t id = point_list[s];
-		for (int k = 0; k < 9; k++) acc[(size_t)id * 9 + k] += slab[(size_t)s * 9 + k];
+		for (int k = 0; k < 9; k++) ACC(acc[(size_t)id * 9 + k], slab[(size_t)s * 9 + k]);
 		if (aacc)
 			for (int k = 0; k < 9; k++) aacc[(size_t)id * 9 + k] += aslab[(size_t)s * 9 + k];
 	}

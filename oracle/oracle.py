@@ -194,7 +194,7 @@ def forward(rs, means3D, opacities, shs=None, colors_precomp=None, scales=None, 
     return st
 
 
-def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradient=False):
+def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradient=False, f32_sums=False):
     """Rasterizer::backward (rasterizer_impl.cu:403-504) + RasterizeGaussiansBackwardCUDA
     (rasterize_points.cu:119-200).  ``grad_depth`` is accepted and ignored, like the reference --
     unless ``depth_gradient=True``, the opt-in EXTENSION that adds the true
@@ -223,11 +223,17 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradien
     focal_x = np.float32(W) / (np.float32(2.0) * np.float32(rs.tanfovx))
     R = st.num_rendered
     plist = st.point_list if R > 0 else np.zeros(1, dtype=np.uint32)
-    L.bsro_render_backward(
-        C.c_int(P), C.c_int(R), _p(st.ranges), _p(plist), C.c_int(W), C.c_int(H), _p(rs.bg), _p(st.means2D),
-        _p(st.conic_opacity), _p(st.features), _p(st.final_T), _p(st.n_contrib), _p(grad_color), _p(grad_depth),
-        _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors),
-        _p(g.abs_sums) if want_abs_sums else None)
+    # f32_sums: the pair sums added in binary32 in one fixed order (one legal outcome of the reference's float
+    # atomicAdds) instead of the order-free binary64 definition; only to measure the spread between legal outcomes
+    L.bsro_set_sum_mode(C.c_int(1 if f32_sums else 0))
+    try:
+        L.bsro_render_backward(
+            C.c_int(P), C.c_int(R), _p(st.ranges), _p(plist), C.c_int(W), C.c_int(H), _p(rs.bg), _p(st.means2D),
+            _p(st.conic_opacity), _p(st.features), _p(st.final_T), _p(st.n_contrib), _p(grad_color), _p(grad_depth),
+            _p(g.dL_dmeans2D), _p(g.dL_dconic), _p(g.dL_dopacity), _p(g.dL_dcolors),
+            _p(g.abs_sums) if want_abs_sums else None)
+    finally:
+        L.bsro_set_sum_mode(C.c_int(0))
     if not depth_gradient:
         return backward_chain(st, g)
     g.dL_dz = np.zeros((P,), dtype=np.float32)

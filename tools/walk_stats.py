@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Lane utilisation and load balance of the backward tile walk (k_render_bwd), from the diagnostic build
+`make -C bloomscene_amd/csrc stats` (libbsr_rast_stats.so: per-wave counters + a per-workgroup timeline; the product
+library carries neither).  Run on the GPU box:
+
+    BSR_LIB_PATH=bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py [--config c3] [--scale-mul 1.0]
+
+Prints one JSON object: visits per staged entry, share of visits passing each vote, live lanes per reducing visit
+(mean + histogram), and from the timeline: workgroup duration spread, concurrency over time, tail idle.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONFIGS = {"c2": (100_000, 800, 800, 1), "c3": (1_000_000, 1920, 1080, 3), "c5": (5_000_000, 1920, 1080, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scale-mul", type=float, default=1.0, help="scene A with all scales multiplied (denser lists)")
+    args = ap.parse_args()
+    from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
+    from bloomscene_amd.synthetic import scene_a, upstream_grads
+    lib = _capi.lib()
+    fn = lib.bsr_debug_walk_stats   # AttributeError here = not the diagnostic build
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    P, W, H, deg = CONFIGS[args.config]
+    dev = torch.device("cuda")
+    sc = scene_a(P, W, H, deg, seed=0)
+    cam = sc.cameras[0].to(dev)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    with torch.no_grad():
+        leaves["scales"].mul_(args.scale_mul)
+    gC, gD = upstream_grads(W, H, seed=1)
+    gC, gD = gC.to(dev), gD.to(dev)
+    stats = np.zeros(24, dtype=np.uint64)
+    for it in range(3):
+        m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, depth = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"],
+                                   shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        if it == 2:
+            torch.cuda.synchronize()
+            assert fn(0, stats.ctypes.data, stats.nbytes) == 0   # clears what the warm-up launches counted
+        torch.autograd.backward((color, depth), (gC, gD))
+    torch.cuda.synchronize()
+    assert fn(0, stats.ctypes.data, stats.nbytes) == 0
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    nblk = (T + 7) // 8 * 8
+    tl = np.zeros(4 * 70000, dtype=np.uint64)
+    assert fn(1, tl.ctypes.data, tl.nbytes) == 0
+    tl = tl.reshape(-1, 4)[:nblk]
+    tl = tl[tl[:, 1] > 0]
+    s = stats.astype(np.float64)
+    visits, pass1, band, reduce_, cand_l, live_l, batches, staged = s[:8]
+    hist = s[8:16]
+    out = {
+        "config": args.config, "scale_mul": args.scale_mul, "tiles": T,
+        "entries_staged_per_tile": staged / 4 / T,            # every wave counts the batch
+        "visits_per_staged_entry": visits / (staged / 4),     # = quadrants kept by the conservative box test
+        "share_of_visits_with_a_candidate": pass1 / visits,
+        "share_of_visits_decided_by_pinned_exp": band / visits,
+        "share_of_visits_reducing": reduce_ / visits,
+        "candidate_lanes_per_candidate_visit": cand_l / max(pass1, 1),
+        "live_lanes_per_reducing_visit": live_l / max(reduce_, 1),
+        "live_lane_histogram_1-8_..._57-64": (hist / max(reduce_, 1)).round(4).tolist(),
+        "reducing_visits_per_kept_instance": reduce_ / (staged / 4),
+    }
+    # timeline: 100 MHz ticks
+    t0 = tl[:, 0].min()
+    st = (tl[:, 0] - t0).astype(np.float64) / 100.0   # us
+    en = (tl[:, 1] - t0).astype(np.float64) / 100.0
+    dur = en - st
+    total = en.max()
+    n_in_tile = (tl[:, 3] >> np.uint64(32)).astype(np.float64)
+    # concurrency curve: workgroups resident over time
+    grid = np.linspace(0, total, 201)
+    conc = [(float(((st <= g) & (en > g)).sum())) for g in grid]
+    busy = float(dur.sum())
+    slots = max(conc)
+    out["timeline"] = {
+        "kernel_us": round(float(total), 1), "workgroups": int(len(tl)),
+        "wg_duration_us": {"p5": round(float(np.percentile(dur, 5)), 1), "median": round(float(np.median(dur)), 1),
+                           "p95": round(float(np.percentile(dur, 95)), 1), "max": round(float(dur.max()), 1)},
+        "entries_per_tile": {"min": float(n_in_tile.min()), "median": float(np.median(n_in_tile)), "max": float(n_in_tile.max())},
+        "peak_resident_workgroups": slots,
+        "mean_resident_workgroups": round(busy / float(total), 1),
+        "occupancy_of_peak": round(busy / float(total) / slots, 4),
+        "time_below_half_peak_us": round(float(sum(1 for c in conc if c < 0.5 * slots)) * float(total) / 200, 1),
+        "last_start_us": round(float(st.max()), 1),
+        "resident_at_10pct_steps": [conc[i] for i in range(0, 201, 20)],
+        "xcc_ids_seen": sorted(set(int(x & np.uint64(0xf)) for x in tl[:, 2])),
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
