@@ -20,7 +20,9 @@ from types import SimpleNamespace
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbsr_oracle.so")
+# BSR_ORACLE_LIB: load another build of the oracle instead (tests/test_oracle_mutations.py points it at deliberately
+# broken copies to prove that the checks would catch a transcription slip)
+_LIB_PATH = os.environ.get("BSR_ORACLE_LIB") or os.path.join(_HERE, "libbsr_oracle.so")
 _lib = None
 
 BLOCK_X = 16
@@ -38,7 +40,8 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not os.environ.get("BSR_ORACLE_LIB"):
+            build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.bsro_expf.restype = C.c_float
         _lib.bsro_expf.argtypes = [C.c_float]
