@@ -1,17 +1,21 @@
-"""Camera conventions consumed by the rasterizer.
+"""Synthetic cameras in the conventions the rasterizer consumes.
 
-Restates, for the host side of the hot path only, what BloomScene's callers hand to
-``GaussianRasterizationSettings``:
+The rasterizer takes its matrices from the caller (``GaussianRasterizationSettings.viewmatrix / projmatrix /
+campos``); this module only builds such matrices for the synthetic scenes of the benchmarks and tests, derived
+here in closed form from what the kernels do with them:
 
-* ``getWorld2View2`` / ``getProjectionMatrix``   -- reference ``utils/graphics.py:43-77``
-* ``MiniCam``                                    -- reference ``scene/cameras.py:67-78``
-* the rotate360 preset (yaw about +Y, zero translation)
-                                                 -- reference ``utils/trajectory.py:16-24,102-126``
-  turned into cameras as ``loadCameraPreset`` does -- reference ``scene/dataset_readers.py:101-131``
+* a point is transformed as ``p' = m[0] x + m[4] y + m[8] z + m[12]`` etc. (reference
+  ``cuda_rasterizer/auxiliary.h:58-77``), i.e. the 16 floats are the column-vector matrix stored column by
+  column -- as a row-major ``[4, 4]`` tensor that is the TRANSPOSE of the usual matrix.  BloomScene's cameras hold
+  exactly these transposed tensors (``world_view_transform``, ``full_proj_transform``; reference
+  ``scene/cameras.py:59-62,75-78``);
+* view space looks down +z, x right, y down; ``p_hom.w`` = view depth (reference ``utils/graphics.py:57-77``
+  with ``z_sign = 1``), so for a symmetric frustum the projection is
+  ``diag(1 / tan(fovx / 2), 1 / tan(fovy / 2))`` on x, y and ``(zfar z - zfar znear) / (zfar - znear)`` on z;
+* ``campos`` is the camera position in world space.
 
-Matrices are stored transposed (row-major tensors whose flat index ``m[4*j+i]`` is the
-column-vector matrix element (i, j)), which is what the kernels index (reference
-``cuda_rasterizer/auxiliary.h:58-77``).
+The rotate360 sweep (reference ``utils/trajectory.py:16-24,110-121`` -> ``scene/dataset_readers.py:105-131``) is
+N cameras at the origin, view i yawed by ``360 i / N`` degrees about +Y, ``FoVx = 0.95 * camera_angle_x``.
 """
 from __future__ import annotations
 
@@ -22,60 +26,18 @@ import numpy as np
 import torch
 
 
-def get_world2view2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """reference utils/graphics.py:43-54 (R is stored transposed, 'glm' convention)."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = R.transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
-
-
-def get_projection_matrix(znear, zfar, fovX, fovY):
-    """reference utils/graphics.py:57-77."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
-    P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
-
-
-def fov2focal(fov, pixels):
-    return pixels / (2 * math.tan(fov / 2))
-
-
-def focal2fov(focal, pixels):
-    return 2 * math.atan(pixels / (2 * focal))
-
-
 @dataclass
 class MiniCam:
-    """Same attributes as reference scene/cameras.py:67-78 (tensors live on ``device``)."""
+    """The camera attributes BloomScene's render() reads (reference scene/cameras.py:67-78)."""
     image_width: int
     image_height: int
     FoVy: float
     FoVx: float
     znear: float
     zfar: float
-    world_view_transform: torch.Tensor
-    full_proj_transform: torch.Tensor
-    camera_center: torch.Tensor
+    world_view_transform: torch.Tensor   # [4, 4], transposed world-to-view matrix
+    full_proj_transform: torch.Tensor    # [4, 4], world_view_transform @ projection^T
+    camera_center: torch.Tensor          # [3]
 
     def to(self, device):
         return MiniCam(self.image_width, self.image_height, self.FoVy, self.FoVx, self.znear, self.zfar,
@@ -83,50 +45,54 @@ class MiniCam:
                        self.camera_center.to(device))
 
 
-def make_minicam(R, T, fovx, fovy, width, height, znear=0.01, zfar=100.0, device="cpu"):
-    """Build the three tensors exactly as reference scene/dataset_readers.py:124-131 does."""
-    world_view_transform = torch.tensor(get_world2view2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
-    projection_matrix = get_projection_matrix(znear=znear, zfar=zfar, fovX=fovx, fovY=fovy).transpose(0, 1)
-    full_proj_transform = (world_view_transform.unsqueeze(0).bmm(projection_matrix.unsqueeze(0))).squeeze(0)
-    camera_center = torch.inverse(world_view_transform)[3][:3]
+def vertical_fov(fovx, width, height):
+    """FoVy of square pixels: tan(fovy / 2) = tan(fovx / 2) * height / width."""
+    return 2.0 * math.atan(math.tan(0.5 * fovx) * height / width)
+
+
+def projection_transposed(znear, zfar, fovx, fovy):
+    """Transposed projection of a symmetric frustum (see the module docstring): float32 [4, 4]."""
+    Pt = torch.zeros(4, 4)
+    Pt[0, 0] = 1.0 / math.tan(0.5 * fovx)
+    Pt[1, 1] = 1.0 / math.tan(0.5 * fovy)
+    Pt[2, 2] = zfar / (zfar - znear)
+    Pt[3, 2] = -(zfar * znear) / (zfar - znear)
+    Pt[2, 3] = 1.0                               # w = view z
+    return Pt
+
+
+def make_minicam(cam_to_world_rot, world_to_cam_trans, fovx, fovy, width, height, znear=0.01, zfar=100.0, device="cpu"):
+    """Camera with axes ``cam_to_world_rot`` (3x3, columns = the camera's x / y / z axes in world space) and
+    world-to-view translation ``world_to_cam_trans``:  p_view = R^T p_world + t."""
+    R = np.asarray(cam_to_world_rot, dtype=np.float64)
+    t = np.asarray(world_to_cam_trans, dtype=np.float64).reshape(3)
+    Vt = np.zeros((4, 4), dtype=np.float64)      # transposed [R^T | t; 0 0 0 1]
+    Vt[:3, :3] = R                               # (R^T)^T
+    Vt[3, :3] = t
+    Vt[3, 3] = 1.0
+    view_t = torch.from_numpy(Vt.astype(np.float32))
+    full_t = view_t @ projection_transposed(znear, zfar, fovx, fovy)
+    centre = torch.from_numpy((-(R @ t)).astype(np.float32))     # p_view = 0  <=>  p_world = -R t
     return MiniCam(int(width), int(height), float(fovy), float(fovx), znear, zfar,
-                   world_view_transform.contiguous().to(device), full_proj_transform.contiguous().to(device),
-                   camera_center.contiguous().to(device))
+                   view_t.contiguous().to(device), full_t.contiguous().to(device), centre.contiguous().to(device))
 
 
-def generate_seed_360(viewangle, n_views):
-    """reference utils/trajectory.py:16-24 (in-place yaw, zero translation)."""
-    N = n_views
-    render_poses = np.zeros((N, 3, 4))
-    for i in range(N):
-        th = (viewangle / N) * i / 180 * np.pi
-        render_poses[i, :3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
-    return render_poses
+def yaw_rotation(yaw_deg):
+    """Camera-to-world rotation of a camera turned by ``yaw_deg`` about the world's +Y axis (its view-space
+    rotation is [[c, 0, s], [0, 1, 0], [-s, 0, c]], the pose matrix of the rotate360 preset)."""
+    th = math.radians(yaw_deg)
+    c, s = math.cos(th), math.sin(th)
+    return np.array([[c, 0.0, -s], [0.0, 1.0, 0.0], [s, 0.0, c]])
 
 
 def rotate360_cameras(n_views, width, height, camera_angle_x, device="cpu"):
-    """The rotate360 view list: ``get_camerapaths`` (reference utils/trajectory.py:102-126)
-    followed by ``loadCameraPreset`` (reference scene/dataset_readers.py:101-131)."""
-    yz_reverse = np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]])
-    fovx = camera_angle_x * 0.95  # dataset_readers.py:105
-    fovy = focal2fov(fov2focal(fovx, width), height)
-    cams = []
-    for pose in generate_seed_360(360, n_views):
-        Rw2i = pose[:3, :3]
-        Tw2i = pose[:3, 3:4]
-        Ri2w = np.matmul(yz_reverse, Rw2i).T
-        Ti2w = -np.matmul(Ri2w, np.matmul(yz_reverse, Tw2i))
-        c2w = np.concatenate((Ri2w, Ti2w), axis=1)
-        c2w = np.concatenate((c2w, np.array([0, 0, 0, 1]).reshape((1, 4))), axis=0)
-        c2w[:3, 1:3] *= -1  # OpenGL/Blender -> COLMAP axes, dataset_readers.py:115
-        w2c = np.linalg.inv(c2w)
-        R = np.transpose(w2c[:3, :3])
-        T = w2c[:3, 3]
-        cams.append(make_minicam(R, T, fovx, fovy, width, height, device=device))
-    return cams
+    """The rotate360 view list: n_views cameras at the origin, yaw 360 i / n_views degrees, FoVx = 0.95 * angle."""
+    fovx = 0.95 * camera_angle_x
+    fovy = vertical_fov(fovx, width, height)
+    return [make_minicam(yaw_rotation(360.0 / n_views * i), np.zeros(3), fovx, fovy, width, height, device=device)
+            for i in range(n_views)]
 
 
 def identity_camera(width, height, fovx, device="cpu"):
     """Camera at the origin looking down +z (synthetic scene A)."""
-    fovy = 2.0 * math.atan(math.tan(fovx / 2.0) * height / width)
-    return make_minicam(np.eye(3), np.zeros(3), fovx, fovy, width, height, device=device)
+    return make_minicam(np.eye(3), np.zeros(3), fovx, vertical_fov(fovx, width, height), width, height, device=device)

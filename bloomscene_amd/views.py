@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .cameras import MiniCam, make_minicam, focal2fov, fov2focal
+from .cameras import MiniCam, make_minicam, vertical_fov, yaw_rotation
 
 
 def shard_views(n_views: int, rank: int, world: int):
@@ -29,11 +29,10 @@ def shard_views(n_views: int, rank: int, world: int):
 
 
 def yawed_camera(width, height, fovx, yaw_deg=0.0, device="cpu") -> MiniCam:
-    """Camera at the origin looking down +z, rotated by ``yaw_deg`` about +Y (scene-A camera when 0)."""
-    th = math.radians(yaw_deg)
-    R = np.array([[math.cos(th), 0, math.sin(th)], [0, 1, 0], [-math.sin(th), 0, math.cos(th)]])
-    fovy = focal2fov(fov2focal(fovx, width), height)
-    return make_minicam(R, np.zeros(3), fovx, fovy, width, height, device=device)
+    """Camera at the origin whose axes are the world's turned by ``yaw_deg`` about +Y: its optical axis is
+    (sin yaw, 0, cos yaw) (the scene-A camera when 0)."""
+    return make_minicam(yaw_rotation(-yaw_deg), np.zeros(3), fovx, vertical_fov(fovx, width, height), width, height,
+                        device=device)
 
 
 def broadcast_gaussians(bufs: dict, src: int = 0, force: bool = False) -> float:

@@ -100,29 +100,50 @@ def test_no_cpu_fallback():
 
 
 def test_camera_conventions():
-    """A0: viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T, campos = inverse(viewmatrix)[3,:3]."""
+    """A0: viewmatrix = W2C^T, projmatrix = viewmatrix @ P^T, campos = camera position, checked against matrices
+    worked out by hand: 8-view rotate360 sweep at 64x48, camera_angle_x = 60 deg -> FoVx = 57 deg
+    (dataset_readers.py:105), tan(28.5 deg) = 0.5429557, tan(FoVy / 2) = 0.5429557 * 48 / 64 = 0.4072168;
+    view 1 is yawed 45 deg about +Y (trajectory.py:16-24): W2C rotation [[c, 0, s], [0, 1, 0], [-s, 0, c]], stored
+    transposed; znear 0.01, zfar 100: P[2][2] = 100 / 99.99, P[2][3] = -1 / 99.99, P[3][2] = 1."""
     W, H = 64, 48
     cams = cameras.rotate360_cameras(8, W, H, math.radians(60))
     assert len(cams) == 8
+    r = 0.70710677
+    want_view = {1: [[r, 0, -r, 0], [0, 1, 0, 0], [r, 0, r, 0], [0, 0, 0, 1]],
+                 3: [[-r, 0, -r, 0], [0, 1, 0, 0], [r, 0, -r, 0], [0, 0, 0, 1]],
+                 0: [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                 4: [[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]]}
+    fx, fy, a, b = 1.8417708, 2.4556944, 1.00010001, -0.010001
+    want_proj = {1: [[fx * r, 0, -r * a, -r], [0, fy, 0, 0], [fx * r, 0, r * a, r], [0, 0, b, 0]],
+                 3: [[-fx * r, 0, -r * a, -r], [0, fy, 0, 0], [fx * r, 0, -r * a, -r], [0, 0, b, 0]],
+                 0: [[fx, 0, 0, 0], [0, fy, 0, 0], [0, 0, a, 1], [0, 0, b, 0]]}
+    for i, m in want_view.items():
+        assert torch.allclose(cams[i].world_view_transform, torch.tensor(m, dtype=torch.float32), atol=1e-7), i
+    for i, m in want_proj.items():
+        assert torch.allclose(cams[i].full_proj_transform, torch.tensor(m, dtype=torch.float32), atol=2e-6), i
     for i, cam in enumerate(cams):
         V = cam.world_view_transform.double()
         assert torch.allclose(V[:3, :3] @ V[:3, :3].T, torch.eye(3, dtype=torch.float64), atol=1e-6)
-        assert torch.allclose(V[3, :3], torch.zeros(3, dtype=torch.float64), atol=1e-6)   # zero translation
-        assert torch.allclose(cam.camera_center, torch.zeros(3), atol=1e-6)
-        assert abs(cam.FoVx - 0.95 * math.radians(60)) < 1e-12   # dataset_readers.py:105
-        Pm = cameras.get_projection_matrix(0.01, 100.0, cam.FoVx, cam.FoVy).double()
-        assert torch.allclose(cam.full_proj_transform.double(), V @ Pm.T, atol=1e-5)
+        assert torch.equal(cam.camera_center, torch.zeros(3))                 # the sweep never translates
+        assert abs(cam.FoVx - math.radians(57.0)) < 1e-12 and abs(math.tan(cam.FoVy / 2) - 0.4072168) < 1e-7
         # a point on the optical axis of view i projects to the image centre with w = depth
         axis = V[:3, 2]          # third column of the stored matrix = camera z axis in world coords
         p = torch.cat([axis * 3.0, torch.ones(1, dtype=torch.float64)])
         hom = p @ cam.full_proj_transform.double()
         assert abs(hom[0] / hom[3]) < 1e-5 and abs(hom[1] / hom[3]) < 1e-5 and abs(hom[3] - 3.0) < 1e-5
-    # yaw of view i is 360/n * i about +Y (trajectory.py:16-24)
-    z1 = cams[1].world_view_transform[:3, 2]
-    assert abs(math.degrees(math.atan2(abs(z1[0].item()), z1[2].item())) - 45.0) < 1e-3
     cam0 = views.yawed_camera(W, H, math.radians(60), 0.0)
     ident = cameras.identity_camera(W, H, math.radians(60))
     assert torch.equal(cam0.full_proj_transform, ident.full_proj_transform)
+    # a translated camera: p_view = R^T p_world + t, campos = -R t; the world point campos maps to view-space 0
+    Rm = cameras.yaw_rotation(30.0)
+    cam = cameras.make_minicam(Rm, [0.5, -1.0, 2.0], 1.0, 0.8, 40, 30)
+    c = cam.camera_center.double()
+    assert torch.allclose(torch.cat([c, torch.ones(1, dtype=torch.float64)]) @ cam.world_view_transform.double(),
+                          torch.tensor([0, 0, 0, 1.0], dtype=torch.float64), atol=1e-6)
+    assert torch.allclose(c, torch.tensor(-(Rm @ [0.5, -1.0, 2.0])), atol=1e-6)
+    # yawed_camera(+y): the optical axis turns towards +x
+    z_axis = views.yawed_camera(W, H, 1.0, 20.0).world_view_transform[:3, 2]
+    assert abs(z_axis[0].item() - math.sin(math.radians(20))) < 1e-6 and abs(z_axis[2].item() - math.cos(math.radians(20))) < 1e-6
 
 
 def test_shard_views_round_robin_partition():
