@@ -51,6 +51,7 @@ SIGNATURES = {
     "bsr_geometry_bytes": (C.c_size_t, [C.c_int]),
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "bsr_transmittance_offset": (C.c_size_t, [C.c_void_p]),
     "bsr_profile_enable": (C.c_int, [C.c_int]),
     "bsr_profile_reset": (C.c_int, []),
     "bsr_profile_read": (C.c_int, [C.POINTER(StageProfile), C.c_int]),

@@ -54,18 +54,29 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.depth = (float*)p;
 	return g;
 }
-size_t BinState::bytes(size_t R)
+// The backward's slab (48 B per instance) lives in the caller's binning buffer too, over the radix ping-pong
+// buffers, which are dead once the forward has returned: the library owns no device memory, as in the reference,
+// where every byte of scratch comes from the caller's resize callbacks (rasterize_points.cu:27-33).
+// with_slab = false (view-batched forward: inference only) sizes the section for the ping-pong buffers alone.
+static size_t bin_work_bytes(size_t R, bool with_slab)
 {
-	return align_up(R * sizeof(uint32_t), 256) + 2 * align_up(R * sizeof(BinElem), 256) +
+	const size_t pingpong = 2 * align_up(R * sizeof(BinElem), 256);
+	const size_t slab = with_slab ? align_up(R * 48, 256) : 0;
+	return pingpong > slab ? pingpong : slab;
+}
+size_t BinState::bytes(size_t R, bool with_slab)
+{
+	return align_up(R * sizeof(uint32_t), 256) + bin_work_bytes(R, with_slab) +
 	       align_up((size_t)BSR_RADIX_BINS_ * (BSR_HIST_BLOCKS_MAX + 1) * sizeof(uint32_t), 256) + 256;
 }
-BinState BinState::carve(char* p, size_t R)
+BinState BinState::carve(char* p, size_t R, bool with_slab)
 {
 	BinState b;
 	p = (char*)align_up((size_t)p, 256);
 	b.point_list = (uint32_t*)p; p += align_up(R * sizeof(uint32_t), 256);
-	b.elems_a = (BinElem*)p;       p += align_up(R * sizeof(BinElem), 256);
-	b.elems_b = (BinElem*)p;       p += align_up(R * sizeof(BinElem), 256);
+	b.elems_a = (BinElem*)p;
+	b.elems_b = (BinElem*)(p + align_up(R * sizeof(BinElem), 256));
+	b.slab = (float4*)p;           p += bin_work_bytes(R, with_slab);
 	b.hist = (uint32_t*)p;
 	return b;
 }
@@ -170,25 +181,6 @@ int fail(const char* fmt, ...)
 		if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                        \
 		if (_e != hipSuccess) return fail("stage %s failed: %s", name, hipGetErrorString(_e));     \
 	} while (0)
-
-// Keep freed stream-ordered allocations cached in the device's default pool (the default release
-// threshold of 0 would hand them back to the driver at every synchronisation).
-static int ensure_pool_keeps_memory()
-{
-	static std::mutex mu;
-	static std::vector<int> done_devices;
-	int dev = 0;
-	HIP_TRY(hipGetDevice(&dev));
-	std::lock_guard<std::mutex> lk(mu);
-	for (int d : done_devices)
-		if (d == dev) return 0;
-	hipMemPool_t pool;
-	HIP_TRY(hipDeviceGetDefaultMemPool(&pool, dev));
-	uint64_t threshold = UINT64_MAX;
-	HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
-	done_devices.push_back(dev);
-	return 0;
-}
 
 // ---------------------------------------------------------------- stage profiler (bench only)
 struct StageRec {
@@ -316,7 +308,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			return fail("Please provide excatly one of either SHs or precomputed colors!");
 		if (shs && (!cam_pos || M <= 0)) return fail("SH colours need cam_pos and M > 0");
 		if (shs && D >= 0 && (D + 1) * (D + 1) > M && D <= 3)
-			return fail("sh_degree %d needs %d coefficients but M = %d", D, (D + 1) * (D + 1), M);
+			return fail("sh_degree %d needs %d coefficients per Gaussian, shs holds %d", D, (D + 1) * (D + 1), M);
 	}
 	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
 	if ((long long)V * gy > 65535 || (long long)V * gx * gy > 0x3fffffff) return fail("too many views for one call");
@@ -382,9 +374,9 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
 	// from device memory and returns at once if it exceeds the capacity
 	auto run_tail = [&](size_t capacity) -> int {
-		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity));
+		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity, V == 1));
 		if (!bin_p) return fail("scratch allocation callback returned null");
-		bin = BinState::carve(bin_p, capacity);
+		bin = BinState::carve(bin_p, capacity, V == 1);
 		cap = capacity;
 		const int* n_ptr = img.flags + 2;
 		{
@@ -444,7 +436,11 @@ int bsr_version(void) { return BSR_VERSION; }
 const char* bsr_last_error(void) { return g_err; }
 
 size_t bsr_geometry_bytes(int P) { return GeomState::bytes((size_t)(P > 0 ? P : 0)); }
-size_t bsr_binning_bytes(int R) { return BinState::bytes((size_t)(R > 0 ? R : 0)); }
+size_t bsr_binning_bytes(int R) { return BinState::bytes((size_t)(R > 0 ? R : 0), true); }
+size_t bsr_transmittance_offset(const void* image_buffer)
+{
+	return align_up((size_t)image_buffer, 256) - (size_t)image_buffer;   // ImgState::carve: final_T is the first section
+}
 size_t bsr_image_bytes(int W, int H)
 {
 	const size_t gx = (W + BSR_TILE - 1) / BSR_TILE, gy = (H + BSR_TILE - 1) / BSR_TILE;
@@ -633,6 +629,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	if (!shs && !dL_dcolor) return fail("dL_dcolor is null but colors_precomp is the colour input");
 	if (!scales && !dL_dcov3D) return fail("dL_dcov3D is null but cov3D_precomp is the covariance input");
 	if (shs && (M <= 0 || !dL_dsh || !campos)) return fail("SH backward needs M > 0, dL_dsh and campos");
+	if (shs && (D < 0 || (D + 1) * (D + 1) > M))
+		return fail("sh_degree %d needs %d coefficients per Gaussian, shs holds %d", D, (D + 1) * (D + 1), M);
 	if (scales && (!dL_dscale || !dL_drot)) return fail("dL_dscale/dL_drot is null");
 
 	const int gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
@@ -640,20 +638,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	const size_t N = (size_t)width * height;
 	GeomState geom = GeomState::carve(geom_buffer, (size_t)P);
 	ImgState img = ImgState::carve(image_buffer, N, (size_t)T);
-	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0));
+	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0), true);
 
-	// Backward-only scratch (stream-ordered, from the device's default memory pool):
-	//   slab[R][12] f32: per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows)
-	const size_t Rn = (size_t)(R > 0 ? R : 0);
-	const size_t scratch_bytes = align_up(Rn * 48, 256) + 256;
-	if (ensure_pool_keeps_memory()) return 1;
-	char* scratch = nullptr;
-	HIP_TRY(hipMallocAsync((void**)&scratch, scratch_bytes, s));
-	float4* slab = (float4*)scratch;
-	struct ScratchFree {
-		char* p; hipStream_t s;
-		~ScratchFree() { if (p) (void)hipFreeAsync(p, s); }
-	} scratch_guard{scratch, s};
+	// slab[R][12] f32: per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows), in the
+	// caller's binning buffer over the forward's dead radix ping-pong buffers.  The buffer was sized by the forward for
+	// a capacity >= R, and the section starts right behind point_list[R], so the R-based carve stays inside it.
+	float4* slab = bin.slab;
 
 	if (R > 0) {
 		{

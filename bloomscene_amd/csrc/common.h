@@ -59,9 +59,11 @@ struct BinState {
 	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
 	BinElem* elems_a;     // [R] (tile id, gaussian id, depth bits): ping-pong buffers of the radix passes
 	BinElem* elems_b;       // [R]
+	float4* slab;         // [R][3] the backward's per-instance partial sums (k_render_bwd -> k_preprocess_bwd): the SAME
+	                      //        bytes as elems_a / elems_b, which are dead once the forward has returned
 	uint32_t* hist;       // [256 * BSR_HIST_BLOCKS_MAX] digit-major workgroup histograms, then [256] digit totals
-	static size_t bytes(size_t R);
-	static BinState carve(char* p, size_t R);
+	static size_t bytes(size_t R, bool with_slab);
+	static BinState carve(char* p, size_t R, bool with_slab);
 };
 struct ImgState {
 	float* final_T;        // [N]

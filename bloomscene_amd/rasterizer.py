@@ -10,6 +10,7 @@ There is no CPU path here: tensors must live on the GPU and the HIP library must
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -283,8 +284,10 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings, depth_gradient)
 
 
+_tls = threading.local()   # .last_final_T: final_T view of this thread's most recent forward call (return_alpha)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
-    last_final_T = None   # final_T view of the most recent forward call (see GaussianRasterizer.forward)
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -310,14 +313,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
                 _rasterize_gaussians_native(*args)
 
-        # accumulated opacity of the call (extension; final_T is the first H*W floats of the image buffer)
+        # accumulated opacity of the call (extension): a view of final_T inside the image buffer, where the library
+        # says it is; nothing is computed unless GaussianRasterizer.forward(return_alpha=True) asks for it
         n_pix = raster_settings.image_height * raster_settings.image_width
         if imgBuffer.numel() >= 4 * n_pix:
-            final_T = imgBuffer[:4 * n_pix].view(torch.float32).view(1, raster_settings.image_height,
-                                                                     raster_settings.image_width)
-            _RasterizeGaussians.last_final_T = final_T   # a view: nothing is computed unless asked for
+            off = int(_capi.lib().bsr_transmittance_offset(imgBuffer.data_ptr()))
+            _tls.last_final_T = imgBuffer[off:off + 4 * n_pix].view(torch.float32).view(
+                1, raster_settings.image_height, raster_settings.image_width)
         else:   # P == 0: nothing was rendered
-            _RasterizeGaussians.last_final_T = None
+            _tls.last_final_T = None
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.depth_gradient = bool(depth_gradient)
@@ -426,7 +430,7 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
                                        cov3D_precomp, raster_settings, self.depth_gradient)
         color, radii, depth = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
                                                   rotations, cov3D_precomp, raster_settings, self.depth_gradient)
-        final_T = _RasterizeGaussians.last_final_T
+        final_T = getattr(_tls, "last_final_T", None)
         alpha = torch.zeros_like(depth) if final_T is None else (1.0 - final_T)
         return color, radii, depth, alpha.detach()
 

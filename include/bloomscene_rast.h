@@ -7,7 +7,12 @@
  * absent" exactly like the empty CPU tensors -> nullptr convention of the reference
  * (depth_diff_gaussian_rasterization/__init__.py:198-208, rasterize_points.cu:95-113).
  * Every function returns 0 on success, non-zero on failure; bsr_last_error() then describes it.
- * The library keeps no results between calls (per host thread: a pinned 16-byte landing buffer, an
+ * Memory ownership is the reference's (rasterize_points.cu:27-33, rasterizer_impl.h:22-27): every byte of device
+ * memory -- inputs, outputs, gradients and ALL scratch of forward and backward -- belongs to the caller; the library
+ * allocates no device memory and touches no allocator or memory-pool setting.  (The one exception is 4 bytes of
+ * stream-ordered memory for the error flag of a prefiltered = 1 call to bsr_visible_filter.)  The backward's 48
+ * bytes per instance of partial sums live in the binning buffer the forward sized, over sections that are dead by
+ * then.  The library keeps no results between calls (per host thread: a pinned 16-byte HOST landing buffer, an
  * event and the previous call's shape / num_rendered as a size hint; plus the opt-in stage profiler); the three
  * scratch buffers handed from forward to backward are opaque, as in the reference
  * (__init__.py:97,106).
@@ -254,8 +259,14 @@ int bsr_backward_depth(int P, int D, int M, int R,
 /* Scratch sizes, for callers that pre-allocate instead of growing inside the callback
  * (the reference's required<T>(n), cuda_rasterizer/rasterizer_impl.h:68-73). */
 size_t bsr_geometry_bytes(int P);
-size_t bsr_binning_bytes(int num_rendered);
+size_t bsr_binning_bytes(int num_rendered);   /* 52 B / instance + 2 MB: point list, radix ping-pong buffers = backward slab */
 size_t bsr_image_bytes(int width, int height);
+
+/* Byte offset, inside the image buffer a forward call filled, of its float final_T[height * width] (the
+ * transmittance left at each pixel; alpha = 1 - final_T).  No reference counterpart: the reference keeps
+ * accum_alpha in its opaque ImageState (rasterizer_impl.h:45-53, forward.cu:459) and exposes no alpha output;
+ * used by the host's opt-in return_alpha extension. */
+size_t bsr_transmittance_offset(const void* image_buffer);
 
 /* ---- measurement hooks (no reference counterpart; used by bench.py only) ------------------
  * bsr_profile_enable(1) makes every kernel stage of subsequent calls be bracketed by hipEvents
