@@ -3,21 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Metric (BASELINE.json): Msplats/s forward+backward @ 1 M Gaussians, 1920x1080, SH degree 3
+Headline metric (BASELINE.json): Msplats/s forward+backward @ 1 M Gaussians, 1920x1080, SH degree 3
 (config C3, synthetic scene A of SURVEY.md §8d), colour + depth targets with upstream gradients.
 One "step" = one `GaussianRasterizer` forward + `torch.autograd.backward` through the C ABI, inputs
 resident in HBM.  N > 1: view-parallel -- rank 0 broadcasts the Gaussian buffers over RCCL once
 (outside the timed region), every rank then renders its own camera view; no data-path collective
 (weak scaling).  Rank 0 prints ONE JSON line with the bench contract keys plus
 
-  "roofline":     dominant kernel, ALGORITHMIC bytes per launch / mean launch time (hipEvents
-                  recorded by the library on the launch stream during the timed region) vs 8 TB/s
-  "cpu_baseline": the CPU oracle (a port of the reference algorithm, OpenMP) on the same workload,
-                  rank 0 at N = 1 only.
+  "roofline":     dominant kernel, ALGORITHMIC bytes per launch / mean launch time (hipEvents recorded by the
+                  library on the launch stream during the timed region) vs 8 TB/s; "traffic" = HBM bytes per
+                  launch from the committed rocprofv3 --pmc passes, only when those passes were taken on the
+                  same kernel sources as the library being timed ("traffic_source"), else null
+  "cpu_baseline": the CPU oracle (a port of the reference algorithm, OpenMP) on the same workload, N = 1 only
+  "c4":           BASELINE config C4 -- the 64-view rotate360 sweep of scene B (1 M Gaussians, forward only),
+                  STRONG-scaled over the N ranks after one packed RCCL broadcast: Msplats/s = 64 P / t with and
+                  without the broadcast, one view per native call (the reference's loop) and 16 per call
+  "secondary":    N = 1 only, never the headline: a dense scene A (long tile lists), BloomScene's real call shape
+                  (512^2, anchors x 10 through the fused expansion, colors_precomp, sh_degree 1) and the headline
+                  workload with the camera changing every step (the scratch-size guess of the forward misses).
 """
 from __future__ import annotations
 
 import argparse
+import gc
+import hashlib
 import json
 import math
 import os
@@ -58,85 +67,169 @@ def step_bytes(P, M, R, N, backward):
     return (187 + 12 * M) * P + 48 * R + 24 * N
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--gaussians", type=int, default=0, help="override P (experiments only)")
-    ap.add_argument("--colors", default="sh", choices=["sh", "precomp"],
-                    help="precomp: colors_precomp[P,3] instead of SHs, the call shape of the reference's render() "
-                         "(gaussian_renderer/__init__.py:254-262); experiments only, the metric is quoted on sh")
-    ap.add_argument("--allreduce-grads", action="store_true",
-                    help="N > 1 only: data-parallel training over views -- sum the per-view gradients with one "
-                         "packed RCCL all-reduce inside every step (SURVEY.md §8f rank 3); off by default, the "
-                         "metric's path has no data-path collective")
-    ap.add_argument("--depth-gradient", action="store_true",
-                    help="opt-in extension: also backpropagate the depth target (bsr_backward_depth); the metric "
-                         "is quoted without it (the reference ignores grad_depth)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
-    args = ap.parse_args()
+def csrc_sha256():
+    """Hash of the kernel sources the timed library is built from (csrc/*.hip, *.h, Makefile, include/*.h): what ties a
+    committed counter profile to a build.  (The .so itself is rebuilt on every box and never committed.)"""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "bloomscene_amd", "csrc")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".h")) or f == "Makefile")
+    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in bloomscene_amd)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    import torch.distributed as dist
-    # BSR_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL init, broadcast, barrier, all-reduce) with one rank
-    force_dist = os.environ.get("BSR_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
-    multi = world > 1 or force_dist
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+def measured_traffic(config, stage):
+    """(HBM bytes per launch, VALU instructions per SIMD and cycle, source) of `stage` from the committed rocprofv3 --pmc
+    passes (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as the
+    MI355X guide prescribes for wide coalesced reads on gfx950) -- or Nones when those passes were taken on other
+    kernel sources than the ones being timed now."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        src = {"profile": d.get("profile"), "csrc_sha256": d.get("csrc_sha256")}
+        if d.get("csrc_sha256") != csrc_sha256():
+            return None, None, dict(src, matches_timed_build=False)
+        e = d[config][stage]
+        return e.get("hbm_bytes"), e.get("valu_insts_per_simd_cycle"), dict(src, matches_timed_build=True)
+    except (OSError, KeyError, ValueError):
+        return None, None, None
 
-    from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
+
+class Dist:
+    """RANK / WORLD_SIZE plumbing; BSR_BENCH_FORCE_DIST=1 takes the N > 1 code path (RCCL init, broadcast, barrier,
+    all-reduce) with one rank."""
+
+    def __init__(self, gpus):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != gpus:
+            if self.world == 1 and gpus > 1:
+                raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback in bloomscene_amd)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.force = os.environ.get("BSR_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
+        self.multi = self.world > 1 or self.force
+        if self.multi:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+
+    def fence(self):
+        if self.multi:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.multi:
+            return x
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_ints(self, x):
+        if not self.multi:
+            return [int(x)]
+        import torch.distributed as dist
+        t = torch.tensor([int(x)], dtype=torch.int64, device=self.dev)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    def close(self):
+        if self.multi:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def timed_steps(D, step, steps, warmup, stage_events=True):
+    """The contract's timing: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
+    ranks.  Also one torch event per step (on the launch stream) for the median step time.  -> dict."""
+    from bloomscene_amd import _capi
+    for _ in range(warmup):
+        step()
+    D.fence()
+    gc.collect()
+    gc.disable()   # no collector pauses inside the timed region (the steps create no reference cycles)
+    # stage events on every 4th step of the timed region: each hipEvent costs a few microseconds of pipeline
+    # bubble, 14 per step were 3 % of the step; the per-launch means are over the sampled launches
+    sample_every = 4 if steps >= 8 else 1
+    _capi.profile_enable(sample_every if stage_events and os.environ.get("BSR_BENCH_NO_STAGE_EVENTS") != "1" else 0)
+    _capi.profile_reset()
+    allocs0 = torch.cuda.memory_stats(D.dev).get("num_device_alloc", 0)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    host_marks = []
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()
+        host_marks.append(time.perf_counter())
+    D.fence()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    device_allocs = torch.cuda.memory_stats(D.dev).get("num_device_alloc", 0) - allocs0
+    host_step_ms = [1e3 * (b - a) for a, b in zip([t0] + host_marks[:-1], host_marks)]
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    prof = _capi.profile_read()
+    _capi.profile_enable(False)
+    return {"seconds": D.max_over_ranks(dt), "median_ms": per_step[len(per_step) // 2], "prof": prof,
+            "device_allocs": int(device_allocs), "max_host_ms": max(host_step_ms)}
+
+
+def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0, cycle_views=1, steps=None, warmup=None,
+                    label="c3", allreduce=False, depth_gradient=False):
+    """fwd(+bwd) steps of the rasterizer on scene A; returns the measurements of this rank (rank 0's are printed)."""
+    from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer
     from bloomscene_amd.synthetic import scene_a, upstream_grads
     from bloomscene_amd.views import allreduce_gradients, broadcast_gaussians, yawed_camera
-
-    P, W, H, deg, do_bwd = CONFIGS[args.config]
-    if args.gaussians:
-        P = args.gaussians
-    precomp = args.colors == "precomp"
+    dev = D.dev
     if precomp:
         deg = 1   # the reference passes sh_degree=1 with shs=None (gaussian_renderer/__init__.py:244,257)
     M = 0 if precomp else (deg + 1) ** 2
     N = W * H
-
     # ---- inputs: generated on rank 0's host, broadcast over RCCL/xGMI, resident in HBM ----
     names = ("means3D", "scales", "rotations", "opacities", "shs")
-    if rank == 0:
+    if D.rank == 0:
         sc = scene_a(P, W, H, 0 if precomp else deg, seed=0)
         if precomp:
             sc.shs = torch.rand(P, 3, generator=torch.Generator().manual_seed(13))   # colours in [0, 1)
+        sc.scales = sc.scales * scale_mul
         bufs = {k: getattr(sc, k).to(dev) for k in names}
     else:
         shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1),
                   "shs": (P, 3) if precomp else (P, M, 3)}
         bufs = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in names}
-    bcast_ms = broadcast_gaussians(bufs, src=0, force=force_dist) if multi else 0.0
+    bcast_ms = broadcast_gaussians(bufs, src=0, force=D.force) if D.multi else 0.0
     gC, gD = upstream_grads(W, H, seed=1)
     gC, gD = gC.to(dev), gD.to(dev)
-    # independent views: rank r looks 0.25*r degrees to the side of the scene-A camera
-    cam = yawed_camera(W, H, math.radians(60.0), yaw_deg=0.25 * rank).to(dev)
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
-        bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
-        projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(settings, depth_gradient=args.depth_gradient)
+    # independent views: rank r looks 0.25*r degrees to the side of the scene-A camera; cycle_views > 1: the camera
+    # changes every step (+-1 degree steps), so the forward's scratch-size guess from the previous call can miss
+    yaws = [0.25 * D.rank + (1.0 * k if cycle_views > 1 else 0.0) for k in range(cycle_views)]
+    rasterizers = []
+    for y in yaws:
+        cam = yawed_camera(W, H, math.radians(60.0), yaw_deg=y).to(dev)
+        st = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+            bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+        rasterizers.append(GaussianRasterizer(st, depth_gradient=depth_gradient))
     leaves = {k: v.requires_grad_(do_bwd) for k, v in bufs.items()}
-    state = {}
+    state = {"i": 0}
 
     def step():
+        rasterizer = rasterizers[state["i"] % len(rasterizers)]
+        state["i"] += 1
         means2D = torch.zeros_like(leaves["means3D"], requires_grad=do_bwd)
         color, radii, depth = rasterizer(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
                                          shs=None if precomp else leaves["shs"],
@@ -146,122 +239,234 @@ def main():
             for v in leaves.values():
                 v.grad = None
             torch.autograd.backward((color, depth), (gC, gD))
-            if args.allreduce_grads and multi:
-                state["allreduce_ms"] = state.get("allreduce_ms", 0.0) + allreduce_gradients(leaves, force=force_dist)
+            if allreduce and D.multi:
+                state["allreduce_ms"] = state.get("allreduce_ms", 0.0) + allreduce_gradients(leaves, force=D.force)
         state["radii"] = radii
 
-    def fence():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    import gc
-    gc.collect()
-    gc.disable()   # no collector pauses inside the timed region (the steps create no reference cycles)
-    # stage events on every 4th step of the timed region: each hipEvent costs a few microseconds of pipeline
-    # bubble, 14 per step were 3 % of the step; the per-launch means below are over the sampled launches
-    sample_every = 4 if args.steps >= 8 else 1
-    _capi.profile_enable(0 if os.environ.get("BSR_BENCH_NO_STAGE_EVENTS") == "1" else sample_every)
-    _capi.profile_reset()
-    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    host_marks = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        host_marks.append(time.perf_counter())
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    # diagnostics: hipMalloc calls inside the timed region (0 in steady state) and the slowest host-side step
-    device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
-    host_step_ms = [1e3 * (b - a) for a, b in zip([t0] + host_marks[:-1], host_marks)]
-    if os.environ.get("BSR_BENCH_STEP_TIMES") == "1":
-        print("host ms per step:", " ".join("%.2f" % v for v in host_step_ms), file=sys.stderr)
-    prof = _capi.profile_read()
-    _capi.profile_enable(False)
-
-    if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # instances of this rank's view, for the algorithmic byte count
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    tm = timed_steps(D, step, steps, warmup)
+    # instances of this rank's first view, for the algorithmic byte count
     from bloomscene_amd.rasterizer import _rasterize_gaussians_native
     e = torch.Tensor([])
+    s0 = rasterizers[0].raster_settings
     with torch.no_grad():
-        R = _rasterize_gaussians_native(settings.bg, bufs["means3D"], bufs["shs"] if precomp else e,
-                                        bufs["opacities"], bufs["scales"], bufs["rotations"], 1.0, e,
-                                        settings.viewmatrix, settings.projmatrix, settings.tanfovx, settings.tanfovy,
-                                        H, W, e if precomp else bufs["shs"], deg, settings.campos, False, False)[0]
+        R = _rasterize_gaussians_native(s0.bg, bufs["means3D"], bufs["shs"] if precomp else e, bufs["opacities"],
+                                        bufs["scales"], bufs["rotations"], 1.0, e, s0.viewmatrix, s0.projmatrix,
+                                        s0.tanfovx, s0.tanfovy, H, W, e if precomp else bufs["shs"], deg, s0.campos,
+                                        False, False)[0]
     visible = int((state["radii"] > 0).sum().item())
+    ms_per_step = tm["seconds"] / steps * 1e3
+    stages = {k: v[0] / max(v[1], 1) for k, v in tm["prof"].items()}  # mean ms per launch
+    alg = algorithmic_bytes(P, M, R, N)
+    if precomp:   # 12 B/G of colours read by preprocess, 12 B/G of colour gradient passed through
+        alg["preprocess"] += 12 * P
+        alg["preprocess_bwd"] += 24 * P
+    sb = step_bytes(P, M, R, N, do_bwd) + (36 * P if precomp and do_bwd else 12 * P if precomp else 0)
+    res = {"value": D.world * P * steps / tm["seconds"] / 1e6, "ms_per_step": ms_per_step,
+           "ms_per_step_median": tm["median_ms"], "steps": steps, "warmup": warmup, "stages": stages, "alg": alg,
+           "prof": tm["prof"], "R": R, "visible": visible, "step_bytes": sb, "bcast_ms": bcast_ms, "M": M, "deg": deg,
+           "device_allocs": tm["device_allocs"], "max_host_ms": tm["max_host_ms"],
+           "allreduce_ms_per_step": state.get("allreduce_ms", 0.0) / max(steps + warmup, 1),
+           "workload": f"{label}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
+                       f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
+                       f"{' WITH depth gradient (extension)' if depth_gradient and do_bwd else ''}, synthetic scene A seed 0"
+                       + (f", all scales x{scale_mul:g}" if scale_mul != 1.0 else "")
+                       + (f", camera changes every step ({cycle_views} views, 1 degree apart)" if cycle_views > 1 else "")}
+    del leaves, bufs, rasterizers
+    torch.cuda.empty_cache()
+    return res
 
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * P * args.steps / dt / 1e6
-        stages = {k: v[0] / max(v[1], 1) for k, v in prof.items()}  # mean ms per launch
-        alg = algorithmic_bytes(P, M, R, N)
-        if precomp:   # 12 B/G of colours read by preprocess, 12 B/G of colour gradient passed through
-            alg["preprocess"] += 12 * P
-            alg["preprocess_bwd"] += 24 * P
+
+def secondary_line(r):
+    """Compact record of a non-headline workload."""
+    whole = r["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9
+    return {"workload": r["workload"], "value": round(r["value"], 2), "unit": "Msplats/s",
+            "ms_per_step": round(r["ms_per_step"], 4), "ms_per_step_median": round(r["ms_per_step_median"], 4),
+            "steps": r["steps"], "num_rendered": r["R"], "instances_per_gaussian": round(r["R"] / max(r["visible"], 1), 2),
+            "roofline_step_frac": round(whole / HBM_PEAK_GBS, 5),
+            "stage_ms": {k: round(v, 4) for k, v in r["stages"].items()},
+            "device_allocs_in_timed_region": r["device_allocs"]}
+
+
+def bloomscene_shape_workload(D, args, n_anchor=100_000, n_offsets=10, W=512, H=512):
+    """BloomScene's real call shape (arguments.py:8,102; gaussian_renderer/__init__.py:165-203,244-262): anchors x 10
+    candidate Gaussians through the fused anchor expansion into the rasterizer with colors_precomp and sh_degree = 1,
+    512 x 512, forward + backward w.r.t. all six head outputs.  Msplats/s counts the SELECTED Gaussians."""
+    from bloomscene_amd import views
+    from bloomscene_amd.synthetic import anchor_scene, upstream_grads
+    dev = D.dev
+    sc = anchor_scene(n_anchor, n_offsets, W, H, seed=0)
+    cam = sc.camera.to(dev)
+    names = ("anchor", "grid_scaling", "grid_offsets", "neural_opacity", "color", "scale_rot")
+    leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in names}
+    gC, gD = upstream_grads(W, H, seed=1)
+    gC, gD = gC.to(dev), gD.to(dev)
+    bg = torch.zeros(3, device=dev)
+    state = {}
+
+    def step():
+        for v in leaves.values():
+            v.grad = None
+        res = views.render_neural(cam, *[leaves[k] for k in names], bg)
+        torch.autograd.backward((res["render"], res["depth"]), (gC, gD))
+        state["radii"] = res["radii"]
+
+    steps = max(20, args.steps // 2)
+    tm = timed_steps(D, step, steps, max(3, args.warmup // 2))
+    S = int(state["radii"].numel())
+    ms = tm["seconds"] / steps * 1e3
+    return {"workload": f"bloomscene-shaped: {n_anchor} anchors x {n_offsets} offsets -> {S} selected Gaussians, fused "
+                        f"expansion + rasterizer (colors_precomp, sh_degree 1), {W}x{H}, fwd+bwd to the six head outputs",
+            "value": round(S * steps / tm["seconds"] / 1e6, 2), "unit": "Msplats/s (selected Gaussians)",
+            "ms_per_step": round(ms, 4), "ms_per_step_median": round(tm["median_ms"], 4), "steps": steps,
+            "visible": int((state["radii"] > 0).sum().item()),
+            "stage_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in tm["prof"].items()},
+            "device_allocs_in_timed_region": tm["device_allocs"]}
+
+
+def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5):
+    """BASELINE config C4: the rotate360 sweep (bloomscene.py:191-193) of scene B, forward only, views dealt round-robin
+    to the ranks (STRONG scaling: the 64 views are fixed) after ONE packed RCCL broadcast of the Gaussian buffers."""
+    from bloomscene_amd import views
+    from bloomscene_amd.synthetic import scene_b
+    dev = D.dev
+    M = (deg + 1) ** 2
+    names = ("means3D", "scales", "rotations", "opacities", "shs")
+    sc = scene_b(P if D.rank == 0 else 1, W, H, deg, n_views=n_views, seed=0)   # cameras on every rank
+    if D.rank == 0:
+        bufs = {k: getattr(sc, k).to(dev) for k in names}
+    else:
+        shapes = {"means3D": (P, 3), "scales": (P, 3), "rotations": (P, 4), "opacities": (P, 1), "shs": (P, M, 3)}
+        bufs = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in names}
+    D.fence()
+    t0 = time.perf_counter()
+    views.broadcast_gaussians(bufs, src=0, force=D.force) if D.multi else None
+    D.fence()
+    bcast_s = D.max_over_ranks(time.perf_counter() - t0) if D.multi else 0.0
+    bg = torch.zeros(3, device=dev)
+    cams = [c.to(dev) for c in sc.cameras]
+    mine = views.shard_views(len(cams), D.rank, D.world)
+    out = {"workload": f"c4: {P} Gaussians scene B, SH deg {deg}, {W}x{H}, {n_views}-view rotate360 sweep, fwd only, "
+                       f"views round-robin over {D.world} rank(s) after one packed RCCL broadcast",
+           "scaling": "strong", "n_gpus": D.world, "views": n_views, "views_per_rank": D.gather_ints(len(mine)),
+           "broadcast_ms": round(bcast_s * 1e3, 3), "broadcast_bytes": int(sum(v.numel() for v in bufs.values()) * 4),
+           "unit": "Msplats/s"}
+    with torch.no_grad():
+        res = views.render_view(cams[mine[0]], bufs, bg, deg)
+        out["visible_first_view_rank0"] = int(res["visibility_filter"].sum().item())
+    for batch in (1, 16):
+        def sweep():
+            return views.render_views_sharded(cams, bufs, bg, deg, rank=D.rank, world=D.world, batch=batch)
+        sweep()   # warm-up (allocator, first touch, size hints)
+        times = []
+        for _ in range(repeats):
+            D.fence()
+            t0 = time.perf_counter()
+            sweep()
+            D.fence()
+            times.append(D.max_over_ranks(time.perf_counter() - t0))
+        t = sorted(times)[len(times) // 2]
+        out[f"views_per_call_{batch}"] = {
+            "sweep_ms": round(t * 1e3, 3), "ms_per_view_per_rank": round(t / max(len(mine), 1) * 1e3, 4),
+            "value": round(n_views * P / t / 1e6, 1),
+            "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1)}
+    del bufs
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--gaussians", type=int, default=0, help="override P (experiments only)")
+    ap.add_argument("--colors", default="sh", choices=["sh", "precomp"],
+                    help="precomp: colors_precomp[P,3] instead of SHs, the call shape of the reference's render() "
+                         "(gaussian_renderer/__init__.py:254-262); experiments only, the metric is quoted on sh")
+    ap.add_argument("--scale-mul", type=float, default=1.0, help="multiply every scale (denser tile lists); experiments only")
+    ap.add_argument("--cycle-views", type=int, default=1, help="change the camera every step among this many views")
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="data-parallel training over views -- sum the per-view gradients with one packed RCCL all-reduce "
+                         "inside every step (SURVEY.md §8f rank 3); off by default, the metric's path has no data-path "
+                         "collective")
+    ap.add_argument("--depth-gradient", action="store_true",
+                    help="opt-in extension: also backpropagate the depth target (bsr_backward_depth); the metric "
+                         "is quoted without it (the reference ignores grad_depth)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4 rotate360 sweep leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (N = 1) workloads")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    D = Dist(args.gpus)
+    P, W, H, deg, do_bwd = CONFIGS[args.config]
+    if args.gaussians:
+        P = args.gaussians
+    precomp = args.colors == "precomp"
+    headline = (args.config == "c3" and not precomp and not args.gaussians and not args.depth_gradient
+                and not args.allreduce_grads and args.scale_mul == 1.0 and args.cycle_views == 1)
+    r = raster_workload(D, args, P, W, H, deg, do_bwd, precomp=precomp, scale_mul=args.scale_mul,
+                        cycle_views=args.cycle_views, label=args.config, allreduce=args.allreduce_grads,
+                        depth_gradient=args.depth_gradient)
+    c4 = None if args.no_c4 else c4_sweep(D, args)
+    secondary = None
+    if D.world == 1 and headline and not args.no_secondary:
+        sec_steps = max(20, args.steps // 2)
+        secondary = {
+            "c3_dense_scales_x3": secondary_line(raster_workload(D, args, P, W, H, deg, True, scale_mul=3.0, steps=sec_steps,
+                                                                 label="c3-dense")),
+            "c3_camera_changes_every_step": secondary_line(raster_workload(D, args, P, W, H, deg, True, cycle_views=8,
+                                                                           steps=sec_steps, label="c3-cycling")),
+            "bloomscene_shape": bloomscene_shape_workload(D, args),
+        }
+
+    if D.rank == 0:
+        stages, alg = r["stages"], r["alg"]
         dom = max(stages, key=lambda k: stages[k]) if stages else None
         roofline = None
         if dom is not None:
             achieved = alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9
+            traffic, valu, src = measured_traffic(args.config, dom) if headline else (None, None, None)
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                        "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4),
-                        "launches_timed": int(prof[dom][1])}
-        if roofline is not None:
-            roofline["traffic"] = measured_traffic(args.config, dom)
-            # what actually bounds the tile renderers (from the same committed PMC passes): VALU instructions
-            # issued per SIMD and core-clock cycle; ~0.29 with this instruction mix is a saturated VALU port
-            roofline["valu_insts_per_simd_cycle"] = measured_traffic(args.config, dom, "valu_insts_per_simd_cycle")
-        sb = step_bytes(P, M, R, N, do_bwd) + (36 * P if precomp and do_bwd else 12 * P if precomp else 0)
-        whole = sb / (ms_per_step * 1e-3) / 1e9
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": src, "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4),
+                        "launches_timed": int(r["prof"][dom][1]),
+                        # what actually bounds the tile renderers (same committed PMC passes): VALU instructions
+                        # issued per SIMD and core-clock cycle
+                        "valu_insts_per_simd_cycle": valu}
+        whole = r["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9
         out = {
-            "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline"
-            if args.config == "c3" and not precomp and not args.gaussians and not args.depth_gradient
-            and not args.allreduce_grads
+            "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if headline
             else f"Msplats/s ({args.config})",
-            "value": round(value, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "value": round(r["value"], 3), "unit": "Msplats/s", "n_gpus": D.world, "steps": r["steps"],
+            "warmup": r["warmup"], "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
-                                   f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
-                                   f"{' WITH depth gradient (extension)' if args.depth_gradient and do_bwd else ''}, synthetic scene A seed 0",
-                       "gaussians": P, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
-                       "visible": visible,
-                       "parallelism": f"view-parallel x{world}" + (" + gradient all-reduce" if args.allreduce_grads
-                                                                    and world > 1 and do_bwd else ""),
-                       "broadcast_ms": round(bcast_ms, 3)},
+            "config": {"workload": r["workload"], "gaussians": P, "width": W, "height": H, "sh_degree": r["deg"],
+                       "num_rendered": r["R"], "visible": r["visible"],
+                       "parallelism": f"view-parallel x{D.world}" + (" + gradient all-reduce" if args.allreduce_grads
+                                                                      and D.multi and do_bwd else ""),
+                       "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256()},
+            "ms_per_step_median": round(r["ms_per_step_median"], 4),
             "roofline": roofline,
-            "roofline_step": {"algorithmic_bytes": sb, "achieved": round(whole, 2),
+            "roofline_step": {"algorithmic_bytes": r["step_bytes"], "achieved": round(whole, 2),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-            "host": {"device_allocs_in_timed_region": int(device_allocs),
-                     "max_host_ms_per_step": round(max(host_step_ms), 3)},
+            "host": {"device_allocs_in_timed_region": r["device_allocs"],
+                     "max_host_ms_per_step": round(r["max_host_ms"], 3)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, P, W, H, deg, do_bwd, precomp)
+        if args.allreduce_grads and D.multi:
+            out["config"]["allreduce_ms_per_step"] = round(r["allreduce_ms_per_step"], 4)
+        if c4 is not None:
+            out["c4"] = c4
+        if secondary is not None:
+            out["secondary"] = secondary
+        if D.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, P, W, H, r["deg"], do_bwd, precomp)
         print(json.dumps(out), flush=True)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def measured_traffic(config, stage, key="hbm_bytes"):
-    """HBM bytes per launch of `stage` from the committed rocprofv3 --pmc passes of this workload
-    (profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE
-    doubled as the MI355X guide prescribes for wide coalesced reads on gfx950), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)[config][stage][key]
-    except (OSError, KeyError, ValueError):
-        return None
+    D.close()
 
 
 def cpu_baseline(args, P, W, H, deg, do_bwd, precomp=False):
@@ -280,7 +485,7 @@ def cpu_baseline(args, P, W, H, deg, do_bwd, precomp=False):
     O.lib()
     t0 = time.perf_counter()
     st = O.forward(rs, sc.means3D, sc.opacities, shs=None if precomp else sc.shs, colors_precomp=col,
-                   scales=sc.scales, rotations=sc.rotations)
+                   scales=sc.scales * args.scale_mul, rotations=sc.rotations)
     if do_bwd:
         O.backward(st, gC, gD)
     dt = time.perf_counter() - t0

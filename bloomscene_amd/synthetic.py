@@ -53,6 +53,32 @@ def scene_b(P, width, height, sh_degree, n_views=64, seed=0, fovx_deg=60.0):
                            sh_degree=sh_degree, cameras=cams, width=width, height=height)
 
 
+def anchor_scene(n_anchor, n_offsets, width, height, seed=0, fovx_deg=60.0, keep_fraction=0.5):
+    """BloomScene-shaped input (Scaffold-GS anchors, gaussian_renderer/__init__.py:165-203): ``n_anchor`` anchors spread
+    through the frustum of the scene-A camera with ``n_offsets`` candidate Gaussians each; the MLP-head outputs are
+    seeded noise with about ``keep_fraction`` of the candidates selected (positive opacity).  Returns the camera and
+    the six tensors ``neural_gaussians.expand_anchors`` / ``views.render_neural`` take."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    cam = identity_camera(width, height, math.radians(fovx_deg))
+    tanfovx, tanfovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    z = torch.rand(n_anchor, generator=g) * 9.0 + 1.0
+    ndc = torch.rand(n_anchor, 2, generator=g) * 2.0 - 1.0
+    anchor = torch.stack([ndc[:, 0] * z * tanfovx, ndc[:, 1] * z * tanfovy, z], dim=1).contiguous()
+    # columns 0-2 scale the offsets (voxel size), 3-5 the Gaussians (screen sigma of roughly 0.5..5 px at 512^2)
+    lo, hi = math.log(1e-3), math.log(1e-2)
+    voxel = torch.exp(torch.rand(n_anchor, 3, generator=g) * (hi - lo) + lo) * z[:, None] * 2.0
+    gs = torch.exp(torch.rand(n_anchor, 3, generator=g) * (hi - lo) + lo) * z[:, None]
+    grid_scaling = torch.cat([voxel, gs], dim=1).contiguous()
+    n = n_anchor * n_offsets
+    grid_offsets = torch.randn(n_anchor, n_offsets, 3, generator=g)
+    op = torch.tanh(torch.randn(n, 1, generator=g)).abs() + 1e-3
+    neural_opacity = torch.where(torch.rand(n, 1, generator=g) < keep_fraction, op, -op)
+    color = torch.rand(n, 3, generator=g)
+    scale_rot = torch.randn(n, 7, generator=g) * 1.5
+    return SimpleNamespace(camera=cam, anchor=anchor, grid_scaling=grid_scaling, grid_offsets=grid_offsets,
+                           neural_opacity=neural_opacity, color=color, scale_rot=scale_rot, width=width, height=height)
+
+
 def upstream_grads(width, height, seed=1):
     g = torch.Generator(device="cpu").manual_seed(seed)
     gC = torch.randn(3, height, width, generator=g)

@@ -67,3 +67,4 @@ def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
         ref = getattr(og, k)
         assert np.isfinite(got[k]).all(), k
         assert Hh.max_err_over_scale(got[k], ref) < 1e-5, k
+

@@ -6,9 +6,15 @@ FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes and FETCH
 `roofline.traffic`.
 
     python tools/pmc_traffic.py profiles/<round>/pmc_summary.json [config] > profiles/pmc_traffic.json
+
+Run it in the same tree the passes were taken on: the output records `csrc_sha256`, the hash of the kernel sources
+(bench.csrc_sha256), and bench.py reports `roofline.traffic` only while that hash matches the library it is timing.
 """
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 STAGE_OF = {   # kernel name prefix (template arguments stripped) -> bench stage
     "bsr::k_preprocess_bwd": "preprocess_bwd", "bsr::k_preprocess": "preprocess", "bsr::k_scans": "scan_wg", "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
@@ -45,7 +51,10 @@ def main():
         st["read_bytes_2xFETCH_SIZE"] += int(rd)
         st["write_bytes"] += int(wr)
         st["profiled_us"] = round(st["profiled_us"] + r.get("dur_us(profiled)", 0.0) * mult, 1)
+    from bench import csrc_sha256
     out = {config: stages,
+           "profile": os.path.basename(os.path.dirname(os.path.abspath(src))),
+           "csrc_sha256": csrc_sha256(),
            "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 3 "
                     "--warmup 1` (config " + config + ") on MI355X; bytes per launch = mean over launches, summed "
                     "over the kernels of a stage; read bytes = 2 x FETCH_SIZE KiB (gfx950 reports half of wide "

@@ -9,7 +9,7 @@ import bench  # noqa: E402
 
 for P in (1_000_000, 2_000_000, 3_000_000, 5_000_000):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--gaussians", str(P),
-                          "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], capture_output=True, text=True)
+                          "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-c4"], capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(json.dumps({"gaussians": P, "error": out.stderr[-300:]}))
