@@ -152,7 +152,9 @@ __device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ 
 	return off + kept_rank(w * h, mask, k);
 }
 
-#define BSR_BWD_BATCH 128
+#ifndef BSR_BWD_BATCH
+#define BSR_BWD_BATCH 128   // entries staged per batch (occupancy sweep: make batch BATCH=64|256, tools/sweep_occupancy.sh)
+#endif
 #ifndef BSR_BWD_PAD
 #define BSR_BWD_PAD 1
 #endif
@@ -441,11 +443,12 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
+	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_BWD");
 	if (out_depth && dL_depths)
-		hipLaunchKernelGGL(k_render_bwd<true>, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start,
+		hipLaunchKernelGGL(k_render_bwd<true>, dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,
 		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, out_depth, dL_depths, slab);
 	else
-		hipLaunchKernelGGL(k_render_bwd<false>, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, W, H, tile_start,
+		hipLaunchKernelGGL(k_render_bwd<false>, dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,
 		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, nullptr, nullptr, slab);
 }
 

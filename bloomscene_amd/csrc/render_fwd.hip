@@ -153,7 +153,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 {
 	const int n_tiles = gx * gy * n_views;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
-	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), 0, s, n_tiles, gx, gy, W, H, n_ptr, capacity, tile_start,
+	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD"), s, n_tiles, gx, gy, W, H, n_ptr, capacity, tile_start,
 	                   point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 

@@ -2,8 +2,18 @@
 // the ballot/prefix-scan compaction of a staged batch into one ordered list per wave.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace bsr {
+
+// Measurement hook of the occupancy sweep (BASELINE config C5: "LDS-tile occupancy + rocprof HBM-GB/s sweep",
+// tools/sweep_occupancy.sh): extra dynamic LDS bytes per workgroup of a tile renderer, unused by the kernel, which
+// only lowers the number of workgroups a CU can hold.  Read once from the environment; 0 (unset) in normal use.
+static inline unsigned occupancy_sweep_lds_pad(const char* env_name)
+{
+	const char* v = getenv(env_name);
+	return v ? (unsigned)strtoul(v, nullptr, 10) : 0u;
+}
 
 // Can the splat reach alpha >= 1/255 at ANY point of an axis-aligned box of pixel centres
 // [bx, bx+EXT] x [by, by+EXT]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with

@@ -1,25 +1,35 @@
 #!/bin/bash
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh <tag>
-# Produces gpurun_out/<tag>/: bench JSON lines, rocprofv3 kernel stats, PMC passes, test log.
+# Produces gpurun_out/<tag>/: bench JSON lines, rocprofv3 kernel stats, PMC passes (C3 and C5), walk statistics,
+# parity report, test log.  Copy what is to be judged into profiles/<tag>/.
 set -u
 TAG=${1:-prof}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; tail -1 "$OUT/pytest_gpu.log"
+python -m pytest tests -m gpu -q -s > "$OUT/pytest_gpu.log" 2>&1; tail -1 "$OUT/pytest_gpu.log"
 python bench.py 2> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3.json"
-python bench.py --config c2 --steps 50 --warmup 10 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
-python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
-python bench.py --colors precomp --steps 20 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_precomp_colors.json"
-python bench.py --depth-gradient --steps 20 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_depth_gradient.json"
-python tools/bench_views.py 2>/dev/null | tail -1 > "$OUT/bench_c4_views_1gpu.json"
-python tools/bench_views.py --batch 16 2>/dev/null | tail -1 > "$OUT/bench_c4_views_1gpu_batch16.json"
+python bench.py --config c2 --steps 100 --warmup 10 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
+python bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
+python bench.py --colors precomp --steps 50 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_precomp_colors.json"
+python bench.py --depth-gradient --steps 50 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_depth_gradient.json"
 python tools/bench_anchors.py 2>/dev/null | tail -1 > "$OUT/bench_anchors.json"
 python tools/sweep_c5.py 2>/dev/null > "$OUT/sweep_c5.jsonl"
+python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp > "$OUT/parity_report.jsonl" 2>/dev/null
+if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then
+  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py 2>/dev/null | tail -1 > "$OUT/walk_stats_c3.json"
+  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"
+  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py --config c5 2>/dev/null | tail -1 > "$OUT/walk_stats_c5.json"
+fi
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-secondary > "$OUT/bench_under_rocprof.log" 2>&1 )
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace_anchors" -- python3 "$ROOT/tools/bench_anchors.py" --steps 10 > "$OUT/bench_anchors_under_rocprof.log" 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace_c5" -- python3 "$ROOT/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 > "$OUT/bench_c5_under_rocprof.log" 2>&1 )
 bash tools/pmc_passes.sh "gpurun_out/$TAG/pmc" > /dev/null 2>&1
 python tools/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.json"
 python tools/pmc_traffic.py "gpurun_out/$TAG/pmc_summary.json" > "$OUT/pmc_traffic.json"
+bash tools/pmc_passes.sh "gpurun_out/$TAG/pmc_c5" --config c5 > /dev/null 2>&1
+python tools/pmc_summary.py "$OUT/pmc_c5" > "$OUT/pmc_summary_c5.json"
+for d in kernel_trace kernel_trace_c5; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d/kernel_trace/kernel_stats}.csv"; done
+# keep the merged-back payload small: the raw per-dispatch CSVs stay on the box
+find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
 cut -c1-300 "$OUT/bench_c3.json"

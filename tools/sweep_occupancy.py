@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""One JSON line per point of tools/sweep_occupancy.sh: stage times of the two tile renderers at C5, the workgroups per
+CU the point allows, measured HBM traffic and GB/s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE doubled as the
+MI355X guide prescribes for gfx950), VALU instructions per SIMD and cycle, share of wave-cycles spent waiting."""
+import json
+import os
+import sys
+
+LDS_CU = 163840
+STATIC = {"fwd": 16464, "bwd": {64: 13536, 128: 26848, 256: 53472}}
+
+
+def wg_per_cu(static, pad, vgpr_waves=8):
+    return min(LDS_CU // (static + pad), 8, vgpr_waves)
+
+
+def main():
+    root = sys.argv[1]
+    for name in sorted(os.listdir(root)):
+        d = os.path.join(root, name)
+        try:
+            b = json.loads(open(os.path.join(d, "bench.json")).read())
+            pmc = json.load(open(os.path.join(d, "pmc_summary.json")))
+        except (OSError, ValueError):
+            continue
+        batch = 64 if "batch64" in name else 256 if "batch256" in name else 128
+        pad = {"fwd": 0, "bwd": 0}
+        for part in name.split("_"):
+            pass
+        rec = {"point": name, "bwd_batch": batch, "ms_per_step": b["ms_per_step"], "Msplats_per_s": b["value"],
+               "stage_ms": {k: b["stage_ms"][k] for k in ("render_fwd", "render_bwd")}}
+        for key, kern in (("render_fwd", "bsr::k_render_fwd"), ("render_bwd", "bsr::k_render_bwd<false>")):
+            r = pmc.get(kern)
+            if not r:
+                continue
+            us = r.get("dur_us(profiled)", 0.0)
+            rd, wr = 2.0 * r.get("FETCH_SIZE", 0.0) * 1024, r.get("WRITE_SIZE", 0.0) * 1024
+            cyc = r.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            rec[key] = {"profiled_us": round(us, 1), "hbm_MB": round((rd + wr) / 1e6, 1),
+                        "hbm_GBps": round((rd + wr) / us / 1e3, 1) if us else None,
+                        "waves": int(r.get("SQ_WAVES", 0)),
+                        "mean_waves_per_simd": round(r.get("SQ_WAVE_CYCLES", 0.0) * 4 / (1024 * cyc), 2) if cyc else None,
+                        "valu_insts_per_simd_cycle": round(r.get("SQ_INSTS_VALU", 0.0) / (1024 * cyc), 4) if cyc else None,
+                        "wait_share": round((r.get("SQ_WAIT_ANY", 0.0) + r.get("SQ_WAIT_INST_ANY", 0.0)) / max(r.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)}
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
