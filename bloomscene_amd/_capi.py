@@ -40,6 +40,10 @@ SIGNATURES = {
                                     C.c_void_p, C.POINTER(C.c_int)]),
     "bsr_visible_filter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                      C.c_float, C.c_float, C.c_int, _F, C.c_int, C.c_void_p]),
+    "bsr_visible_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "bsr_visible_filter_indices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
+                                             C.c_float, C.c_float, C.c_int, _F, _F, _F, C.POINTER(C.c_int), C.c_int,
+                                             C.c_void_p]),
     "bsr_visible_filter_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                            C.c_float, C.c_float, _F, C.c_int, C.c_void_p]),
     "bsr_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,

@@ -12,6 +12,7 @@
 // sums are an LDS reduction in slot order -- no atomics, deterministic.
 #include "common.h"
 #include "../../include/bloomscene_anchors.h"
+#include "../../include/bloomscene_rast.h"
 
 namespace bsr {
 
@@ -96,6 +97,30 @@ __global__ void __launch_bounds__(1024) k_anchor_scan(int n, uint32_t* __restric
 		__syncthreads();
 	}
 	if (t == 0) wg_count[n] = s_carry;
+}
+
+// ---- index list of the visible points (bsr_visible_filter_indices, SURVEY.md §8f rank 2, training half) ----
+// radii > 0 per workgroup of 256 points -> counts; k_anchor_scan; ordered write of the indices.
+__global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_visible_count(int P, const int* __restrict__ radii,
+                                                                    uint32_t* __restrict__ wg_count)
+{
+	__shared__ uint32_t s_wave[BSR_ANCHOR_BLOCK / 64];
+	const long long i = (long long)blockIdx.x * BSR_ANCHOR_BLOCK + threadIdx.x;
+	uint32_t total;
+	wg_prefix(i < P && radii[i] > 0, s_wave, total);
+	if (threadIdx.x == 0) wg_count[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_visible_compact(int P, const int* __restrict__ radii,
+                                                                      const uint32_t* __restrict__ wg_base,
+                                                                      int* __restrict__ visible_idx)
+{
+	__shared__ uint32_t s_wave[BSR_ANCHOR_BLOCK / 64];
+	const long long i = (long long)blockIdx.x * BSR_ANCHOR_BLOCK + threadIdx.x;
+	const bool vis = i < P && radii[i] > 0;
+	uint32_t total;
+	const uint32_t rank = wg_prefix(vis, s_wave, total);
+	if (vis) visible_idx[wg_base[blockIdx.x] + rank] = (int)i;
 }
 
 // torch.sigmoid in fp32: 1 / (1 + exp(-x))
@@ -241,6 +266,40 @@ inline bool make_partition(int N, int K, Partition* p)
 }  // namespace
 
 extern "C" {
+
+size_t bsr_visible_scratch_bytes(int P)
+{
+	const size_t n_wg = ((size_t)(P > 0 ? P : 0) + BSR_ANCHOR_BLOCK - 1) / BSR_ANCHOR_BLOCK;
+	return align_up((n_wg + 1) * sizeof(uint32_t), 256);
+}
+
+int bsr_visible_filter_indices(int P, int M, int width, int height, const float* means3D, const float* scales,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                               const float* viewmatrix, const float* projmatrix, float tan_fovx, float tan_fovy,
+                               int prefiltered, int* radii, int* visible_idx, void* scratch, int* num_visible, int debug,
+                               void* stream)
+{
+	if (!num_visible) return fail("bsr_visible_filter_indices: num_visible is NULL");
+	*num_visible = 0;
+	const int rc = bsr_visible_filter(P, M, width, height, means3D, scales, scale_modifier, rotations, cov3D_precomp,
+	                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, prefiltered, radii, debug, stream);
+	if (rc != 0 || P == 0) return rc;
+	if (!visible_idx || !scratch) return fail("bsr_visible_filter_indices: NULL buffer");
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t* wg = (uint32_t*)scratch;
+	const int n_wg = (P + BSR_ANCHOR_BLOCK - 1) / BSR_ANCHOR_BLOCK;
+	hipLaunchKernelGGL(k_visible_count, dim3(n_wg), dim3(BSR_ANCHOR_BLOCK), 0, s, P, radii, wg);
+	hipLaunchKernelGGL(k_anchor_scan, dim3(1), dim3(1024), 0, s, n_wg, wg);
+	hipLaunchKernelGGL(k_visible_compact, dim3(n_wg), dim3(BSR_ANCHOR_BLOCK), 0, s, P, radii, wg, visible_idx);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return fail("bsr_visible_filter_indices: launch failed: %s", hipGetErrorString(e));
+	uint32_t total = 0;
+	e = hipMemcpyAsync(&total, wg + n_wg, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+	if (e == hipSuccess) e = hipStreamSynchronize(s);
+	if (e != hipSuccess) return fail("bsr_visible_filter_indices: reading the count failed: %s", hipGetErrorString(e));
+	*num_visible = (int)total;
+	return 0;
+}
 
 size_t bsr_anchor_scratch_bytes(int n_anchors, int n_offsets)
 {

@@ -251,6 +251,35 @@ def _rasterize_gaussians_filter_native(means3D, scales, rotations, scale_modifie
     return radii
 
 
+def _rasterize_gaussians_filter_indices_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                               projmatrix, tan_fovx, tan_fovy, image_height, image_width, prefiltered,
+                                               debug):
+    """visible_filter plus the ascending index list of the visible points (bsr_visible_filter_indices):
+    -> (radii int32 [P], visible_idx int64 [n_visible])."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P = means3D.size(0)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    idx = torch.empty((P,), dtype=torch.int32, device=dev)
+    n = C.c_int(0)
+    if P != 0:
+        lib = _capi.lib()
+        m = _dev_f32(means3D, "means3D", dev)
+        s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)
+        c = _dev_f32(cov3D_precomp, "cov3D_precomp", dev)
+        v, p = _dev_f32(viewmatrix, "viewmatrix", dev), _dev_f32(projmatrix, "projmatrix", dev)
+        scratch = torch.empty(lib.bsr_visible_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.bsr_visible_filter_indices(
+                P, 0, int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier), _ptr(r),
+                _ptr(c), v.data_ptr(), p.data_ptr(), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                radii.data_ptr(), idx.data_ptr(), scratch.data_ptr(), C.byref(n), int(bool(debug)), _stream_handle(dev))
+        _capi.check(rc, "rasterize_gaussians_filter_indices")
+    return radii, idx[:n.value].long()
+
+
 def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
                                              projmatrices, tan_fovx, tan_fovy, image_height, image_width, debug):
     """visible_filter for V cameras in one pass (bsr_visible_filter_views): -> int32 [V, P]."""
@@ -433,6 +462,18 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
         final_T = getattr(_tls, "last_final_T", None)
         alpha = torch.zeros_like(depth) if final_T is None else (1.0 - final_T)
         return color, radii, depth, alpha.detach()
+
+    def visible_filter_indices(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
+        """EXTENSION: ``visible_filter`` that also returns the ascending indices of the visible points,
+        ``(radii int32 [P], idx int64 [n_visible])`` with ``idx == (radii > 0).nonzero().squeeze(1)``; one native call
+        and one host synchronisation instead of a nonzero() pass per boolean index (GR:33-43)."""
+        rs = self.raster_settings
+        e = torch.Tensor([])
+        with torch.no_grad():
+            return _rasterize_gaussians_filter_indices_native(
+                means3D, e if scales is None else scales, e if rotations is None else rotations, rs.scale_modifier,
+                e if cov3D_precomp is None else cov3D_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                rs.image_height, rs.image_width, rs.prefiltered, rs.debug)
 
     def visible_filter(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         raster_settings = self.raster_settings

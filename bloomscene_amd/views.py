@@ -172,6 +172,46 @@ def prefilter(cam: MiniCam, means3D, scales, rotations, bg_color, scaling_modifi
     return radii_pure > 0
 
 
+def training_view(cam: MiniCam, anchor, anchor_scaling, anchor_rotation, grid_offsets, heads, bg_color,
+                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False):
+    """One training iteration's pass through the rasterizer for ONE view, as bloomscene.py:240-243 drives it:
+    ``prefilter_voxel`` on the anchors (GR:342-349), the per-anchor gathers of ``generate_neural_gaussians``
+    (GR:33-43), [the caller's MLP heads on the visible anchors], the fused anchor expansion (GR:165-203) and the
+    render (GR:254-262) -- with ONE rasterizer object / settings tuple for filter and render (the camera terms are
+    derived once) and ONE native call that returns the filter's radii together with the index list of the visible
+    anchors (``bsr_visible_filter_indices``), so the six boolean indexes of GR:33-43 become index gathers without
+    their six nonzero() passes and host synchronisations (the per-iteration half).
+
+    ``anchor [N,3]``, ``anchor_scaling [N,6]``, ``anchor_rotation [N,4]``, ``grid_offsets [N,K,3]`` are the full
+    per-anchor parameters; ``heads(idx)`` is the caller's (out-of-scope) MLP evaluation and returns
+    ``(neural_opacity [n*K,1], color [n*K,3], scale_rot [n*K,7])`` for the ``n`` visible anchors ``idx``.
+    Returns render_neural's dict plus ``visible_mask`` (= prefilter_voxel's result), ``visible_idx`` and
+    ``anchor_radii``; every output is bit-identical to the separate calls (tests/test_anchors_gpu.py)."""
+    from .neural_gaussians import expand_anchors
+    from .rasterizer import GaussianRasterizer
+    rasterizer = GaussianRasterizer(raster_settings=make_settings(cam, bg_color, 1, scaling_modifier, debug),
+                                    depth_gradient=depth_gradient)
+    radii_pure, idx = rasterizer.visible_filter_indices(means3D=anchor, scales=anchor_scaling[:, :3],
+                                                        rotations=anchor_rotation, cov3D_precomp=None)
+    vis_anchor = anchor.index_select(0, idx)
+    vis_scaling = anchor_scaling.index_select(0, idx)
+    vis_offsets = grid_offsets.index_select(0, idx)
+    neural_opacity, color, scale_rot = heads(idx)
+    xyz, rgb, opacity, scaling, rot, mask = expand_anchors(vis_anchor, vis_scaling, vis_offsets, neural_opacity, color,
+                                                           scale_rot)
+    screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device) + 0
+    if retain_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    rendered_image, radii, depth = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=rgb,
+                                              opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "selection_mask": mask, "neural_opacity": neural_opacity,
+            "scaling": scaling, "visible_mask": radii_pure > 0, "visible_idx": idx, "anchor_radii": radii_pure}
+
+
 def prefilter_views(cams, means3D, scales, rotations, scaling_modifier=1.0, debug=False):
     """prefilter_voxel for a whole camera path at once: bool [V, P], row v equal
     to ``prefilter(cams[v], ...)``.  The reference filters the anchors once per view of the rotate360

@@ -152,6 +152,32 @@ int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user,
                       void* stream,
                       int* num_rendered);
 
+/* bsr_visible_filter plus the index list of the visible points: radii[P] exactly as bsr_visible_filter writes it,
+ * visible_idx[P] (int32) whose first *num_visible (HOST int) entries are, ascending, the indices i with
+ * radii[i] > 0 -- the rows a boolean index `x[radii > 0]` selects.  scratch: bsr_visible_scratch_bytes(P) bytes.
+ * One blocking 4-byte device->host read.  No reference counterpart as ONE call: every training iteration the
+ * reference runs visible_filter on the anchors (gaussian_renderer/__init__.py:342-349 from bloomscene.py:240) and then
+ * boolean-indexes six per-anchor tensors with the mask (:33-43), each index with its own nonzero() pass and host
+ * synchronisation; with the index list those become plain gathers (the per-iteration half). */
+size_t bsr_visible_scratch_bytes(int P);
+int bsr_visible_filter_indices(int P, int M,
+                               int width, int height,
+                               const float* means3D,
+                               const float* scales,
+                               float scale_modifier,
+                               const float* rotations,
+                               const float* cov3D_precomp,
+                               const float* viewmatrix,
+                               const float* projmatrix,
+                               float tan_fovx, float tan_fovy,
+                               int prefiltered,
+                               int* radii,
+                               int* visible_idx,
+                               void* scratch,
+                               int* num_visible,
+                               int debug,
+                               void* stream);
+
 /* bsr_visible_filter for n_views cameras of one image size and field of view in ONE pass over the
  * Gaussians: radii[v*P + i] is exactly what bsr_visible_filter writes to radii[i] with
  * viewmatrices + 16*v / projmatrices + 16*v (DEVICE float[n_views,16] each).  Each Gaussian is read,

@@ -195,3 +195,70 @@ def test_render_neural_result_dict():
     assert not vp[:, 2].any()
     for leaf in leaves:
         assert leaf.grad is not None and torch.isfinite(leaf.grad).all()
+
+
+def test_training_view_equals_the_separate_calls():
+    """SURVEY.md §8f rank 2, per-iteration half (bloomscene.py:240-243): views.training_view -- one rasterizer object,
+    bsr_visible_filter_indices, index gathers, fused expansion, render -- against the reference's shape of the same
+    iteration: prefilter_voxel (visible_filter > 0), six boolean indexes (GR:33-43), expansion, render.  The filter
+    radii, the index list, the image, depth, radii and every gradient w.r.t. the FULL per-anchor parameters must be
+    bit-identical; the index list must be what nonzero() gives."""
+    from bloomscene_amd import GaussianRasterizer, views
+    from bloomscene_amd.synthetic import anchor_scene, upstream_grads
+    dev = torch.device("cuda")
+    N, K, W, H = 30000, 10, 320, 200
+    sc = anchor_scene(N, K, W, H, seed=5)
+    g = torch.Generator().manual_seed(9)
+    # half the anchors behind / beside the camera, so the filter really filters
+    sc.anchor[torch.randperm(N, generator=g)[: N // 2], 2] *= -1.0
+    rot = torch.nn.functional.normalize(torch.randn(N, 4, generator=g))
+    cam = sc.camera.to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    gC, gD = upstream_grads(W, H, seed=2)
+    gC, gD = gC.to(dev), gD.to(dev)
+    heads_full = tuple(t.to(dev) for t in (sc.neural_opacity.view(N, K, 1), sc.color.view(N, K, 3), sc.scale_rot.view(N, K, 7)))
+
+    def leaves():
+        return [t.to(dev).clone().requires_grad_(True) for t in (sc.anchor, sc.grid_scaling, sc.grid_offsets)] + \
+               [t.clone().requires_grad_(True) for t in heads_full]
+
+    # ---- the fused per-iteration path
+    a, s6, off, h_op, h_col, h_sr = leaves()
+
+    def heads(idx):
+        return (h_op.index_select(0, idx).reshape(-1, 1), h_col.index_select(0, idx).reshape(-1, 3),
+                h_sr.index_select(0, idx).reshape(-1, 7))
+    res = views.training_view(cam, a, s6, rot.to(dev), off, heads, bg)
+    torch.autograd.backward((res["render"], res["depth"]), (gC, gD))
+    got = [t.grad.clone() for t in (a, s6, off, h_op, h_col, h_sr)]
+
+    # ---- the reference's shape of the same iteration
+    a2, s62, off2, h_op2, h_col2, h_sr2 = leaves()
+    mask = views.prefilter(cam, a2, s62, rot.to(dev), bg)
+    assert 0.1 * N < int(mask.sum()) < 0.9 * N
+    va, vs, vo = a2[mask], s62[mask], off2[mask]                       # GR:33-38
+    ref = views.render_neural(cam, va, vs, vo, h_op2[mask].reshape(-1, 1), h_col2[mask].reshape(-1, 3),
+                              h_sr2[mask].reshape(-1, 7), bg)
+    torch.autograd.backward((ref["render"], ref["depth"]), (gC, gD))
+    want = [t.grad for t in (a2, s62, off2, h_op2, h_col2, h_sr2)]
+
+    assert torch.equal(res["visible_mask"], mask)
+    assert torch.equal(res["visible_idx"], mask.nonzero().squeeze(1))
+    rast = GaussianRasterizer(views.make_settings(cam, bg, 1))
+    assert torch.equal(res["anchor_radii"], rast.visible_filter(a2.detach(), s62.detach()[:, :3], rot.to(dev)))
+    for k in ("render", "depth", "radii", "selection_mask"):
+        assert torch.equal(res[k], ref[k]), k
+    for name, x, y in zip(("anchor", "scaling", "offsets", "opacity head", "colour head", "scale_rot head"), got, want):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+    assert float(got[0].abs().sum()) > 0 and not got[0][~mask].any()      # invisible anchors: zero gradient rows
+    # edge cases of the index entry point: nothing visible, everything visible, no points
+    behind = sc.anchor.to(dev).clone()
+    behind[:, 2] = -1.0
+    r0, i0 = rast.visible_filter_indices(behind, sc.grid_scaling.to(dev)[:, :3], rot.to(dev))
+    assert i0.numel() == 0 and not r0.any()
+    front = sc.anchor.to(dev).clone()
+    front[:, 2] = front[:, 2].abs()
+    r1, i1 = rast.visible_filter_indices(front, sc.grid_scaling.to(dev)[:, :3], rot.to(dev))
+    assert torch.equal(i1, (r1 > 0).nonzero().squeeze(1)) and i1.numel() > 0.9 * N
+    r2, i2 = rast.visible_filter_indices(front[:0], sc.grid_scaling.to(dev)[:0, :3], rot.to(dev)[:0])
+    assert r2.numel() == 0 and i2.numel() == 0
