@@ -273,6 +273,34 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+#ifdef BSR_WALK_STATS
+		{
+			// what-if: per-wave lists split into the two 8x4 halves of the quadrant (rows 0-3 / 4-7), or its four 8x2
+			// strips: how many (entry, half / strip) pairs are there, and how long would the longest list of a wave be?
+			// every thread tests its own staged entry against the strips of THIS wave's quadrant
+			int n_half[2] = {0, 0}, n_strip[4] = {0, 0, 0, 0};
+			for (int e0 = 0; e0 < cnt; e0 += 64) {
+				const int e = e0 + lane;
+				bool hh[2] = {false, false}, hs[4] = {false, false, false, false};
+				if (e < cnt) {
+					const float4 a0 = sh.st.q0[e], a1 = sh.st.q1[e];
+					const float ca = a0.z, cb = a0.w, cc = a1.x;
+					const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
+					const float rb_c = -cb / cc, rb_a = -cb / ca;
+					const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
+					for (int h = 0; h < 2; h++) hh[h] = box_may_hit<7, 3>(a0.x, a0.y, ca, cb, cc, a1.y, rb_c, rb_a, pd, qx, qy + 4.0f * h);
+					for (int h = 0; h < 4; h++) hs[h] = box_may_hit<7, 1>(a0.x, a0.y, ca, cb, cc, a1.y, rb_c, rb_a, pd, qx, qy + 2.0f * h);
+				}
+				for (int h = 0; h < 2; h++) n_half[h] += __popcll(wave_ballot(hh[h]));
+				for (int h = 0; h < 4; h++) n_strip[h] += __popcll(wave_ballot(hs[h]));
+			}
+			STAT_ADD(16, n_half[0] + n_half[1]);                                        // (entry, half) pairs
+			STAT_ADD(17, max(n_half[0], n_half[1]));                                    // iterations with 2 halves per visit
+			STAT_ADD(18, n_strip[0] + n_strip[1] + n_strip[2] + n_strip[3]);            // (entry, strip) pairs
+			STAT_ADD(19, max(max(n_strip[0], n_strip[1]), max(n_strip[2], n_strip[3]))); // iterations with 4 strips per visit
+			STAT_ADD(20, n_u);                                                          // iterations now (per-quadrant list)
+		}
+#endif
 		STAT_ADD(6, 1);        // batches (per wave)
 		STAT_ADD(7, cnt);      // staged entries (per wave: every wave sees the batch)
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor

@@ -22,12 +22,12 @@ static inline unsigned occupancy_sweep_lds_pad(const char* env_name)
 // parabola minimum.  The splat is kept iff  -qmin >= power_cut - slack  (power_cut already carries
 // a margin; the extra slack covers the rounding of this test).  Anything not provably a miss --
 // non-PD conics, NaNs -- is kept, so the per-pixel decisions downstream stay exact.
-template <int EXT>   // box of pixel centres [bx, bx+EXT] x [by, by+EXT]: EXT = 7 (quadrant) or 15 (tile)
+template <int EXT, int EXTY = EXT>   // box of pixel centres [bx, bx+EXT] x [by, by+EXTY]: EXT = 7 (quadrant) or 15 (tile)
 __device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
                                             float rb_a, bool pd, float bx, float by)
 {
 	const float dx_lo = X - (bx + (float)EXT), dx_hi = X - bx;
-	const float dy_lo = Y - (by + (float)EXT), dy_hi = Y - by;
+	const float dy_lo = Y - (by + (float)EXTY), dy_hi = Y - by;
 	const bool in_x = (dx_lo <= 0.0f) && (dx_hi >= 0.0f);
 	const bool in_y = (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
 	float qmin = 0.0f;

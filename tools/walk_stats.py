@@ -79,6 +79,10 @@ def main():
         "live_lanes_per_reducing_visit": live_l / max(reduce_, 1),
         "live_lane_histogram_1-8_..._57-64": (hist / max(reduce_, 1)).round(4).tolist(),
         "reducing_visits_per_kept_instance": reduce_ / (staged / 4),
+        # what-if counts (conservative box test per 8x4 half / 8x2 strip of each quadrant)
+        "what_if": {"iterations_now": s[20], "entry_half_pairs": s[16], "iterations_two_halves_per_visit": s[17],
+                    "entry_strip_pairs": s[18], "iterations_four_strips_per_visit": s[19],
+                    "ratio_two_halves": s[17] / max(s[20], 1), "ratio_four_strips": s[19] / max(s[20], 1)},
     }
     # timeline: 100 MHz ticks
     t0 = tl[:, 0].min()
