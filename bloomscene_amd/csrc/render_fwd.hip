@@ -8,9 +8,12 @@
 // MI355X mapping: one tile = one 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel
 // quadrant.  List entries are staged 256 at a time: each thread gathers one 48-byte splat record
 // (3 x 16-B loads out of its one 64-B line in the L2/Infinity-Cache resident record table), runs a conservative
-// ellipse-vs-quadrant test on it and the batch is compacted with wave ballots + prefix popcounts
-// into one ordered index list per wave (tile_common.h).  A wave then walks only the entries that
-// can touch its quadrant, with broadcast LDS reads.  The per-pixel reject path needs 24 B of LDS
+// ellipse-vs-strip test on it and the batch is compacted with wave ballots + prefix popcounts
+// into ordered index lists, one per 8 x 4 pixel half of each quadrant (NS = 2, tile_common.h "split lists"): the two
+// 32-lane halves of a wave walk their own lists side by side (0.82x the visits of one list per quadrant at C3;
+// k_render_fwd -6..8 % at C3 / C5, unchanged on dense and on sparse views; one list per 8 x 2 strip (NS = 4) halves
+// the visits' gain again but its 16 box tests per entry and 29 KB of LDS cost more than it saves).  The per-pixel reject
+// path needs 24 B of LDS
 // and no exp: `power < power_cut` (precomputed -ln(255*opacity) minus a margin) proves
 // alpha < 1/255 without evaluating it.  The inner loop is wave-uniform (one ballot per entry).
 #include "tile_common.h"
@@ -19,6 +22,7 @@ namespace bsr {
 
 // View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
 // row tyv belongs to view tyv / gy; pixel coordinates, image outputs and the per-pixel state are per view.
+template <int NS, int FB>
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
@@ -30,7 +34,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
                                                           float* __restrict__ out_color,
                                                           float* __restrict__ out_depth)
 {
-	__shared__ TileStage st;
+	__shared__ TileStageS<FB, NS> st;
 	__shared__ int s_done[4];
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
@@ -38,6 +42,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	if (*n_ptr > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
+	stage_init(st, tid);   // (fenced by the first loop-top barrier)
+	const unsigned int* const my_list = &st.list[my_list_index<NS>(wave, lane)][0];
 	const int tx = tile % gx, tyv = tile / gx;
 	const int view = tyv / gy, ty = tyv - view * gy;
 	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
@@ -61,14 +67,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	float D = 0.f;
 	float acc = 0.000001f;
 
-	for (int base = 0; base < n; base += BSR_BLOCK) {
+	for (int base = 0; base < n; base += FB) {
 		// whole tile finished?  (the barrier is also the WAR fence for the staging buffers)
 		const bool wave_done = (wave_ballot(!done) == 0ull);
 		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
 		__syncthreads();
 		if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
 
-		const int cnt = min(BSR_BLOCK, n - base);
+		const int cnt = min(FB, n - base);
 		const bool valid = tid < cnt;
 		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		if (valid) {
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			r1 = r[1];
 			r2 = r[2];
 		}
-		const int n_mine = stage_and_compact(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
+		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
 		if (!wave_done) {
 			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
@@ -86,17 +92,17 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			int n_lim = __builtin_amdgcn_readfirstlane(n_mine);   // set to 0 to leave (single loop exit)
 			const uint32_t base16 = (uint32_t)(base + 1) << 4;
 			auto visit = [&](const unsigned int joff) {
-				const char* rec = stage_rec(st, joff);
-				const float4 q0 = rec_q0<BSR_BLOCK>(rec);      // x, y, conic a, conic b
-				const float2 ct = rec_q1lo<BSR_BLOCK>(rec);    // conic c, power cut
+				const char* rec = reinterpret_cast<const char*>(&st.q0[0]) + joff;
+				const float4 q0 = srec_q0<FB>(rec);      // x, y, conic a, conic b
+				const float2 ct = srec_q1lo<FB>(rec);    // conic c, power cut
 				const float dx = q0.x - pixfx;
 				const float dy = q0.y - pixfy;
 				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !(power > 0.0f) && !(power < ct.y);
 				if (wave_ballot(cand) == 0ull) return;
-				const float2 od = rec_q1hi<BSR_BLOCK>(rec);    // opacity, depth
-				const float4 q2 = rec_q2<BSR_BLOCK>(rec);
+				const float2 od = srec_q1hi<FB>(rec);    // opacity, depth
+				const float4 q2 = srec_q2<FB>(rec);
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
 				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
 				//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			};
 			// four list entries per trip: one address computation and the four 16-bit list reads up front
 			for (int i = 0; i < n_lim; i += 4) {
-				const uint4 l = *reinterpret_cast<const uint4*>(&st.list[wave][i]);   // (reads past the end stay inside st.list)
+				const uint4 l = *reinterpret_cast<const uint4*>(my_list + i);   // (the row is sentinel-padded to a multiple of 4)
 				visit(l.x);
 				if (i + 1 < n_lim) visit(l.y);
 				if (i + 2 < n_lim) visit(l.z);
@@ -153,8 +159,16 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 {
 	const int n_tiles = gx * gy * n_views;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
-	hipLaunchKernelGGL(k_render_fwd, dim3(blocks), dim3(BSR_BLOCK), occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD"), s, n_tiles, gx, gy, W, H, n_ptr, capacity, tile_start,
-	                   point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
+	// split lists pay off once tiles hold a few dozen entries (C3: 360, C5: 1800); on the sparse views of a camera sweep
+	// (a dozen entries per tile, most tiles empty) their 8 box tests per entry and the padding are pure overhead.
+	// Both instantiations produce identical bits.
+	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD");
+	if ((long long)capacity >= 48ll * n_tiles)
+		hipLaunchKernelGGL((k_render_fwd<2, BSR_BLOCK>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, n_ptr,
+		                   capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
+	else
+		hipLaunchKernelGGL((k_render_fwd<1, BSR_BLOCK>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, n_ptr,
+		                   capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 
 }  // namespace bsr

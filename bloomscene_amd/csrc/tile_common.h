@@ -108,6 +108,110 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 	return total;
 }
 
+// ---- split lists: one list per 8 x (8 / NS) pixel strip of a quadrant --------------------------------------------
+// With one list per quadrant a wave spends a full visit on every entry that may touch ANY of its 64 pixels, and only
+// 22 of them are live on average (C3).  NS = 2 / 4 gives every 32- / 16-lane group of the wave (rows 0-3 | 4-7 of the
+// quadrant, or its four 8 x 2 strips = the four DPP rows) its own list: in one visit the groups work on DIFFERENT
+// entries (per-lane record addresses; a 16-lane group still reads one address, so the LDS reads stay broadcasts), and
+// the wave needs max-over-groups(list length) visits instead of the quadrant's: 0.82x (NS = 2) / 0.73x (NS = 4) at C3
+// (tools/walk_stats.py).  Every per-pixel operation and its order are unchanged: a lane only skips entries that the
+// conservative box test proves inert for its strip, so results stay bit-identical.
+// Lists are padded with the offset of a SENTINEL record (slot BATCH: no pixel can be a candidate of it) so that all
+// groups run the same number of visits.
+template <int BATCH, int NS, typename LT = unsigned int>   // LT: list entry type (uint16_t where LDS is tight; BATCH << 4 must fit)
+struct TileStageS {
+	static constexpr int NL = 4 * NS;        // lists per tile
+	static constexpr int ROW = BATCH + 4;    // list row, sentinel-padded to the next multiple of 4
+	float4 q0[BATCH + 1];                    // x, y, conic a, conic b          ([BATCH] = sentinel)
+	float4 q1[BATCH + 1];                    // conic c, power cut, opacity, depth
+	float4 q2[BATCH + 1];                    // r, g, b, -
+	LT list[NL][ROW];                        // BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
+	unsigned int cnt[4][NL];                 // [staging wave][list]
+};
+#define BSR_SENTINEL_X (-1.0e15f)            // (finished forward lanes sit at +1e15: the sentinel must be far from that too)
+
+template <int BATCH, int NS, typename LT>
+__device__ __forceinline__ void stage_init(TileStageS<BATCH, NS, LT>& st, int tid)
+{
+	if (tid == 0) {
+		st.q0[BATCH] = make_float4(BSR_SENTINEL_X, 0.f, 1.f, 0.f);   // power = -0.5e30: below any cut, never > 0
+		st.q1[BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
+		st.q2[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+}
+
+// List of the calling lane: quadrant = wave, strip = its 64 / NS-lane group.
+template <int NS>
+__device__ __forceinline__ int my_list_index(int wave, int lane) { return wave * NS + (NS == 1 ? 0 : NS == 2 ? (lane >> 5) : (lane >> 4)); }
+
+// As stage_and_compact, for the split lists.  Returns the number of visits the calling wave needs (the longest of
+// its NS lists); st.list[l][0 .. that, rounded up to 4) is valid for each of its lists.
+template <int BATCH, int NS, typename LT>
+__device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT>& st, int tid, bool valid, const float4 r0,
+                                                   const float4 r1, const float4 r2, float tile_x0, float tile_y0)
+{
+	constexpr int NL = 4 * NS;
+	constexpr int SH = 8 / NS;   // strip height in pixels
+	const int wave = tid >> 6, lane = tid & 63;
+	unsigned int hits = 0;       // bit l: this thread's entry may touch strip l (one VGPR, not NL flags and masks)
+	if (valid) {
+		st.q0[tid] = r0;
+		st.q1[tid] = r1;
+		st.q2[tid] = r2;
+		const float a = r0.z, b = r0.w, c = r1.x;
+		const bool pd = (a > 0.0f) && (c > 0.0f) && (a * c - b * b > 0.0f);
+		const float rb_c = -b / c, rb_a = -b / a;
+		// one quadrant at a time (a real loop: fully unrolled, the NL tests' shared subexpressions cost 30+ VGPRs of
+		// the kernel's budget), its NS strips unrolled
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)   // (vectorised it runs two quadrants in v_pk_* pairs)
+		for (int q = 0; q < 4; q++) {
+			const float bx = tile_x0 + (float)((q & 1) << 3), by = tile_y0 + (float)((q >> 1) << 3);
+			unsigned int hq = 0;
+#pragma unroll
+			for (int sidx = 0; sidx < NS; sidx++)
+				if (box_may_hit<7, SH - 1>(r0.x, r0.y, a, b, c, r1.y, rb_c, rb_a, pd, bx, by + (float)(sidx * SH))) hq |= 1u << sidx;
+			hits |= hq << (q * NS);
+		}
+	}
+#pragma unroll
+	for (int l = 0; l < NL; l++) {
+		const unsigned long long m = wave_ballot((hits >> l) & 1u);
+		if (lane == 0) st.cnt[wave][l] = (unsigned int)__popcll(m);
+	}
+	__syncthreads();
+	const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int l = 0; l < NL; l++) {
+		const unsigned long long m = wave_ballot((hits >> l) & 1u);
+		if ((hits >> l) & 1u) {
+			const unsigned int off = (wave > 0 ? st.cnt[0][l] : 0u) + (wave > 1 ? st.cnt[1][l] : 0u) +
+			                         (wave > 2 ? st.cnt[2][l] : 0u);
+			st.list[l][off + (unsigned int)__popcll(m & lt)] = (LT)(tid << 4);
+		}
+	}
+	// each wave pads ITS lists with the sentinel up to the longest of them (rounded up to the four entries the walk
+	// reads per trip); nobody else writes there
+	int tot[NS];
+	int longest = 0;
+#pragma unroll
+	for (int sidx = 0; sidx < NS; sidx++) {
+		const int l = wave * NS + sidx;
+		tot[sidx] = (int)(st.cnt[0][l] + st.cnt[1][l] + st.cnt[2][l] + st.cnt[3][l]);
+		longest = max(longest, tot[sidx]);
+	}
+	const int padded = (longest + 3) & ~3;
+#pragma unroll
+	for (int sidx = 0; sidx < NS; sidx++)
+		for (int i = tot[sidx] + lane; i < padded; i += 64) st.list[wave * NS + sidx][i] = (LT)(BATCH << 4);
+	__syncthreads();
+	return longest;
+}
+template <int BATCH> __device__ __forceinline__ float4 srec_q0(const char* r) { return *reinterpret_cast<const float4*>(r); }
+template <int BATCH> __device__ __forceinline__ float4 srec_q1(const char* r) { return *reinterpret_cast<const float4*>(r + (BATCH + 1) * 16); }
+template <int BATCH> __device__ __forceinline__ float2 srec_q1lo(const char* r) { return *reinterpret_cast<const float2*>(r + (BATCH + 1) * 16); }
+template <int BATCH> __device__ __forceinline__ float2 srec_q1hi(const char* r) { return *reinterpret_cast<const float2*>(r + (BATCH + 1) * 16 + 8); }
+template <int BATCH> __device__ __forceinline__ float4 srec_q2(const char* r) { return *reinterpret_cast<const float4*>(r + (BATCH + 1) * 32); }
+
 // Record fields of the list entry at byte offset `joff` (wave-uniform, but deliberately left in a VGPR:
 // a readfirstlane + scalar shift + move back costs four issue slots per visit and buys nothing, the
 // LDS broadcasts a uniform address anyway).
