@@ -14,7 +14,7 @@ namespace bsr {
 // Private layout of the three scratch buffers (opaque to callers).
 // Per-Gaussian "splat record": everything the tile kernels gather per list entry, exactly one
 // 64-byte cache line:
-//   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, power_cut, opacity, depth)   q2 = (r, g, b, 0)
+//   q0 = (x, y, -conic.a / 2, -conic.b)   q1 = (-conic.c / 2, power_cut, opacity, depth)   q2 = (r, g, b, 0)
 //   q3 = bits(inst_offset (relative to its workgroup's base), xmin | ymin << 16, width | height << 16, kept_mask_lo), q2.w = bits(kept_mask_hi)
 //        (backward only).  kept_mask bit k = the k-th tile (row-major) of the rect is kept; rects of
 //        more than 64 tiles keep every tile and ignore the mask.

@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				bool hh[2] = {false, false}, hs[4] = {false, false, false, false};
 				if (e < cnt) {
 					const float4 a0 = sh.st.q0[e], a1 = sh.st.q1[e];
-					const float ca = a0.z, cb = a0.w, cc = a1.x;
+					const float ca = -2.0f * a0.z, cb = -a0.w, cc = -2.0f * a1.x;
 					const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
 					const float rb_c = -cb / cc, rb_a = -cb / ca;
 					const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float4 q1 = rec_q1<BSR_BWD_BATCH>(rec);   // conic c, power cut, opacity, depth
 			const float dx = q0.x - pixfx;
 			const float dy = q0.y - pixfy;
-			const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+			const float power = (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic (common.h): the forward's bits
 			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
 			STAT_ADD(0, 1);                                  // visits
 			if (wave_ballot(cand) == 0ull) return;   // wave-uniform
@@ -423,11 +423,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				sh.part[3][k][tid] = 0.f;
 			}
 			// moments -> the reference's sums (see the walk); this thread staged entry `tid` itself
-			const float4 e0 = sh.st.q0[tid], e1 = sh.st.q1[tid];   // (x, y, a, b), (c, cut, o, depth)
+			const float4 e0 = sh.st.q0[tid], e1 = sh.st.q1[tid];   // (x, y, -a/2, -b), (-c/2, cut, o, depth)
+			const float ca = -2.0f * e0.z, cb = -e0.w, cc = -2.0f * e1.x;
 			const float no = -e1.z;
 			const float h = 0.5f * no;
 			float4* row = slab + (size_t)my_row * 3;
-			row[0] = make_float4(no * ddelx_dx * (e0.z * a9[0] + e0.w * a9[1]), no * ddely_dy * (e1.x * a9[1] + e0.w * a9[0]),
+			row[0] = make_float4(no * ddelx_dx * (ca * a9[0] + cb * a9[1]), no * ddely_dy * (cc * a9[1] + cb * a9[0]),
 			                     h * a9[2], h * a9[3]);
 			row[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
 			row[2] = make_float4(a9[8], a9[9], 0.f, 0.f);

@@ -93,11 +93,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			const uint32_t base16 = (uint32_t)(base + 1) << 4;
 			auto visit = [&](const unsigned int joff) {
 				const char* rec = reinterpret_cast<const char*>(&st.q0[0]) + joff;
-				const float4 q0 = srec_q0<FB>(rec);      // x, y, conic a, conic b
-				const float2 ct = srec_q1lo<FB>(rec);    // conic c, power cut
+				const float4 q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
+				const float2 ct = srec_q1lo<FB>(rec);    // -c/2, power cut
 				const float dx = q0.x - pixfx;
 				const float dy = q0.y - pixfy;
-				const float power = -0.5f * (q0.z * dx * dx + ct.x * dy * dy) - q0.w * dx * dy;
+				const float power = (q0.z * dx * dx + ct.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !(power > 0.0f) && !(power < ct.y);
 				if (wave_ballot(cand) == 0ull) return;

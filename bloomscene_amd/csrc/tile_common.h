@@ -54,8 +54,8 @@ __device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, 
 // per-wave partial-sum slots keeps LDS at 25 KB per workgroup (6 workgroups per CU).
 template <int BATCH>
 struct TileStageT {
-	float4 q0[BATCH];                // x, y, conic a, conic b
-	float4 q1[BATCH];                // conic c, power cut, opacity, depth
+	float4 q0[BATCH];                // x, y, -conic a / 2, -conic b
+	float4 q1[BATCH];                // -conic c / 2, power cut, opacity, depth
 	float4 q2[BATCH];                // r, g, b, -
 	unsigned int list[4][BATCH];     // per quadrant: BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
 	                                 // (32-bit: the walks fetch four entries with one 16-byte read, no unpacking)
@@ -78,7 +78,7 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 		st.q0[tid] = r0;
 		st.q1[tid] = r1;
 		st.q2[tid] = r2;
-		const float a = r0.z, b = r0.w, c = r1.x;
+		const float a = -2.0f * r0.z, b = -r0.w, c = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
 		const bool pd = (a > 0.0f) && (c > 0.0f) && (a * c - b * b > 0.0f);
 		const float rb_c = -b / c, rb_a = -b / a;
 #pragma unroll
@@ -122,8 +122,8 @@ template <int BATCH, int NS, typename LT = unsigned int>   // LT: list entry typ
 struct TileStageS {
 	static constexpr int NL = 4 * NS;        // lists per tile
 	static constexpr int ROW = BATCH + 4;    // list row, sentinel-padded to the next multiple of 4
-	float4 q0[BATCH + 1];                    // x, y, conic a, conic b          ([BATCH] = sentinel)
-	float4 q1[BATCH + 1];                    // conic c, power cut, opacity, depth
+	float4 q0[BATCH + 1];                    // x, y, -conic a / 2, -conic b    ([BATCH] = sentinel)
+	float4 q1[BATCH + 1];                    // -conic c / 2, power cut, opacity, depth
 	float4 q2[BATCH + 1];                    // r, g, b, -
 	LT list[NL][ROW];                        // BYTE offsets (entry << 4) into q0 / q1 / q2, in list order
 	unsigned int cnt[4][NL];                 // [staging wave][list]
@@ -134,8 +134,8 @@ template <int BATCH, int NS, typename LT>
 __device__ __forceinline__ void stage_init(TileStageS<BATCH, NS, LT>& st, int tid)
 {
 	if (tid == 0) {
-		st.q0[BATCH] = make_float4(BSR_SENTINEL_X, 0.f, 1.f, 0.f);   // power = -0.5e30: below any cut, never > 0
-		st.q1[BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
+		st.q0[BATCH] = make_float4(BSR_SENTINEL_X, 0.f, -0.5f, 0.f);   // power = -0.5e30: below any cut, never > 0
+		st.q1[BATCH] = make_float4(-0.5f, 0.f, 0.f, 0.f);
 		st.q2[BATCH] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
 }
@@ -158,7 +158,7 @@ __device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT>& st
 		st.q0[tid] = r0;
 		st.q1[tid] = r1;
 		st.q2[tid] = r2;
-		const float a = r0.z, b = r0.w, c = r1.x;
+		const float a = -2.0f * r0.z, b = -r0.w, c = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
 		const bool pd = (a > 0.0f) && (c > 0.0f) && (a * c - b * b > 0.0f);
 		const float rb_c = -b / c, rb_a = -b / a;
 		// one quadrant at a time (a real loop: fully unrolled, the NL tests' shared subexpressions cost 30+ VGPRs of
