@@ -113,14 +113,22 @@ class Dist:
             raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback in bloomscene_amd)")
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # Test hooks (tests/test_bench_gpu.py): BSR_BENCH_SINGLE_DEVICE=1 puts every rank on GPU 0 and
+        # BSR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so the N > 1 control flow --
+        # rank-0 generation, broadcasts, view sharding, max-over-ranks timing -- can run with 2 ranks on a 1-GPU box.
+        index = 0 if os.environ.get("BSR_BENCH_SINGLE_DEVICE") == "1" else self.local_rank
+        torch.cuda.set_device(index)
+        self.dev = torch.device("cuda", index)
         self.force = os.environ.get("BSR_BENCH_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ
         self.multi = self.world > 1 or self.force
         if self.multi:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            backend = os.environ.get("BSR_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
 
     def fence(self):
         if self.multi:

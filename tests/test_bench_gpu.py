@@ -44,6 +44,22 @@ def test_bench_rccl_path_on_one_rank():
     assert "secondary" not in d                                  # not the headline workload
 
 
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """The N = 2 control flow of bench.py -- scene generated on rank 0 only, packed broadcast into rank 1's empty
+    buffers, per-rank cameras, views dealt round-robin, barrier + max-over-ranks timing, rank 0 printing -- with both
+    ranks on the one GPU of this box over gloo (RCCL refuses two ranks on one device; the RCCL calls themselves are
+    exercised by test_bench_rccl_path_on_one_rank).  A reduced Gaussian count keeps it short."""
+    d = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "200000", "--allreduce-grads",
+                    "--no-cpu-baseline"], env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["visible"] > 150_000          # rank 0 rendered the broadcast scene
+    assert d["config"]["broadcast_ms"] > 0 and d["config"]["allreduce_ms_per_step"] > 0
+    c4 = d["c4"]
+    assert c4["n_gpus"] == 2 and c4["views_per_rank"] == [32, 32] and c4["broadcast_ms"] > 0
+    assert c4["views_per_call_16"]["value_including_broadcast"] > 0
+    assert "secondary" not in d and "cpu_baseline" not in d
+
+
 def test_bench_headline_line_has_the_contract_keys():
     """The default invocation's JSON (shortened): contract keys, roofline, C4 and the secondary workloads."""
     d = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-sample", "20000"])
