@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			r1 = r[1];
 			r2 = r[2];
 			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
+			r2.w = r1.y + 1.0e-3f;   // staged q2.w (the mask half is used up): centre of the decision band, -ln(255 o)
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -329,10 +330,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// candidate inside that 2e-3 wide band evaluates E to decide; everywhere else the VALUE of exp(power) is
 			// all that is needed, and gradients are compared with a tolerance (the reference's sums are unordered),
 			// so it comes from v_exp_f32: 2 issue slots instead of 13.
-			// "inside the band" is voted on |power - (cut + 1e-3)| < 1.1e-3 over ALL lanes (a vote on an AND with `cand`
+			// "inside the band" is voted on |power - centre| < 1.1e-3 (centre = cut + 1e-3, staged in q2.w) over ALL lanes (a vote on an AND with `cand`
 			// makes hipcc materialise the mask in a VGPR): a lane that is not a candidate can only add a harmless
 			// trip through the pinned exp.
-			const bool in_band = wave_ballot(fabsf(power - (q1.y + 1.0e-3f)) < 1.1e-3f) != 0ull;   // rare: ~1 % of the visits
+			const bool in_band = wave_ballot(fabsf(power - q2.w) < 1.1e-3f) != 0ull;   // rare: ~1 % of the visits
 			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
 			if (in_band) Gx = bsr_expf_walk(power);
 			// Lanes that must not blend carry G = 0, hence alpha = 0: every recurrence below then leaves their state
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// fma, so the 1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare
 				// cases: the T chain (hundreds of steps in dense tiles) does not drift.
 				const float qT = T * inv;
-				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);
+				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);   // (plain T * inv: -2 % time, +20 % elements off by > 1e-4)
 				// The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it
 				// only through sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so
 				// the projection Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence

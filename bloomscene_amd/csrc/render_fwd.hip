@@ -114,12 +114,13 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float test_T = T * (1 - a_eff);
 				const bool stop = test_T < 0.0001f;
 				const float a = stop ? 0.0f : a_eff;
-				// x + (c * 0) * T == x exactly for every finite c (reference :439-446 order kept)
-				C0 = C0 + q2.x * a * T;
-				C1 = C1 + q2.y * a * T;
-				C2 = C2 + q2.z * a * T;
-				D = D + od.y * a * T;
-				acc = acc + a * T;
+				// reference :439-446 as its nvcc build evaluates them (and the oracle restates them): c * alpha rounded, then
+				// ONE fused multiply-add with T.  fma(c * 0, T, x) == x exactly for every finite c.
+				C0 = __builtin_fmaf(q2.x * a, T, C0);
+				C1 = __builtin_fmaf(q2.y * a, T, C1);
+				C2 = __builtin_fmaf(q2.z * a, T, C2);
+				D = __builtin_fmaf(od.y * a, T, D);
+				acc = __builtin_fmaf(a, T, acc);
 				T = stop ? T : test_T;
 				last16 = (c2 && !stop) ? joff + base16 : last16;   // 16 * (list position + 1)
 				if (wave_ballot(stop) != 0ull) {   // rare
@@ -145,9 +146,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		final_T[img + pix_id] = T;
 		n_contrib[img + pix_id] = last16 >> 4;
 		float* oc = out_color + 3 * img;
-		oc[pix_id] = C0 + T * bg_color[0];
-		oc[plane + pix_id] = C1 + T * bg_color[1];
-		oc[2 * plane + pix_id] = C2 + T * bg_color[2];
+		oc[pix_id] = __builtin_fmaf(T, bg_color[0], C0);
+		oc[plane + pix_id] = __builtin_fmaf(T, bg_color[1], C1);
+		oc[2 * plane + pix_id] = __builtin_fmaf(T, bg_color[2], C2);
 		out_depth[img + pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
 	}
 }

@@ -28,7 +28,9 @@
  *     path can evaluate the *same* function and be compared bit for bit.
  *
  * All arithmetic is IEEE binary32 evaluated in source order (build with
- * -ffp-contract=off, no fast-math).  The unordered float atomicAdd sums of the reference
+ * -ffp-contract=off, no fast-math); the only fused operations are the explicit fmaf() calls of
+ * bsro_expf and of the forward blend accumulations (bsro_render_forward, where the reference's
+ * nvcc build contracts `+= a * b * c` into one FMA).  The unordered float atomicAdd sums of the reference
  * backward are accumulated in binary64 in a fixed order and rounded once.
  */
 #include <math.h>
@@ -476,16 +478,21 @@ void bsro_render_forward(const uint32_t* ranges, const uint32_t* point_list, int
 					if (alpha < 1.0f / 255.0f) continue;
 					float test_T = T * (1 - alpha);
 					if (test_T < 0.0001f) break; /* done = true, :433-437 */
-					for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += features[id * NUM_CHANNELS + ch] * alpha * T;
-					Dd += depths[id] * alpha * T;
-					acc += alpha * T;
+					/* `C[ch] += features[...] * alpha * T;` etc. (:439-446).  The reference is built with nvcc's defaults
+					 * (RAST/setup.py passes no -fmad=false), under which a product that feeds an add is contracted:
+					 * these three statements are x = f * alpha (rounded), then ONE fused multiply-add with T.  They are
+					 * restated that way; every other expression of this file stays in source order without contraction
+					 * (where nvcc's choice among several possible contractions is not determined by the source). */
+					for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] = fmaf(features[id * NUM_CHANNELS + ch] * alpha, T, C[ch]);
+					Dd = fmaf(depths[id] * alpha, T, Dd);
+					acc = fmaf(alpha, T, acc);
 					T = test_T;
 					last_contributor = contributor;
 				}
 				final_T[pix_id] = T;
 				n_contrib[pix_id] = last_contributor;
 				for (int ch = 0; ch < NUM_CHANNELS; ch++)
-					out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * bg_color[ch];
+					out_color[(size_t)ch * H * W + pix_id] = fmaf(T, bg_color[ch], C[ch]); /* :462, contracted likewise */
 				out_depth[pix_id] = (acc > 0.5f) ? Dd / acc : 0; /* :464-468 */
 			}
 	}
