@@ -7,7 +7,7 @@ transcription slip would -- one token per mutant: a constant of SURVEY.md row A1
 builds each broken copy and requires that cross-check + micro-cases FAIL on it.  A mutant nobody notices is a
 line of the oracle that nothing pins.
 
-    python tests/test_oracle_mutations.py --report profiles/r02_v1/oracle_mutation_report.json     (full table)
+    python tests/test_oracle_mutations.py --report profiles/r02_v3/oracle_mutation_report.json     (full table)
 
 Mutants that are expected to survive are listed with the reason (their effect is below fp32 resolution).
 """
