@@ -20,6 +20,16 @@
 
 namespace bsr {
 
+// ---- diagnostic build only (make stats; tools/walk_stats.py --forward): counters of the forward walk + a timeline
+#ifdef BSR_WALK_STATS
+#define BSR_NSTAT_F 24
+__device__ unsigned long long g_fwd_stats[BSR_NSTAT_F];
+__device__ unsigned long long g_fwd_times[4 * 70000];
+#define FSTAT_ADD(i, v) (wstat[i] += (unsigned long long)(v))
+#else
+#define FSTAT_ADD(i, v) ((void)0)
+#endif
+
 // View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
 // row tyv belongs to view tyv / gy; pixel coordinates, image outputs and the per-pixel state are per view.
 template <int NS, int FB>
@@ -42,6 +52,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	if (*n_ptr > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
+#ifdef BSR_WALK_STATS
+	unsigned long long wstat[BSR_NSTAT_F] = {};
+	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 	stage_init(st, tid);   // (fenced by the first loop-top barrier)
 	const unsigned int* const my_list = &st.list[my_list_index<NS>(wave, lane)][0];
 	const int tx = tile % gx, tyv = tile / gx;
@@ -85,6 +99,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			r2 = r[2];
 		}
 		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
+		FSTAT_ADD(6, 1);      // batches (per wave)
+		FSTAT_ADD(7, cnt);    // staged entries (every wave sees the batch)
 
 		if (!wave_done) {
 			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
@@ -100,7 +116,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const float power = (q0.z * dx * dx + ct.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
 				const bool cand = !(power > 0.0f) && !(power < ct.y);
+				FSTAT_ADD(0, 1);   // visits (incl. sentinel padding)
 				if (wave_ballot(cand) == 0ull) return;
+				FSTAT_ADD(1, 1);   // ... with a candidate lane
 				const float2 od = srec_q1hi<FB>(rec);    // opacity, depth
 				const float4 q2 = srec_q2<FB>(rec);
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
@@ -122,6 +140,13 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				D = __builtin_fmaf(od.y * a, T, D);
 				acc = __builtin_fmaf(a, T, acc);
 				T = stop ? T : test_T;
+#ifdef BSR_WALK_STATS
+				{
+					const int live = __popcll(wave_ballot(c2 && !stop));
+					FSTAT_ADD(5, live);                                     // lanes that blend
+					if (live) { FSTAT_ADD(3, 1); FSTAT_ADD(8 + ((live - 1) >> 3), 1); }   // blending visits + histogram
+				}
+#endif
 				last16 = (c2 && !stop) ? joff + base16 : last16;   // 16 * (list position + 1)
 				if (wave_ballot(stop) != 0ull) {   // rare
 					pixfx = stop ? 1.0e15f : pixfx;
@@ -151,6 +176,22 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		oc[2 * plane + pix_id] = __builtin_fmaf(T, bg_color[2], C2);
 		out_depth[img + pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
 	}
+#ifdef BSR_WALK_STATS
+	if (lane == 0) {
+		for (int i = 0; i < BSR_NSTAT_F; i++)
+			if (wstat[i]) atomicAdd(&g_fwd_stats[i], wstat[i]);
+		if (wave == 0 && blockIdx.x < 70000) {
+			unsigned long long* t = g_fwd_times + 4 * (size_t)blockIdx.x;
+			uint32_t xcc, hwid;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+			t[0] = t_start;
+			t[1] = __builtin_amdgcn_s_memrealtime();
+			t[2] = (unsigned long long)xcc | ((unsigned long long)hwid << 32);
+			t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
+		}
+	}
+#endif
 }
 
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
@@ -173,3 +214,19 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 }
 
 }  // namespace bsr
+
+#ifdef BSR_WALK_STATS
+// Diagnostic build only: copies (and clears) the forward counters (which = 2) / its timeline (3).
+extern "C" int bsr_debug_walk_stats_fwd(int which, void* out, size_t bytes)
+{
+	hipError_t e = hipDeviceSynchronize();
+	if (e == hipSuccess)
+		e = which == 2 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_stats), bytes)
+		               : hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_times), bytes);
+	if (e == hipSuccess && which == 2) {
+		static unsigned long long zeros[BSR_NSTAT_F];
+		e = hipMemcpyToSymbol(HIP_SYMBOL(bsr::g_fwd_stats), zeros, sizeof(zeros));
+	}
+	return e == hipSuccess ? 0 : 1;
+}
+#endif

@@ -34,6 +34,9 @@ def main():
     fn = lib.bsr_debug_walk_stats   # AttributeError here = not the diagnostic build
     fn.restype = C.c_int
     fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    fnf = lib.bsr_debug_walk_stats_fwd
+    fnf.restype = C.c_int
+    fnf.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
     P, W, H, deg = CONFIGS[args.config]
     dev = torch.device("cuda")
     sc = scene_a(P, W, H, deg, seed=0)
@@ -49,7 +52,11 @@ def main():
     gC, gD = upstream_grads(W, H, seed=1)
     gC, gD = gC.to(dev), gD.to(dev)
     stats = np.zeros(24, dtype=np.uint64)
+    fstats = np.zeros(24, dtype=np.uint64)
     for it in range(3):
+        if it == 2:
+            torch.cuda.synchronize()
+            assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0   # clears what the warm-up forwards counted
         m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
         color, radii, depth = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"],
                                    shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
@@ -59,6 +66,7 @@ def main():
         torch.autograd.backward((color, depth), (gC, gD))
     torch.cuda.synchronize()
     assert fn(0, stats.ctypes.data, stats.nbytes) == 0
+    assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0
     T = ((W + 15) // 16) * ((H + 15) // 16)
     nblk = (T + 7) // 8 * 8
     tl = np.zeros(4 * 70000, dtype=np.uint64)
@@ -84,7 +92,27 @@ def main():
                     "entry_strip_pairs": s[18], "iterations_four_strips_per_visit": s[19],
                     "ratio_two_halves": s[17] / max(s[20], 1), "ratio_four_strips": s[19] / max(s[20], 1)},
     }
-    # timeline: 100 MHz ticks
+    out["backward_timeline"] = timeline(tl)
+    ftl = np.zeros(4 * 70000, dtype=np.uint64)
+    assert fnf(3, ftl.ctypes.data, ftl.nbytes) == 0
+    ftl = ftl.reshape(-1, 4)[:nblk]
+    ftl = ftl[ftl[:, 1] > 0]
+    f = fstats.astype(np.float64)
+    out["forward"] = {
+        "lists": "one per 8x4 half of a quadrant when tiles average >= 48 instances, else one per quadrant",
+        "visits_per_staged_entry": f[0] / max(f[7] / 4, 1),
+        "share_of_visits_with_a_candidate": f[1] / max(f[0], 1),
+        "share_of_visits_blending": f[3] / max(f[0], 1),
+        "blending_lanes_per_blending_visit": f[5] / max(f[3], 1),
+        "blending_lane_histogram_1-8_..._57-64": (f[8:16] / max(f[3], 1)).round(4).tolist(),
+        "timeline": timeline(ftl),
+    }
+    print(json.dumps(out))
+
+
+def timeline(tl):
+    """Per-workgroup start / end stamps (100 MHz) -> duration spread, residency over time, tail."""
+    out = {}
     t0 = tl[:, 0].min()
     st = (tl[:, 0] - t0).astype(np.float64) / 100.0   # us
     en = (tl[:, 1] - t0).astype(np.float64) / 100.0
@@ -96,7 +124,7 @@ def main():
     conc = [(float(((st <= g) & (en > g)).sum())) for g in grid]
     busy = float(dur.sum())
     slots = max(conc)
-    out["timeline"] = {
+    return {
         "kernel_us": round(float(total), 1), "workgroups": int(len(tl)),
         "wg_duration_us": {"p5": round(float(np.percentile(dur, 5)), 1), "median": round(float(np.median(dur)), 1),
                            "p95": round(float(np.percentile(dur, 95)), 1), "max": round(float(dur.max()), 1)},
@@ -109,7 +137,6 @@ def main():
         "resident_at_10pct_steps": [conc[i] for i in range(0, 201, 20)],
         "xcc_ids_seen": sorted(set(int(x & np.uint64(0xf)) for x in tl[:, 2])),
     }
-    print(json.dumps(out))
 
 
 if __name__ == "__main__":
