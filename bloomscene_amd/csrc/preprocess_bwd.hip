@@ -164,26 +164,76 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const bool in_range = idx < a.P;
-	if (ROW_F4 <= 0 && !in_range) return;   // the cooperative variants keep whole waves alive
+	// (no early exit: whole waves take part in the slab gather and in the cooperative SH part)
 	const ushort4 rc = in_range ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
 	const bool visible = in_range && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
 
 	// ---- add the per-instance partial sums of this Gaussian (adjacent slab rows) in tile (row-major) order.
 	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
 	// the order is fixed, so the per-Gaussian sums do not depend on scheduling.
+	//
+	// The blocks of the 64 Gaussians of a wave are adjacent too (k_preprocess numbers the kept instances of a workgroup
+	// in id order), so the wave's rows are ONE contiguous run of the slab.  A thread walking its own rows issues
+	// 48-B-strided loads, one dependent round trip per row, and the wave runs as many trips as its longest block;
+	// instead the wave copies the run into LDS with coalesced 16-byte loads (all in flight at once) and every thread
+	// adds its rows from there, in the same order: same sums bit for bit.  The staging area is the SH tile, which is
+	// not in use yet (its own few KB in the instantiations without one).
+	constexpr int STAGE_F4 = ROW_F4 > 0 ? 64 * (ROW_F4 + 1) : 192;   // float4 per wave
+	constexpr uint32_t STAGE_ROWS = STAGE_F4 / 3;
+	__shared__ float4 s_stage[4][STAGE_F4];   // ROW_F4 > 0: reinterpreted as ShTile<ROW_F4> by the SH part below
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float g_z = 0.f;   // dL/d(view z): written only by the depth-gradient variant of k_render_bwd (else 0)
 	{
+		const int lane = threadIdx.x & 63;
+		float4* const stage = s_stage[threadIdx.x >> 6];
 		const uint32_t area = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
 		const uint32_t off = n_inst ? a.geom.wg_kept[idx >> 8] + a.geom.inst_offset[idx] : 0u;
-		for (uint32_t k = 0; k < n_inst; k++) {
-			const float4* row = a.slab + (size_t)(off + k) * 3;
-			const float4 s0 = row[0], s1 = row[1], s2 = row[2];
-			g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
-			g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
-			g[8] += s2.x;
-			g_z += s2.y;
+		uint32_t incl = n_inst;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const uint32_t t = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += t;
+		}
+		const uint32_t excl = incl - n_inst;
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		const uint64_t has = wave_ballot(n_inst != 0u);
+		if (has != 0ull) {   // wave-uniform
+			// first row of the run: any lane with a block knows it (its block starts `excl` rows in)
+			const uint32_t run0 = (uint32_t)__builtin_amdgcn_readlane((int)(off - excl), (int)__builtin_ctzll(has));
+			const float4* const src = a.slab + (size_t)run0 * 3;
+			for (uint32_t c0 = 0; c0 < total; c0 += STAGE_ROWS) {
+				const uint32_t n_rows = min(STAGE_ROWS, total - c0);
+				const uint32_t n_f4 = n_rows * 3;
+				const float4* const s = src + (size_t)c0 * 3;
+				for (uint32_t i0 = 0; i0 < n_f4; i0 += 256) {   // four 1-KiB loads in flight per trip
+					const uint32_t i = i0 + (uint32_t)lane;
+					float4 v0, v1, v2, v3;
+					if (i < n_f4) v0 = s[i];
+					if (i + 64 < n_f4) v1 = s[i + 64];
+					if (i + 128 < n_f4) v2 = s[i + 128];
+					if (i + 192 < n_f4) v3 = s[i + 192];
+					if (i < n_f4) stage[i] = v0;
+					if (i + 64 < n_f4) stage[i + 64] = v1;
+					if (i + 128 < n_f4) stage[i + 128] = v2;
+					if (i + 192 < n_f4) stage[i + 192] = v3;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const uint32_t k0 = max(excl, c0), k1 = min(incl, c0 + n_rows);
+				for (uint32_t k = k0; k < k1; k++) {
+					const float4* row = stage + (k - c0) * 3;
+					const float4 s0 = row[0], s1 = row[1], s2 = row[2];
+					g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
+					g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
+					g[8] += s2.x;
+					g_z += s2.y;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();   // the next chunk / the SH part overwrites the staging area
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			}
 		}
 	}
 	if (in_range) {
@@ -344,18 +394,18 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 			drot[2] = 2 * x * (G[1][0] + G[0][1]) + 2 * r * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) - 4 * y * (G[2][2] + G[0][0]);
 			drot[3] = 2 * r * (G[0][1] - G[1][0]) + 2 * x * (G[2][0] + G[0][2]) + 2 * y * (G[1][2] + G[2][1]) - 4 * z * (G[1][1] + G[0][0]);
 		}
-	} else if (ROW_F4 == 0 && a.shs && a.dL_dsh) {
+	} else if (ROW_F4 == 0 && in_range && a.shs && a.dL_dsh) {
 		zero_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M);
 	}
 
 	if (ROW_F4 > 0) {
 		// SH part for the whole wave at once (the reference adds it to dL_dmean after the projection
 		// part, backward.cu:387-391; the cov3D part above does not touch dL_dmean, so the order holds)
-		__shared__ ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)> s_tile[4];
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int g0 = blockIdx.x * 256 + wave * 64;
 		const int n_valid = min(64, max(0, a.P - g0));
-		ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>& tile = s_tile[wave];
+		static_assert(sizeof(ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>) <= sizeof(s_stage[0]), "the SH tile lives in the staging area");
+		ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>& tile = *reinterpret_cast<ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>*>(&s_stage[wave][0]);
 		if (a.D <= 0) sh_bwd_coop<0, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
 		else if (a.D == 1) sh_bwd_coop<1, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
 		else if (ROW_F4 < 12) { /* degree > 1 needs M >= 9: not reachable with M = 4 (checked by the host) */ }
