@@ -325,7 +325,9 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	GeomState geom = GeomState::carve(geom_p, P_rows);
 	ImgState img = ImgState::carve(img_p, N, (size_t)T);
 
-	HIP_TRY(hipMemsetAsync(img.flags, 0, 8 * sizeof(int), s));
+	// flags[1..7] are initialised by k_scans (which precedes every kernel that counts into or reads them); flags[0] is
+	// written by k_preprocess itself, and only for prefiltered calls, so only those pay a memset launch
+	if (prefiltered) HIP_TRY(hipMemsetAsync(img.flags, 0, sizeof(int), s));
 
 	{
 		PreArgs a;

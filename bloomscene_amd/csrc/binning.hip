@@ -96,6 +96,8 @@ __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__
 		if (threadIdx.x == 0) {
 			flags[2] = (int)kept;
 			flags[3] = (int)area;
+			flags[1] = flags[4] = flags[5] = 0;   // counters of k_tile_ranges (the image buffer arrives uninitialised)
+			flags[6] = flags[7] = 0;
 		}
 		return;
 	}

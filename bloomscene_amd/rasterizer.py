@@ -351,6 +351,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 1, raster_settings.image_height, raster_settings.image_width)
         else:   # P == 0: nothing was rendered
             _tls.last_final_T = None
+        # radii is an index output, and unused outputs need no zero gradients: without these two lines autograd
+        # fills an int32 [P] zero tensor for grad_radii on every backward (the reference pays that fill, PYW:101)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.depth_gradient = bool(depth_gradient)
