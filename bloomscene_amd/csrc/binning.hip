@@ -399,6 +399,26 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 // The network is the all-ascending form of bitonic sort (first step of every merge compares
 // mirrored partners), so keys beyond n behave as +infinity pads without ever being stored:
 // a compare-exchange whose upper index is >= n is a no-op.
+//
+// LDS bank swizzle.  The keys are 8 bytes: a ds_read_b64 is served in two groups of 32 lanes, conflict-free when
+// the 32 key slots differ mod 32; a ds_write_b64 in four groups of 16 lanes, slots mod 16.  The network's short
+// strides break that badly: with keys at their natural index a thread of the stride-(2, 1) pair owns keys 4i .. 4i+3,
+// so 32 lanes hit 8 slots mod 32 (4-way), and every pair with a stride below 32 is 2- to 4-way on reads and worse on
+// writes -- PMC: SQ_LDS_BANK_CONFLICT = 61 % of the small class's LDS cycles, and the LDS array, not the VALU, was
+// the kernel's bound (82 % busy).  Key i therefore lives in slot
+//     swz(i) = i ^ ((i >> 2) & 31) ^ ((i >> 1) & 1),
+// a bijection of [0, n2) for every power of two n2 (bits are only ever folded downwards), found by enumerating
+// XOR-linear maps against the access patterns of every step of the network for 256 .. 8192 keys, 256 .. 1024
+// threads: all reads and writes of all steps, the load and the read-out become conflict-free.  swz is linear over
+// XOR and the four keys of a step pair differ from the first by wave-uniform bit patterns (i | h == i ^ h there,
+// mirrored partners are i ^ (size - 1)), so a thread swizzles ONE index per pair and reaches the others with XORs
+// of scalar constants.
+__device__ __host__ __forceinline__ constexpr int lds_swz(int i) { return i ^ ((i >> 2) & 31) ^ ((i >> 1) & 1); }
+struct LdsKeys {   // an LDS key array addressed through the swizzle (the global-memory arrays stay plain pointers)
+	uint64_t* p;
+	__device__ __forceinline__ uint64_t& operator[](int i) const { return p[lds_swz(i)]; }
+};
+
 template <typename KeyPtr>
 __device__ __forceinline__ void cmp_exchange(KeyPtr k, int lo, int hi)
 {
@@ -464,14 +484,31 @@ __device__ __forceinline__ void quad_steps(KeyPtr k, int n, int i0, int i1, int 
 	if (i3 < n && e3 != o3) k[i3] = e3;
 }
 
+// The padded LDS classes: slot of the first key + the three (wave-uniform) slot differences
+__device__ __forceinline__ void quad_steps_slots(uint64_t* p, int p0, int d1, int d2, int d3, bool mirror)
+{
+	uint64_t e0 = p[p0], e1 = p[p0 ^ d1], e2 = p[p0 ^ d2], e3 = p[p0 ^ d3];
+	if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
+	cx(e0, e1);
+	cx(e2, e3);
+	p[p0] = e0; p[p0 ^ d1] = e1; p[p0 ^ d2] = e2; p[p0 ^ d3] = e3;
+}
+
 // mirrored first step of the merge that builds runs of `size` (>= 4) + its stride size/4 step
 template <int NT, bool PADDED, typename KeyPtr>
 __device__ __forceinline__ void merge_mirror_pair(KeyPtr k, int n, int n2, int size, int tid)
 {
 	const int q = size >> 2, sh = __builtin_ctz(q);
-	for (int i = tid; i < (n2 >> 2); i += NT) {
-		const int blk = i >> sh, off = i & (q - 1), base = blk * size;
-		quad_steps<PADDED>(k, n, base + off, base + off + q, base + size - 1 - off - q, base + size - 1 - off, true);
+	if constexpr (PADDED) {
+		// keys base + off, .. + q, base + size - 1 - off - q, base + size - 1 - off = i0, i0 ^ q, i0 ^ (size - 1) ^ q, i0 ^ (size - 1)
+		const int d1 = lds_swz(q), d2 = lds_swz((size - 1) ^ q), d3 = lds_swz(size - 1);
+		for (int i = tid; i < (n2 >> 2); i += NT)
+			quad_steps_slots(k.p, lds_swz(((i >> sh) * size) | (i & (q - 1))), d1, d2, d3, true);
+	} else {
+		for (int i = tid; i < (n2 >> 2); i += NT) {
+			const int blk = i >> sh, off = i & (q - 1), base = blk * size;
+			quad_steps<false>(k, n, base + off, base + off + q, base + size - 1 - off - q, base + size - 1 - off, true);
+		}
 	}
 }
 
@@ -480,9 +517,15 @@ template <int NT, bool PADDED, typename KeyPtr>
 __device__ __forceinline__ void merge_stride_pair(KeyPtr k, int n, int n2, int s, int tid)
 {
 	const int h = s >> 1;
-	for (int i = tid; i < (n2 >> 2); i += NT) {
-		const int lo = ((i & ~(h - 1)) << 2) | (i & (h - 1));
-		quad_steps<PADDED>(k, n, lo, lo | h, lo | s, lo | s | h, false);
+	if constexpr (PADDED) {
+		const int d1 = lds_swz(h), d2 = lds_swz(s), d3 = lds_swz(s | h);
+		for (int i = tid; i < (n2 >> 2); i += NT)
+			quad_steps_slots(k.p, lds_swz(((i & ~(h - 1)) << 2) | (i & (h - 1))), d1, d2, d3, false);
+	} else {
+		for (int i = tid; i < (n2 >> 2); i += NT) {
+			const int lo = ((i & ~(h - 1)) << 2) | (i & (h - 1));
+			quad_steps<false>(k, n, lo, lo | h, lo | s, lo | s | h, false);
+		}
 	}
 }
 
@@ -523,6 +566,7 @@ __device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t star
                                                  uint32_t* __restrict__ point_list)
 {
 	const int tid = threadIdx.x;
+	const LdsKeys keys{s_keys};
 	int n2 = 4;
 	while (n2 < n) n2 <<= 1;
 	for (int i = tid * 4; i < n2; i += NT * 4) {
@@ -533,10 +577,11 @@ __device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t star
 		cx(e0, e1); cx(e2, e3);
 		cx(e0, e3); cx(e1, e2);
 		cx(e0, e1); cx(e2, e3);
-		s_keys[i] = e0; s_keys[i + 1] = e1; s_keys[i + 2] = e2; s_keys[i + 3] = e3;
+		const int p0 = lds_swz(i);   // i is a multiple of 4: i + 1, i + 2, i + 3 = i ^ 1, i ^ 2, i ^ 3
+		s_keys[p0] = e0; s_keys[p0 ^ lds_swz(1)] = e1; s_keys[p0 ^ lds_swz(2)] = e2; s_keys[p0 ^ lds_swz(3)] = e3;
 	}
-	bitonic_sort_asc<NT, true>(s_keys, n, tid, 8);
-	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)s_keys[i];
+	bitonic_sort_asc<NT, true>(keys, n, tid, 8);
+	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)keys[i];
 }
 
 // Small class: one workgroup per tile, n <= BSR_SORT_SMALL.
@@ -607,15 +652,16 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= CH) return;
 		uint64_t* k = keys + start;
+		const LdsKeys lk{s_keys};
 		int n2 = 1;
 		while (n2 < n) n2 <<= 1;
 		// runs of CH: every chunk sorted on its own in LDS
 		for (int base = 0; base < n; base += CH) {
 			const int m = min(CH, n - base);
 			__syncthreads();
-			for (int i = tid; i < m; i += NT) s_keys[i] = elem_key(load_elem(elems + start + base + i));
-			bitonic_sort_asc<NT>(s_keys, m, tid);
-			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
+			for (int i = tid; i < m; i += NT) lk[i] = elem_key(load_elem(elems + start + base + i));
+			bitonic_sort_asc<NT>(lk, m, tid);
+			for (int i = tid; i < m; i += NT) k[base + i] = lk[i];
 		}
 		// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
 		for (int size = 2 * CH; size <= n2; size <<= 1) {
@@ -628,13 +674,13 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 			for (int base = 0; base < n; base += CH) {
 				const int m = min(CH, n - base);
 				__syncthreads();
-				for (int i = tid; i < m; i += NT) s_keys[i] = k[base + i];
+				for (int i = tid; i < m; i += NT) lk[i] = k[base + i];
 				for (int stride = CH >> 1; stride > 0; stride >>= 1) {
 					__syncthreads();
-					merge_stride_step<NT>(s_keys, m, CH, stride, tid);
+					merge_stride_step<NT>(lk, m, CH, stride, tid);
 				}
 				__syncthreads();
-				for (int i = tid; i < m; i += NT) k[base + i] = s_keys[i];
+				for (int i = tid; i < m; i += NT) k[base + i] = lk[i];
 			}
 		}
 		__syncthreads();
