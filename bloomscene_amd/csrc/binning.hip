@@ -392,43 +392,28 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 }
 
 // ---- per-tile bitonic sort of 64-bit keys ----
-// One workgroup per tile.  Segments of up to CAP keys are sorted in LDS.  Longer ones (rare: a
-// tile overlapped by > 8192 splats) run the same network hybrid: every 8192-key chunk is sorted in
-// LDS, then each merge does only its steps with partner distance >= 8192 in global memory and
-// finishes chunk by chunk in LDS.
-// The network is the all-ascending form of bitonic sort (first step of every merge compares
-// mirrored partners), so keys beyond n behave as +infinity pads without ever being stored:
-// a compare-exchange whose upper index is >= n is a no-op.
-//
-// LDS bank swizzle.  The keys are 8 bytes: a ds_read_b64 is served in two groups of 32 lanes, conflict-free when
-// the 32 key slots differ mod 32; a ds_write_b64 in four groups of 16 lanes, slots mod 16.  The network's short
-// strides break that badly: with keys at their natural index a thread of the stride-(2, 1) pair owns keys 4i .. 4i+3,
-// so 32 lanes hit 8 slots mod 32 (4-way), and every pair with a stride below 32 is 2- to 4-way on reads and worse on
-// writes -- PMC: SQ_LDS_BANK_CONFLICT = 61 % of the small class's LDS cycles, and the LDS array, not the VALU, was
-// the kernel's bound (82 % busy).  Key i therefore lives in slot
-//     swz(i) = i ^ ((i >> 2) & 31) ^ ((i >> 1) & 1),
-// a bijection of [0, n2) for every power of two n2 (bits are only ever folded downwards), found by enumerating
-// XOR-linear maps against the access patterns of every step of the network for 256 .. 8192 keys, 256 .. 1024
-// threads: all reads and writes of all steps, the load and the read-out become conflict-free.  swz is linear over
-// XOR and the four keys of a step pair differ from the first by wave-uniform bit patterns (i | h == i ^ h there,
-// mirrored partners are i ^ (size - 1)), so a thread swizzles ONE index per pair and reaches the others with XORs
-// of scalar constants.
-__device__ __host__ __forceinline__ constexpr int lds_swz(int i) { return i ^ ((i >> 2) & 31) ^ ((i >> 1) & 1); }
-struct LdsKeys {   // an LDS key array addressed through the swizzle (the global-memory arrays stay plain pointers)
-	uint64_t* p;
-	__device__ __forceinline__ uint64_t& operator[](int i) const { return p[lds_swz(i)]; }
-};
-
-template <typename KeyPtr>
-__device__ __forceinline__ void cmp_exchange(KeyPtr k, int lo, int hi)
+// Order = (tile, depth bits, Gaussian id) = the reference's stable radix-sort order (rasterizer_impl.cu:304-309): the
+// tile part is done by the radix passes, here every tile's segment is sorted on the 64-bit key (depth bits, id).
+// The network is the all-ascending form of bitonic sort (first step of every merge compares mirrored partners), so
+// keys beyond n behave as +infinity pads.  Segments of up to 8192 keys are sorted in LDS by the round-based network
+// below; longer ones (rare: a tile overlapped by > 8192 splats) run hybrid: every 8192-key chunk is sorted in LDS,
+// then each merge does only its steps with partner distance >= 8192 in global memory (the plain steps right here)
+// and finishes chunk by chunk in LDS.
+#define BSR_PAD_KEY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ void cx(uint64_t& a, uint64_t& b)
+{
+	const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+	a = lo;
+	b = hi;
+}
+__device__ __forceinline__ void cmp_exchange(uint64_t* k, int lo, int hi)
 {
 	const uint64_t a = k[lo], b = k[hi];
 	if (a > b) { k[lo] = b; k[hi] = a; }
 }
-
-// mirrored first step of the merge that builds sorted runs of `size`
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void merge_mirror_step(KeyPtr k, int n, int n2, int size, int tid)
+// global-memory steps of the hybrid (a compare-exchange whose upper index is >= n is the no-op a pad needs)
+template <int NT>
+__device__ __forceinline__ void merge_mirror_step(uint64_t* k, int n, int n2, int size, int tid)
 {
 	const int half = size >> 1, sh = __builtin_ctz(half);
 	for (int i = tid; i < (n2 >> 1); i += NT) {
@@ -437,9 +422,8 @@ __device__ __forceinline__ void merge_mirror_step(KeyPtr k, int n, int n2, int s
 		if (hi < n) cmp_exchange(k, blk * size + off, hi);
 	}
 }
-
-template <int NT, typename KeyPtr>
-__device__ __forceinline__ void merge_stride_step(KeyPtr k, int n, int n2, int stride, int tid)
+template <int NT>
+__device__ __forceinline__ void merge_stride_step(uint64_t* k, int n, int n2, int stride, int tid)
 {
 	for (int i = tid; i < (n2 >> 1); i += NT) {
 		const int lo = ((i & ~(stride - 1)) << 1) | (i & (stride - 1));
@@ -448,155 +432,273 @@ __device__ __forceinline__ void merge_stride_step(KeyPtr k, int n, int n2, int s
 	}
 }
 
-__device__ __forceinline__ void cx(uint64_t& a, uint64_t& b)
-{
-	const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
-	a = lo;
-	b = hi;
-}
-
-// Two network steps per LDS round trip: a thread holds the four keys that the two steps connect (pads beyond n
-// are +infinity and never move, so a compare-exchange with a pad is the no-op the network needs).  The sort is
-// instruction-issue bound (PMC: ~30 instructions per wave and step, 8 workgroups per CU), so the LDS classes
-// store their pads (PADDED: the array holds n2 keys) and run without any bounds test.
-#define BSR_PAD_KEY 0xFFFFFFFFFFFFFFFFull
-template <bool PADDED, typename KeyPtr>
-__device__ __forceinline__ void quad_steps(KeyPtr k, int n, int i0, int i1, int i2, int i3, bool mirror)
-{
-	if (PADDED) {
-		uint64_t e0 = k[i0], e1 = k[i1], e2 = k[i2], e3 = k[i3];
-		if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
-		cx(e0, e1);
-		cx(e2, e3);
-		k[i0] = e0; k[i1] = e1; k[i2] = e2; k[i3] = e3;
-		return;
-	}
-	if (i0 >= n) return;
-	const uint64_t o0 = k[i0], o1 = i1 < n ? k[i1] : BSR_PAD_KEY, o2 = i2 < n ? k[i2] : BSR_PAD_KEY,
-	               o3 = i3 < n ? k[i3] : BSR_PAD_KEY;
-	uint64_t e0 = o0, e1 = o1, e2 = o2, e3 = o3;
-	if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
-	cx(e0, e1);
-	cx(e2, e3);
-	if (e0 != o0) k[i0] = e0;
-	if (i1 < n && e1 != o1) k[i1] = e1;
-	if (i2 < n && e2 != o2) k[i2] = e2;
-	if (i3 < n && e3 != o3) k[i3] = e3;
-}
-
-// The padded LDS classes: slot of the first key + the three (wave-uniform) slot differences
-__device__ __forceinline__ void quad_steps_slots(uint64_t* p, int p0, int d1, int d2, int d3, bool mirror)
-{
-	uint64_t e0 = p[p0], e1 = p[p0 ^ d1], e2 = p[p0 ^ d2], e3 = p[p0 ^ d3];
-	if (mirror) { cx(e0, e3); cx(e1, e2); } else { cx(e0, e2); cx(e1, e3); }
-	cx(e0, e1);
-	cx(e2, e3);
-	p[p0] = e0; p[p0 ^ d1] = e1; p[p0 ^ d2] = e2; p[p0 ^ d3] = e3;
-}
-
-// mirrored first step of the merge that builds runs of `size` (>= 4) + its stride size/4 step
-template <int NT, bool PADDED, typename KeyPtr>
-__device__ __forceinline__ void merge_mirror_pair(KeyPtr k, int n, int n2, int size, int tid)
-{
-	const int q = size >> 2, sh = __builtin_ctz(q);
-	if constexpr (PADDED) {
-		// keys base + off, .. + q, base + size - 1 - off - q, base + size - 1 - off = i0, i0 ^ q, i0 ^ (size - 1) ^ q, i0 ^ (size - 1)
-		const int d1 = lds_swz(q), d2 = lds_swz((size - 1) ^ q), d3 = lds_swz(size - 1);
-		for (int i = tid; i < (n2 >> 2); i += NT)
-			quad_steps_slots(k.p, lds_swz(((i >> sh) * size) | (i & (q - 1))), d1, d2, d3, true);
-	} else {
-		for (int i = tid; i < (n2 >> 2); i += NT) {
-			const int blk = i >> sh, off = i & (q - 1), base = blk * size;
-			quad_steps<false>(k, n, base + off, base + off + q, base + size - 1 - off - q, base + size - 1 - off, true);
-		}
-	}
-}
-
-// stride steps s and s/2 (s >= 2)
-template <int NT, bool PADDED, typename KeyPtr>
-__device__ __forceinline__ void merge_stride_pair(KeyPtr k, int n, int n2, int s, int tid)
-{
-	const int h = s >> 1;
-	if constexpr (PADDED) {
-		const int d1 = lds_swz(h), d2 = lds_swz(s), d3 = lds_swz(s | h);
-		for (int i = tid; i < (n2 >> 2); i += NT)
-			quad_steps_slots(k.p, lds_swz(((i & ~(h - 1)) << 2) | (i & (h - 1))), d1, d2, d3, false);
-	} else {
-		for (int i = tid; i < (n2 >> 2); i += NT) {
-			const int lo = ((i & ~(h - 1)) << 2) | (i & (h - 1));
-			quad_steps<false>(k, n, lo, lo | h, lo | s, lo | s | h, false);
-		}
-	}
-}
-
-// Runs of first_size / 2 are already sorted on entry (first_size = 2: nothing is).  PADDED: k[n .. n2) hold
-// BSR_PAD_KEY (n2 = n rounded up to a power of two).
-template <int NT, bool PADDED = false, typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort_asc(KeyPtr k, int n, int tid, int first_size = 2)
-{
-	int n2 = 1;
-	while (n2 < n) n2 <<= 1;
-	const int nb = PADDED ? n2 : n;   // padded arrays: every index below n2 is real
-	for (int size = first_size; size <= n2; size <<= 1) {
-		__syncthreads();
-		if (size == 2) {
-			merge_mirror_step<NT>(k, nb, n2, size, tid);
-			continue;
-		}
-		merge_mirror_pair<NT, PADDED>(k, nb, n2, size, tid);
-		int stride = size >> 3;
-		for (; stride >= 2; stride >>= 2) {
-			__syncthreads();
-			merge_stride_pair<NT, PADDED>(k, nb, n2, stride, tid);
-		}
-		if (stride == 1) {
-			__syncthreads();
-			merge_stride_step<NT>(k, nb, n2, 1, tid);
-		}
-	}
-	__syncthreads();
-}
-
 __device__ __forceinline__ uint64_t elem_key(const BinElem e) { return ((uint64_t)e.z << 32) | (uint64_t)e.y; }
 
-// LDS sort of one segment (n <= CAP, CAP a power of two >= 4): runs of four are sorted in registers on the way
-// in and the pads up to the next power of two are stored with them
-template <int CAP, int NT>
-__device__ __forceinline__ void sort_segment_lds(uint64_t* s_keys, uint32_t start, int n, const BinElem* __restrict__ elems,
-                                                 uint32_t* __restrict__ point_list)
+// ---- round-based network: 2^M keys per thread, M network steps per LDS round trip --------------------------------
+// A thread holds K = 2^M keys of a round in registers: the M index bits a round's steps act on enumerate the thread's
+// keys, every other bit comes from the thread id, so M steps run between one read and one write of the keys (8 keys:
+// 3 steps).  With n2 / K <= 64 (two trips per round up to 128) a whole segment belongs to ONE wave and needs no
+// workgroup barrier at all: the small class sorts four tiles per workgroup, one per wave.  (Its predecessor ran two
+// steps per barrier with 4 keys per thread, half of its 256 threads idle on a 512-key tile: 65 % of its wave-cycles
+// were barrier and LDS-latency waits.)
+// A merge of runs into runs of `size` = first round: the mirrored step + strides size/4 .. size/2^M (the thread's
+// key set {i0 ^ a (size - 1) ^ sum c_b t_b} is closed under all of them), then rounds of up to M plain strides down
+// to 1.  Keys in the mirrored half are labelled with complemented stride bits so that every plain step orders
+// "bit clear below bit set" in both halves.
+// LDS bank swizzle.  The keys are 8 bytes: a ds_read_b64 is served in two groups of 32 lanes, conflict-free when the
+// 32 key slots differ mod 32; a ds_write_b64 in four groups of 16 lanes, slots mod 16.  With keys at their natural
+// index the short strides are 2- to 4-way conflicts on every access (PMC on the predecessor: SQ_LDS_BANK_CONFLICT =
+// 61 % of its LDS cycles).  Key i lives in slot i ^ ((i >> M) & 31): a bijection of [0, n2) for every power of two n2
+// (bits are only folded downwards), found by enumerating XOR-linear maps against the access pattern of every round
+// (M zero bits inserted into the thread index at any position), the load and the read-out: all conflict-free.  It is
+// linear over XOR, so a thread swizzles ONE index per round and reaches its other keys by XOR with wave-uniform
+// constants.
+template <int M> __device__ __forceinline__ constexpr int swz_m(int i) { return i ^ ((i >> M) & 31); }
+
+// Compare-exchange flavours.  F64: the keys of a segment whose depth bits all lie in [0x00100000, 0x7ff00000) are
+// positive, normal, finite doubles when read as binary64, and for those the unsigned order of the bit patterns IS
+// the numeric order: v_min_f64 / v_max_f64 return one operand unchanged each, two instructions instead of a 64-bit
+// compare and four selects (selects and compares issue at 4.25 cycles on gfx950, the sort is bound by exactly these).
+// The pad is +infinity (above every such key).  Segments holding any other depth pattern (NaN payloads, denormal or
+// non-positive depths: the reference orders them by raw bits too) take the integer flavour.
+#define BSR_PAD_F64 0x7FF0000000000000ull
+template <bool F64>
+__device__ __forceinline__ void cxt(uint64_t& a, uint64_t& b)
 {
-	const int tid = threadIdx.x;
-	const LdsKeys keys{s_keys};
-	int n2 = 4;
-	while (n2 < n) n2 <<= 1;
-	for (int i = tid * 4; i < n2; i += NT * 4) {
-		uint64_t e0 = i + 0 < n ? elem_key(load_elem(elems + start + i)) : BSR_PAD_KEY;
-		uint64_t e1 = i + 1 < n ? elem_key(load_elem(elems + start + i + 1)) : BSR_PAD_KEY;
-		uint64_t e2 = i + 2 < n ? elem_key(load_elem(elems + start + i + 2)) : BSR_PAD_KEY;
-		uint64_t e3 = i + 3 < n ? elem_key(load_elem(elems + start + i + 3)) : BSR_PAD_KEY;
-		cx(e0, e1); cx(e2, e3);
-		cx(e0, e3); cx(e1, e2);
-		cx(e0, e1); cx(e2, e3);
-		const int p0 = lds_swz(i);   // i is a multiple of 4: i + 1, i + 2, i + 3 = i ^ 1, i ^ 2, i ^ 3
-		s_keys[p0] = e0; s_keys[p0 ^ lds_swz(1)] = e1; s_keys[p0 ^ lds_swz(2)] = e2; s_keys[p0 ^ lds_swz(3)] = e3;
+	if constexpr (F64) {
+		double lo, hi;
+		const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+		asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+		asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+		a = (uint64_t)__double_as_longlong(lo);
+		b = (uint64_t)__double_as_longlong(hi);
+	} else {
+		cx(a, b);
 	}
-	bitonic_sort_asc<NT, true>(keys, n, tid, 8);
-	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)keys[i];
+}
+__device__ __forceinline__ bool key_is_plain_double(uint64_t k)
+{
+	const uint32_t h = (uint32_t)(k >> 32);
+	return h >= 0x00100000u && h < 0x7ff00000u;
 }
 
-// Small class: one workgroup per tile, n <= BSR_SORT_SMALL.
+template <int M, int BIT, bool F64>
+__device__ __forceinline__ void reg_step(uint64_t (&e)[1 << M])
+{
+#pragma unroll
+	for (int c = 0; c < (1 << M); c++)
+		if (!(c & (1 << BIT))) cxt<F64>(e[c], e[c | (1 << BIT)]);
+}
+// plain steps on local bits NS-1 .. 0
+template <int M, int NS, bool F64>
+__device__ __forceinline__ void reg_steps(uint64_t (&e)[1 << M])
+{
+	if constexpr (NS > 0) {
+		reg_step<M, NS - 1, F64>(e);
+		reg_steps<M, NS - 1, F64>(e);
+	}
+}
+// mirrored step: local index (a, c), a = top bit: (0, c) <-> (1, ~c)
+template <int M, bool F64>
+__device__ __forceinline__ void reg_mirror(uint64_t (&e)[1 << M])
+{
+	constexpr int H = 1 << (M - 1);
+#pragma unroll
+	for (int c = 0; c < H; c++) cxt<F64>(e[c], e[H + (H - 1 - c)]);
+}
+// the K keys of a thread, ascending, entirely in registers (bitonic: sizes 2 .. K)
+template <int M, bool F64>
+__device__ __forceinline__ void reg_sort(uint64_t (&e)[1 << M])
+{
+#pragma unroll
+	for (int sbit = 1; sbit <= M; sbit++) {
+#pragma unroll
+		for (int c = 0; c < (1 << M); c++)
+			if (!(c & (1 << (sbit - 1)))) {
+				const int partner = c ^ ((1 << sbit) - 1);
+				cxt<F64>(e[c], e[partner]);
+			}
+#pragma unroll
+		for (int b = sbit - 2; b >= 0; b--)
+#pragma unroll
+			for (int c = 0; c < (1 << M); c++)
+				if (!(c & (1 << b))) cxt<F64>(e[c], e[c | (1 << b)]);
+	}
+}
+
+// byte offset of local key L from the thread's first slot: XOR of the deltas of L's set bits (all wave-uniform)
+template <int M>
+__device__ __forceinline__ int local_delta(const int (&d)[M], int L)
+{
+	int x = 0;
+#pragma unroll
+	for (int b = 0; b < M; b++)
+		if (L & (1 << b)) x ^= d[b];
+	return x;
+}
+template <int M>
+__device__ __forceinline__ void round_load(const char* lds, int p0, const int (&d)[M], uint64_t (&e)[1 << M])
+{
+#pragma unroll
+	for (int L = 0; L < (1 << M); L++) e[L] = *reinterpret_cast<const uint64_t*>(lds + (p0 ^ local_delta<M>(d, L)));
+}
+template <int M>
+__device__ __forceinline__ void round_store(char* lds, int p0, const int (&d)[M], const uint64_t (&e)[1 << M])
+{
+#pragma unroll
+	for (int L = 0; L < (1 << M); L++) *reinterpret_cast<uint64_t*>(lds + (p0 ^ local_delta<M>(d, L))) = e[L];
+}
+
+template <bool BLOCK>
+__device__ __forceinline__ void round_sync()
+{
+	if (BLOCK) {
+		__syncthreads();
+	} else {   // one wave owns the segment: its LDS operations execute in order; only the compiler must not reorder
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
+// The plain strides 2^(rem-1) .. 1 of a merge, M per round, over n2 keys (slots swz_m<M>); t = thread index among
+// the NT threads that share the segment.
+template <int NT, int M, bool BLOCK, bool F64>
+__device__ __forceinline__ void lds_stride_rounds(uint64_t* keys, int n2, int rem, int t)
+{
+	char* const lds = reinterpret_cast<char*>(keys);
+	while (rem > 0) {
+		const int ns = min(M, rem);
+		const int lo = max(rem - M, 0);   // local bit b <-> index bit lo + b; a last, short round steps on bits ns-1 .. 0 only
+		int d[M];
+#pragma unroll
+		for (int b = 0; b < M; b++) d[b] = swz_m<M>(1 << (lo + b)) << 3;
+		round_sync<BLOCK>();
+		for (int i = t; i < (n2 >> M); i += NT) {
+			const int i0 = ((i >> lo) << (lo + M)) | (i & ((1 << lo) - 1));
+			const int p0 = swz_m<M>(i0) << 3;
+			uint64_t e[1 << M];
+			round_load<M>(lds, p0, d, e);
+			if (ns == M) reg_steps<M, M, F64>(e);
+			else if (M > 3 && ns == 3) reg_steps<M, (M > 3 ? 3 : 1), F64>(e);
+			else if (ns == 2) reg_steps<M, 2, F64>(e);
+			else reg_steps<M, 1, F64>(e);
+			round_store<M>(lds, p0, d, e);
+		}
+		rem -= ns;
+	}
+}
+
+// Ascending sort of n2 (a power of two >= 2^M) keys in LDS whose aligned runs of 2^M are sorted already; pads
+// (BSR_PAD_KEY) are ordinary keys.  Ends with a sync.
+template <int NT, int M, bool BLOCK, bool F64>
+__device__ __forceinline__ void lds_sort_rounds(uint64_t* keys, int n2, int t)
+{
+	static_assert(M == 3 || M == 4, "8 or 16 keys per thread");
+	char* const lds = reinterpret_cast<char*>(keys);
+	for (int size = 2 << M; size <= n2; size <<= 1) {
+		const int k = __builtin_ctz(size), lo = k - M, tlow = 1 << lo;
+		// first round: mirror + strides size/4 .. size/2^M.  Local bits 0 .. M-2 <-> strides tlow << b; the top local
+		// bit selects the mirrored half, whose keys carry complemented stride bits: its delta is (size - 1) ^ all strides
+		int d[M], low_all = 0;
+#pragma unroll
+		for (int b = 0; b < M - 1; b++) {
+			d[b] = swz_m<M>(tlow << b) << 3;
+			low_all ^= tlow << b;
+		}
+		d[M - 1] = swz_m<M>((size - 1) ^ low_all) << 3;
+		round_sync<BLOCK>();
+		for (int i = t; i < (n2 >> M); i += NT) {
+			const int i0 = ((i >> lo) << k) | (i & (tlow - 1));
+			const int p0 = swz_m<M>(i0) << 3;
+			uint64_t e[1 << M];
+			round_load<M>(lds, p0, d, e);
+			reg_mirror<M, F64>(e);
+			reg_steps<M, M - 1, F64>(e);
+			round_store<M>(lds, p0, d, e);
+		}
+		lds_stride_rounds<NT, M, BLOCK, F64>(keys, n2, k - M, t);
+	}
+	round_sync<BLOCK>();
+}
+
+// One segment of n <= n2 keys, sorted by the NT threads (thread index t) that share `keys` (n2 slots).  Runs of 2^M
+// are sorted in registers on the way in (integer compare-exchange: the flavour of the merges is only known once every
+// key has been seen) and the pads up to n2 are stored with them; returns this thread's vote on "every key I loaded is
+// a positive, normal, finite binary64".
+template <int NT, int M>
+__device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_t start, int n, int t,
+                                                 const BinElem* __restrict__ elems)
+{
+	constexpr int K = 1 << M;
+	bool plain = true;
+	for (int i = t * K; i < n2; i += NT * K) {
+		uint64_t e[K];
+#pragma unroll
+		for (int j = 0; j < K; j++) {
+			e[j] = i + j < n ? elem_key(load_elem(elems + start + i + j)) : BSR_PAD_KEY;
+			plain = plain && (i + j >= n || key_is_plain_double(e[j]));
+		}
+		reg_sort<M, false>(e);
+		const int p0 = swz_m<M>(i);   // i is a multiple of K: i + j == i ^ j
+#pragma unroll
+		for (int j = 0; j < K; j++) keys[p0 ^ swz_m<M>(j)] = e[j];
+	}
+	return plain;
+}
+template <int NT, int M, bool BLOCK, bool F64>
+__device__ __forceinline__ void merge_loaded_runs(uint64_t* keys, int n2, uint32_t start, int n, int t,
+                                                  uint32_t* __restrict__ point_list)
+{
+	if (F64) {   // the pads become +infinity (they sit at the ends of their runs either way)
+		round_sync<BLOCK>();
+		for (int i = n + t; i < n2; i += NT) keys[swz_m<M>(i)] = BSR_PAD_F64;
+	}
+	lds_sort_rounds<NT, M, BLOCK, F64>(keys, n2, t);
+	for (int i = t; i < n; i += NT) point_list[start + i] = (uint32_t)keys[swz_m<M>(i)];
+}
+
+// Wave-owned segment: load, pick the compare-exchange flavour, sort.  No workgroup barrier anywhere.
+template <int M>
+__device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32_t start, int n, int lane,
+                                                  const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list)
+{
+	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems);
+	if (wave_ballot(!plain) == 0ull)
+		merge_loaded_runs<64, M, false, true>(keys, n2, start, n, lane, point_list);
+	else
+		merge_loaded_runs<64, M, false, false>(keys, n2, start, n, lane, point_list);
+}
+
+// Workgroup-owned segment (the wide classes): the same, with workgroup barriers and a workgroup vote.
+template <int NT, int M>
+__device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint32_t start, int n, int tid,
+                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list)
+{
+	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems);
+	if (__syncthreads_and(plain))
+		merge_loaded_runs<NT, M, true, true>(keys, n2, start, n, tid, point_list);
+	else
+		merge_loaded_runs<NT, M, true, false>(keys, n2, start, n, tid, point_list);
+}
+
+// Small class (n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
+// lane and round (16 in two trips beyond 512 keys).
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const BinElem* __restrict__ elems,
                                                           uint32_t* __restrict__ point_list)
 {
-	__shared__ uint64_t s_keys[BSR_SORT_SMALL];
-	const int tile = blockIdx.x;
+	__shared__ uint64_t s_keys[4][BSR_SORT_SMALL];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * 4 + wave;
 	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
-	if (n > BSR_SORT_SMALL) return;   // on the big-tile list
-	sort_segment_lds<BSR_SORT_SMALL, 256>(s_keys, start, n, elems, point_list);
+	if (n > BSR_SORT_SMALL || n <= 0) return;   // on the big-tile list / empty
+	int n2 = 8;
+	while (n2 < n) n2 <<= 1;
+	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list);   // (> 512 keys: two runs per lane)
 }
 
 // Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
@@ -614,7 +716,9 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n <= min_n || n > CAP) return;   // another class (uniform over the workgroup)
-	sort_segment_lds<CAP, NT>(s_keys, start, n, elems, point_list);
+	int n2 = 1024;
+	while (n2 < n) n2 <<= 1;
+	sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list);
 }
 
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
@@ -641,7 +745,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 		const uint32_t start = tile_start[tile];
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= 4096 || n > CH) return;   // (uniform over the workgroup)
-		sort_segment_lds<CH, NT>(s_keys, start, n, elems, point_list);
+		sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list);
 		return;
 	}
 	b -= g4;
@@ -652,16 +756,15 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= CH) return;
 		uint64_t* k = keys + start;
-		const LdsKeys lk{s_keys};
 		int n2 = 1;
 		while (n2 < n) n2 <<= 1;
-		// runs of CH: every chunk sorted on its own in LDS
+		// runs of CH: every chunk sorted on its own in LDS (integer flavour: the global steps compare integers too)
 		for (int base = 0; base < n; base += CH) {
 			const int m = min(CH, n - base);
 			__syncthreads();
-			for (int i = tid; i < m; i += NT) lk[i] = elem_key(load_elem(elems + start + base + i));
-			bitonic_sort_asc<NT>(lk, m, tid);
-			for (int i = tid; i < m; i += NT) k[base + i] = lk[i];
+			load_sorted_runs<NT, 3>(s_keys, CH, start + (uint32_t)base, m, tid, elems);
+			lds_sort_rounds<NT, 3, true, false>(s_keys, CH, tid);
+			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
 		}
 		// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
 		for (int size = 2 * CH; size <= n2; size <<= 1) {
@@ -674,13 +777,10 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 			for (int base = 0; base < n; base += CH) {
 				const int m = min(CH, n - base);
 				__syncthreads();
-				for (int i = tid; i < m; i += NT) lk[i] = k[base + i];
-				for (int stride = CH >> 1; stride > 0; stride >>= 1) {
-					__syncthreads();
-					merge_stride_step<NT>(lk, m, CH, stride, tid);
-				}
+				for (int i = tid; i < CH; i += NT) s_keys[swz_m<3>(i)] = i < m ? k[base + i] : BSR_PAD_KEY;
+				lds_stride_rounds<NT, 3, true, false>(s_keys, CH, 13, tid);   // strides CH/2 .. 1
 				__syncthreads();
-				for (int i = tid; i < m; i += NT) k[base + i] = lk[i];
+				for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
 			}
 		}
 		__syncthreads();
@@ -735,7 +835,7 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_sort_tiles_small, dim3(T), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
+	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
 	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
 	const int g1 = min(T, n_bound / (BSR_SORT_SMALL + 1)), g4 = min(T, n_bound / 4097),

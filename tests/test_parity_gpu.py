@@ -645,7 +645,9 @@ def test_library_owns_no_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     outside1 = total - free1 - torch.cuda.memory_reserved()
-    assert abs(outside1 - outside0) < (8 << 20), (outside0, outside1)
+    # (growth only: the HIP runtime may RELEASE memory of its own meanwhile -- kernel scratch of earlier tests in this
+    # process was seen to shrink by 400 MB here -- which says nothing about the library)
+    assert outside1 - outside0 < (8 << 20), (outside0, outside1)
     assert torch.cuda.max_memory_allocated() - alloc0 >= 52 * R          # the scratch is on torch's books
     assert np.isfinite(out["mean3D"]).all()
 
