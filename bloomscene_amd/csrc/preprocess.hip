@@ -122,13 +122,19 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	float4 rq0 = make_float4(0.f, 0.f, 0.f, 0.f), rq1 = rq0, rq2 = rq0;   // splat record, stored at the end
 
 	const int ld = in_range ? idx : 0;
-	const float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
+	float3 p = make_float3(a.means3D[3 * ld], a.means3D[3 * ld + 1], a.means3D[3 * ld + 2]);
 	const float* vm = a.viewmatrix + 16 * view;
 	const float* pm = a.projmatrix + 16 * view;
-	const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
-	bool alive = in_range && !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
+	float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+	const bool alive = in_range && !(pvz <= BSR_NEAR);   // reference auxiliary.h:154
 	if (in_range && !alive && a.prefiltered) a.flags[0] = 1;
 
+	// ---- part 1, per Gaussian: everything up to the tile rect (reference forward.cu:186-236).  `vis` = the rect is
+	// not empty; what part 2 needs of a visible Gaussian stays in these variables.
+	bool vis = false;
+	float cov3D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+	float conic_a = 0.f, conic_b = 0.f, conic_c = 0.f, pix_x = 0.f, pix_y = 0.f;
+	int rmin[2] = {0, 0}, rmax[2] = {0, 0};
 	if (alive) {
 		const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
 		const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
@@ -136,7 +142,6 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		const float p_w = 1.0f / (hw + 0.0000001f);
 		const float projx = hx * p_w, projy = hy * p_w;
 
-		float cov3D[6];
 		if (a.cov3D_precomp != nullptr) {
 #pragma unroll
 			for (int k = 0; k < 6; k++) cov3D[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
@@ -154,94 +159,158 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		const float det = (ca * cc - cb * cb);
 		if (det != 0.0f) {
 			const float det_inv = 1.f / det;
-			const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+			conic_a = cc * det_inv;
+			conic_b = -cb * det_inv;
+			conic_c = ca * det_inv;
 			const float mid = 0.5f * (ca + cc);
 			const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
 			const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
 			const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-			const float pix_x = ndc2pix(projx, a.W), pix_y = ndc2pix(projy, a.H);
-			int rmin[2], rmax[2];
+			pix_x = ndc2pix(projx, a.W);
+			pix_y = ndc2pix(projy, a.H);
 			get_rect(pix_x, pix_y, (int)my_radius, a.gx, a.gy, rmin, rmax);
 			if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) != 0) {
 				radius_out = (int)my_radius;
-				if (!FILTER_ONLY) {
-					rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)(rmin[1] + ty_off),
-					                        (unsigned short)rmax[0], (unsigned short)(rmax[1] + ty_off));
-					// kept for the backward, which only visits Gaussians with radius > 0 (the reference stores it for
-					// every Gaussian in front of the camera, rasterizer_impl.cu / forward.cu:208-214)
-#pragma unroll
-					for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)id * 6 + k] = cov3D[k];
-					float rgb[3];
-					uint8_t clamp_bits = 0;
-					if (COLOR == 1) {
-						sh3_to_rgb_stream(p, a.cam_pos + 3 * view, a.shs + (size_t)idx * 48, rgb, clamp_bits);
-					} else if (COLOR == 0 && a.colors_precomp == nullptr) {
-						sh_to_rgb(a.D, a.M, p, a.cam_pos + 3 * view, a.shs + (size_t)idx * a.M * 3, rgb, clamp_bits);
-					} else {
-						rgb[0] = a.colors_precomp[3 * idx];
-						rgb[1] = a.colors_precomp[3 * idx + 1];
-						rgb[2] = a.colors_precomp[3 * idx + 2];
-					}
-					const float opacity = a.opacities[idx];
-					// alpha = min(0.99, o*exp(power)) < 1/255  <=>  power < -ln(255*o); keep a margin far
-					// above the rounding of logf/expf so the cut only skips pairs the exact test rejects.
-					const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
-					// The record carries the conic pre-scaled: (-a/2, -b, -c/2).  Scaling by a power of two commutes with
-					// every rounding, so the walks' power = (ha dx) dx + (hc dy) dy + (nb dx) dy is bit for bit the
-					// reference's -0.5f * (a dx dx + c dy dy) - b dx dy (forward.cu:419) with one multiply less per pair.
-					rq0 = make_float4(pix_x, pix_y, -0.5f * conic_a, -conic_b);
-					rq1 = make_float4(-0.5f * conic_c, power_cut, opacity, pvz);
-					a.geom.clamped[id] = clamp_bits;
-					// Keep one instance per tile of the rect the splat can actually reach: the reference
-					// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
-					// alpha < 1/255 everywhere only ever `continue` in its render loops, so dropping them
-					// changes no pixel.  Rects of more than 64 tiles are kept whole (mask too short).
-					const uint32_t area = (uint32_t)(rmax[0] - rmin[0]) * (uint32_t)(rmax[1] - rmin[1]);
-					const bool pd = (conic_a > 0.0f) && (conic_c > 0.0f) && (conic_a * conic_c - conic_b * conic_b > 0.0f);
-					const float rb_c = -conic_b / conic_c, rb_a = -conic_b / conic_a;
-					if (area <= 64u) {
-						// Axis-aligned bounding box of the region {alpha >= 1/255} = {q(d) <= t}, t = -(cut - slack):
-						// |dx| <= sqrt(2 t c / det), |dy| <= sqrt(2 t a / det).  Tiles outside it are dropped
-						// without the edge test; NaN / non-PD conics fall back to the whole rect.
-						int x0 = rmin[0], x1 = rmax[0], y0 = rmin[1], y1 = rmax[1];
-						const float tq = -(power_cut - (1.0e-3f + 1.0e-4f * fabsf(power_cut)));
-						const float cdet = conic_a * conic_c - conic_b * conic_b;
-						if (pd) {
-							if (tq < 0.0f) {
-								x1 = x0;   // opacity below 1/255: nothing is ever blended
-							} else {
-								const float hx = sqrtf(2.0f * tq * conic_c / cdet) * 1.0001f + 0.01f;
-								const float hy = sqrtf(2.0f * tq * conic_a / cdet) * 1.0001f + 0.01f;
-								if (hx == hx && hy == hy) {
-									// tile x holds pixel centres [16x, 16x+15]
-									x0 = max(x0, (int)ceilf((pix_x - hx - 15.0f) * (1.0f / BSR_TILE)));
-									x1 = min(x1, (int)floorf((pix_x + hx) * (1.0f / BSR_TILE)) + 1);
-									y0 = max(y0, (int)ceilf((pix_y - hy - 15.0f) * (1.0f / BSR_TILE)));
-									y1 = min(y1, (int)floorf((pix_y + hy) * (1.0f / BSR_TILE)) + 1);
-								}
-							}
-						}
-						const int w = rmax[0] - rmin[0];
-						for (int y = y0; y < y1; y++)
-							for (int x = x0; x < x1; x++) {
-								if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
-								                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
-									kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
-									atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
-								}
-							}
-					} else {
-						for (int y = rmin[1]; y < rmax[1]; y++)
-							for (int x = rmin[0]; x < rmax[0]; x++)
-								atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
-					}
-					rq2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
-				}
+				vis = true;
 			}
 		}
 	}
 	if (in_range && a.radii) a.radii[(size_t)view * a.P + idx] = radius_out;
-	if (!FILTER_ONLY) {
+	if (FILTER_ONLY) return;
+	// rows without a rect need nothing else (readers look at the rect first); the padding rows between the views of a
+	// batched call are rows too
+	if (!vis && (in_range || a.n_views > 1)) a.geom.rect[id] = make_ushort4(0, 0, 0, 0);
+
+	// ---- re-pack.  Part 2 (SH evaluation, the exact tile cull, the record) is 70 % of the kernel's instructions and a
+	// wave runs it as long as ONE of its lanes is visible: on a camera sweep ~5 % of the Gaussians are, spread over
+	// every wave, and the kernel was bound by exactly that divergence.  When the workgroup's visible Gaussians fit
+	// fewer waves than they occupy, they are handed (through LDS, in id order) to the first threads of the workgroup:
+	// thread t continues as the t-th visible Gaussian `li` of the workgroup, the other waves skip part 2.  Every value
+	// is computed by the same instructions as before, only on another lane; the instance numbering below follows the
+	// thread order, which is still the id order.
+	int li = (int)threadIdx.x;   // Gaussian of the workgroup this thread works for from here on
+	{
+		constexpr int PACK_MAX = 128, NF = 21;
+		__shared__ uint32_t s_pack[NF][PACK_MAX];
+		__shared__ uint32_t s_nvis[4];
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		const uint64_t vm_mask = wave_ballot(vis);
+		if (lane == 0) s_nvis[wave] = (uint32_t)__popcll(vm_mask);
+		__syncthreads();
+		const uint32_t v0 = s_nvis[0], v1 = s_nvis[1], v2 = s_nvis[2], v3 = s_nvis[3];
+		const int n_vis = (int)(v0 + v1 + v2 + v3);
+		const int waves_now = (v0 != 0) + (v1 != 0) + (v2 != 0) + (v3 != 0);
+		if (n_vis <= PACK_MAX && ((n_vis + 63) >> 6) < waves_now) {   // workgroup-uniform
+			if (vis) {
+				const int slot = (int)((wave > 0 ? v0 : 0u) + (wave > 1 ? v1 : 0u) + (wave > 2 ? v2 : 0u)) +
+				                 __popcll(vm_mask & ((1ull << lane) - 1ull));
+				s_pack[0][slot] = (uint32_t)threadIdx.x;
+				s_pack[1][slot] = __float_as_uint(p.x); s_pack[2][slot] = __float_as_uint(p.y); s_pack[3][slot] = __float_as_uint(p.z);
+#pragma unroll
+				for (int k = 0; k < 6; k++) s_pack[4 + k][slot] = __float_as_uint(cov3D[k]);
+				s_pack[10][slot] = __float_as_uint(conic_a); s_pack[11][slot] = __float_as_uint(conic_b); s_pack[12][slot] = __float_as_uint(conic_c);
+				s_pack[13][slot] = (uint32_t)radius_out;
+				s_pack[14][slot] = __float_as_uint(pix_x); s_pack[15][slot] = __float_as_uint(pix_y);
+				s_pack[16][slot] = (uint32_t)rmin[0]; s_pack[17][slot] = (uint32_t)rmin[1];
+				s_pack[18][slot] = (uint32_t)rmax[0]; s_pack[19][slot] = (uint32_t)rmax[1];
+				s_pack[20][slot] = __float_as_uint(pvz);
+			}
+			__syncthreads();
+			const int t = (int)threadIdx.x;
+			vis = t < n_vis;
+			radius_out = 0;
+			if (vis) {
+				li = (int)s_pack[0][t];
+				p = make_float3(__uint_as_float(s_pack[1][t]), __uint_as_float(s_pack[2][t]), __uint_as_float(s_pack[3][t]));
+#pragma unroll
+				for (int k = 0; k < 6; k++) cov3D[k] = __uint_as_float(s_pack[4 + k][t]);
+				conic_a = __uint_as_float(s_pack[10][t]); conic_b = __uint_as_float(s_pack[11][t]); conic_c = __uint_as_float(s_pack[12][t]);
+				radius_out = (int)s_pack[13][t];
+				pix_x = __uint_as_float(s_pack[14][t]); pix_y = __uint_as_float(s_pack[15][t]);
+				rmin[0] = (int)s_pack[16][t]; rmin[1] = (int)s_pack[17][t];
+				rmax[0] = (int)s_pack[18][t]; rmax[1] = (int)s_pack[19][t];
+				pvz = __uint_as_float(s_pack[20][t]);
+			}
+		}
+	}
+	const int gi = (int)blockIdx.x * 256 + li;   // the Gaussian (index into the caller's arrays)
+	const int gid = wg * 256 + li;               // its geometry row
+
+	// ---- part 2, visible Gaussians only
+	if (vis) {
+		rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)(rmin[1] + ty_off),
+		                        (unsigned short)rmax[0], (unsigned short)(rmax[1] + ty_off));
+		// kept for the backward, which only visits Gaussians with radius > 0 (the reference stores it for
+		// every Gaussian in front of the camera, rasterizer_impl.cu / forward.cu:208-214)
+#pragma unroll
+		for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)gid * 6 + k] = cov3D[k];
+		float rgb[3];
+		uint8_t clamp_bits = 0;
+		if (COLOR == 1) {
+			sh3_to_rgb_stream(p, a.cam_pos + 3 * view, a.shs + (size_t)gi * 48, rgb, clamp_bits);
+		} else if (COLOR == 0 && a.colors_precomp == nullptr) {
+			sh_to_rgb(a.D, a.M, p, a.cam_pos + 3 * view, a.shs + (size_t)gi * a.M * 3, rgb, clamp_bits);
+		} else {
+			rgb[0] = a.colors_precomp[3 * gi];
+			rgb[1] = a.colors_precomp[3 * gi + 1];
+			rgb[2] = a.colors_precomp[3 * gi + 2];
+		}
+		const float opacity = a.opacities[gi];
+		// alpha = min(0.99, o*exp(power)) < 1/255  <=>  power < -ln(255*o); keep a margin far
+		// above the rounding of logf/expf so the cut only skips pairs the exact test rejects.
+		const float power_cut = -logf(255.0f * opacity) - 1.0e-3f;
+		// The record carries the conic pre-scaled: (-a/2, -b, -c/2).  Scaling by a power of two commutes with
+		// every rounding, so the walks' power = (ha dx) dx + (hc dy) dy + (nb dx) dy is bit for bit the
+		// reference's -0.5f * (a dx dx + c dy dy) - b dx dy (forward.cu:419) with one multiply less per pair.
+		rq0 = make_float4(pix_x, pix_y, -0.5f * conic_a, -conic_b);
+		rq1 = make_float4(-0.5f * conic_c, power_cut, opacity, pvz);
+		a.geom.clamped[gid] = clamp_bits;
+		// Keep one instance per tile of the rect the splat can actually reach: the reference
+		// lists every tile of the bounding rect (rasterizer_impl.cu:88-108); tiles where
+		// alpha < 1/255 everywhere only ever `continue` in its render loops, so dropping them
+		// changes no pixel.  Rects of more than 64 tiles are kept whole (mask too short).
+		const uint32_t area = (uint32_t)(rmax[0] - rmin[0]) * (uint32_t)(rmax[1] - rmin[1]);
+		const bool pd = (conic_a > 0.0f) && (conic_c > 0.0f) && (conic_a * conic_c - conic_b * conic_b > 0.0f);
+		const float rb_c = -conic_b / conic_c, rb_a = -conic_b / conic_a;
+		if (area <= 64u) {
+			// Axis-aligned bounding box of the region {alpha >= 1/255} = {q(d) <= t}, t = -(cut - slack):
+			// |dx| <= sqrt(2 t c / det), |dy| <= sqrt(2 t a / det).  Tiles outside it are dropped
+			// without the edge test; NaN / non-PD conics fall back to the whole rect.
+			int x0 = rmin[0], x1 = rmax[0], y0 = rmin[1], y1 = rmax[1];
+			const float tq = -(power_cut - (1.0e-3f + 1.0e-4f * fabsf(power_cut)));
+			const float cdet = conic_a * conic_c - conic_b * conic_b;
+			if (pd) {
+				if (tq < 0.0f) {
+					x1 = x0;   // opacity below 1/255: nothing is ever blended
+				} else {
+					const float hx = sqrtf(2.0f * tq * conic_c / cdet) * 1.0001f + 0.01f;
+					const float hy = sqrtf(2.0f * tq * conic_a / cdet) * 1.0001f + 0.01f;
+					if (hx == hx && hy == hy) {
+						// tile x holds pixel centres [16x, 16x+15]
+						x0 = max(x0, (int)ceilf((pix_x - hx - 15.0f) * (1.0f / BSR_TILE)));
+						x1 = min(x1, (int)floorf((pix_x + hx) * (1.0f / BSR_TILE)) + 1);
+						y0 = max(y0, (int)ceilf((pix_y - hy - 15.0f) * (1.0f / BSR_TILE)));
+						y1 = min(y1, (int)floorf((pix_y + hy) * (1.0f / BSR_TILE)) + 1);
+					}
+				}
+			}
+			const int w = rmax[0] - rmin[0];
+			for (int y = y0; y < y1; y++)
+				for (int x = x0; x < x1; x++) {
+					if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
+					                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
+						kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
+						atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
+					}
+				}
+		} else {
+			for (int y = rmin[1]; y < rmax[1]; y++)
+				for (int x = rmin[0]; x < rmax[0]; x++)
+					atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
+		}
+		rq2 = make_float4(rgb[0], rgb[1], rgb[2], __uint_as_float((uint32_t)(kept_mask >> 32)));
+	}
+	{
 		// Gaussian-major instance blocks for the backward's gather: exclusive scan of the per-Gaussian
 		// tile counts inside the workgroup; the per-workgroup totals are prefix-summed by k_scans.  Blocks of
 		// different workgroups land in arbitrary order; inside a workgroup they ascend with the id.
@@ -277,20 +346,17 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			a.geom.wg_kept[wg] = w0 + w1 + w2 + w3;
 			a.geom.wg_area[wg] = s_area[0] + s_area[1] + s_area[2] + s_area[3];
 		}
-		if (!in_range && a.n_views > 1) a.geom.rect[id] = rect_out;   // padding rows between the views: empty rect
-		if (in_range) {
+		if (vis) {
 			const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u) + incl - n_inst;
-			a.geom.rect[id] = rect_out;
-			if (area_all != 0u) {   // readers look at the rect first: culled rows need nothing else (sparse views)
-				a.geom.depth[id] = rq1.w;
-				a.geom.inst_offset[id] = off;
-				a.geom.kept_mask[id] = kept_mask;
-			}
-			if (radius_out > 0) {
+			a.geom.rect[gid] = rect_out;
+			a.geom.depth[gid] = rq1.w;
+			a.geom.inst_offset[gid] = off;
+			a.geom.kept_mask[gid] = kept_mask;
+			{
 				// the whole 64-B splat record in four back-to-back stores: each cache line is written once,
 				// completely (written piecemeal across the kernel, partially filled lines were evicted and
 				// re-written: 181 MB of HBM writes for 113 MB of data at C3)
-				float4* rec = a.geom.rec + (size_t)id * BSR_REC;
+				float4* rec = a.geom.rec + (size_t)gid * BSR_REC;
 				rec[0] = rq0;
 				rec[1] = rq1;
 				rec[2] = rq2;
