@@ -4,8 +4,8 @@
 // cuda_rasterizer/rasterizer_impl.cu:198-339):
 //   k_preprocess (project, cull, SH, exact tile cull, Gaussian-major instance numbering)
 //   -> k_scans (workgroup bases, totals, pass-1 histogram rows) -> 16-byte D2H read (kept, num_rendered), overlapped with:
-//   binning alloc (sized from the previous call) -> k_emit_scatter (= first radix pass) -> remaining radix
-//   passes on the tile id -> k_tile_ranges
+//   binning alloc (sized from the previous call) -> k_emit_scatter (= first radix pass) -> k_tile_count ->
+//   k_tile_starts -> k_tile_scatter (tile ids of up to 16 bits; else the remaining radix passes -> k_tile_ranges)
 //   -> k_sort_tiles_* (per-tile LDS sort) -> k_render_fwd.  No float atomics anywhere.
 // Backward (rasterizer_impl.cu:403-504): k_render_bwd (per-instance partial sums to a Gaussian-major
 // slab, no atomics) -> k_preprocess_bwd (adds each Gaussian's adjacent rows, then the chain).

@@ -1,4 +1,4 @@
-// Per-tile binning and depth sort -- no global atomics anywhere.
+// Per-tile binning and depth sort -- no floating-point atomics, and the few integer ones never decide a result.
 //
 // The reference emits one 64-bit (tile | depth) key per (Gaussian, tile) instance in Gaussian order
 // and runs a global stable radix sort over all R instances on 32+bit key bits, six 8-bit passes at
@@ -14,7 +14,9 @@
 //      depth bits) straight to its position after the FIRST radix pass: digit base + the prefix of
 //      the earlier workgroups + an LDS counter.  The order inside one (workgroup, digit) group is
 //      whatever the LDS atomics give -- it does not matter, see 5,
-//   3. the remaining ceil(bits(T)/8) - 1 stable LSD radix passes on the TILE ID only (1080p: one
+//   3. tile ids of up to 16 bits (every single-view call up to 4096 x 4096): the tile-owned second pass further down
+//      (k_tile_count -> k_tile_starts -> k_tile_scatter), which also produces the tile ranges of 4.  Otherwise:
+//      the remaining ceil(bits(T)/8) - 1 stable LSD radix passes on the TILE ID only (1080p: one
 //      more pass; the reference does six over 45 key bits; elements move as single 12-byte
 //      loads/stores): per-workgroup digit histogram -> 256 parallel row scans -> stable scatter
 //      (wave ballots for the in-round rank, stamped per-wave counters across the 4 waves),
