@@ -57,6 +57,7 @@ SIGNATURES = {
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "bsr_transmittance_offset": (C.c_size_t, [C.c_void_p]),
     "bsr_profile_enable": (C.c_int, [C.c_int]),
+    "bsr_profile_only": (C.c_int, [C.c_char_p]),
     "bsr_profile_reset": (C.c_int, []),
     "bsr_profile_read": (C.c_int, [C.POINTER(StageProfile), C.c_int]),
     # include/bloomscene_anchors.h
@@ -105,6 +106,11 @@ def check(rc: int, what: str):
 def profile_enable(on):
     """False/0: off; True/1: bracket every stage with events; N > 1: only every Nth forward (+ its backward)."""
     lib().bsr_profile_enable(int(on))
+
+
+def profile_only(stage=None):
+    """Bracket only this stage ("render_bwd", ...); None: all stages again."""
+    lib().bsr_profile_only(stage.encode() if stage else None)
 
 
 def profile_reset():

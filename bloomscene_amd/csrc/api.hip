@@ -192,6 +192,7 @@ struct StageRec {
 };
 static bool g_prof_on = false;
 static int g_prof_every = 1;                      // sample every Nth forward call (and the backward that follows it)
+static char g_prof_only[32] = "";                 // non-empty: only this stage is bracketed (bsr_profile_only)
 static std::atomic<unsigned> g_prof_calls{0};     // forward calls since enable
 static std::atomic<bool> g_prof_this_call{true};  // whether the current forward/backward pair is sampled (process-wide:
                                                   // PyTorch runs the backward on an autograd worker thread)
@@ -247,6 +248,7 @@ struct StageTimer {
 		if (!g_prof_on) return;
 		if (!strcmp(name, "preprocess")) g_prof_this_call = (g_prof_calls.fetch_add(1) % (unsigned)g_prof_every) == 0;
 		if (!g_prof_this_call) return;
+		if (g_prof_only[0] && strcmp(g_prof_only, name)) return;
 		std::lock_guard<std::mutex> lk(g_prof_mu);
 		for (auto& r : g_stages)
 			if (r.name == name || !strcmp(r.name, name)) rec = &r;
@@ -453,6 +455,17 @@ int bsr_profile_enable(int on)
 {
 	g_prof_on = on != 0;
 	g_prof_every = on > 1 ? on : 1;
+	return 0;
+}
+
+int bsr_profile_only(const char* stage)
+{
+	std::lock_guard<std::mutex> lk(g_prof_mu);
+	g_prof_only[0] = 0;
+	if (stage) {
+		strncpy(g_prof_only, stage, sizeof(g_prof_only) - 1);
+		g_prof_only[sizeof(g_prof_only) - 1] = 0;
+	}
 	return 0;
 }
 

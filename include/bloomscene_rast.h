@@ -306,6 +306,10 @@ typedef struct bsr_stage_profile {
 	int launches;
 } bsr_stage_profile;
 int bsr_profile_enable(int on);
+/* Restrict the bracketing to ONE stage ("render_bwd", "render_fwd", "preprocess", ...; NULL or "" = all stages
+ * again): two events per sampled call instead of fourteen, for timing the dominant kernel inside a throughput
+ * measurement without taxing it (an event pair costs ~35 us of pipeline bubble on MI355X). */
+int bsr_profile_only(const char* stage);
 int bsr_profile_reset(void);
 int bsr_profile_read(bsr_stage_profile* out, int max_stages);
 
