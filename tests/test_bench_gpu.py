@@ -70,6 +70,10 @@ def test_bench_headline_line_has_the_contract_keys():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel"] == "render_bwd" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-4
+    # inside the timed region only the dominant stage carries events (every 4th of the 8 steps); the stage table is complete
+    assert rf["timed_region_events"]["stage"] == "render_bwd" and rf["launches_timed"] == 2
+    assert set(d["stage_ms"]) >= {"preprocess", "scan_wg", "binning", "sort_tiles", "render_fwd", "render_bwd",
+                                  "preprocess_bwd"}
     # the committed counter passes count only while they belong to the kernel sources being timed
     src = rf["traffic_source"]
     assert src is None or (rf["traffic"] is not None) == src["matches_timed_build"]
@@ -79,3 +83,32 @@ def test_bench_headline_line_has_the_contract_keys():
     assert sec["c3_dense_scales_x3"]["instances_per_gaussian"] > 10       # long tile lists
     assert sec["c3_camera_changes_every_step"]["value"] > 0 and sec["bloomscene_shape"]["value"] > 0
     assert d["host"]["device_allocs_in_timed_region"] == 0
+
+
+def test_profile_only_brackets_one_stage():
+    """bsr_profile_only(stage): the library records events for that stage alone (what bench.py relies on to time the
+    dominant kernel inside the timed region without taxing the step), and NULL restores all stages."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import helpers as Hh
+    from bloomscene_amd import _capi
+    c = Hh.make_case(P=20_000, W=256, H=192, deg=1, seed=5)
+    try:
+        _capi.profile_only("render_fwd")
+        _capi.profile_enable(1)
+        _capi.profile_reset()
+        Hh.run_hip(c)
+        Hh.run_hip(c)
+        torch.cuda.synchronize()
+        prof = {k: v for k, v in _capi.profile_read().items() if v[1] > 0}
+        assert set(prof) == {"render_fwd"} and prof["render_fwd"][1] == 2 and prof["render_fwd"][0] > 0
+        _capi.profile_only(None)
+        _capi.profile_reset()
+        Hh.run_hip(c)
+        torch.cuda.synchronize()
+        prof = {k: v for k, v in _capi.profile_read().items() if v[1] > 0}
+        assert {"preprocess", "scan_wg", "binning", "sort_tiles", "render_fwd"} <= set(prof)
+    finally:
+        _capi.profile_enable(False)
+        _capi.profile_only(None)
