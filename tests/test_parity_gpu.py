@@ -62,6 +62,9 @@ CASES = {
     "M16_D1": dict(P=2500, W=150, H=90, deg=1, seed=22, M_extra=12, scale_mul=3.0),
     "M16_D2": dict(P=2500, W=150, H=90, deg=2, seed=23, M_extra=7, scale_mul=3.0, free_camera=True),
     "M4_D0": dict(P=2500, W=150, H=90, deg=0, seed=24, M_extra=3, scale_mul=3.0),
+    # an 8K image: 129 600 tiles -> tile ids of 17 bits: the generic three-pass binning of a SINGLE view (the
+    # tile-owned second pass covers up to 16 bits), 33 M pixels, rects of hundreds of tiles
+    "image_8k_130k_tiles": dict(P=3000, W=7680, H=4320, deg=1, seed=21, scale_mul=6.0),
 }
 
 
@@ -182,7 +185,7 @@ def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD):
 BWD_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "extraM_scalemod_bg", "shell_view",
              "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "free_camera_sh3",
              "free_camera_precomp_cov", "huge_splats", "c2_100k_800x800", "c1_10k_256x256", "M16_D0", "M16_D1",
-             "M16_D2", "M4_D0"]
+             "M16_D2", "M4_D0", "image_8k_130k_tiles"]
 
 
 @pytest.mark.parametrize("name", BWD_CASES)
