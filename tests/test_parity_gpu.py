@@ -25,6 +25,8 @@ import ctypes as C
 import glob
 import os
 
+import copy
+
 import numpy as np
 import pytest
 import math
@@ -571,6 +573,46 @@ def test_full_size_c5_forward_and_gradients():
     Hh.assert_gradient_parity(c, st, g, out.grads, label="c5_5M_1920x1080_sh3")
     del st, g
     out2 = Hh.run_hip(c)
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        np.testing.assert_array_equal(getattr(out2.grads, k).view(np.uint32), getattr(out.grads, k).view(np.uint32), err_msg=k)
+
+
+def test_24M_gaussians_past_4GiB_arrays():
+    """Maximum sizes: 24 M Gaussians with SH 3 at 1920x1080 -- coefficient and gradient arrays of 4.6 GB each (byte
+    offsets past 2^32, element offsets past 2^30), ~100 M tile instances, ~13 000 per tile (every tile in the wide sort
+    classes), 24-bit Gaussian ids.  The oracle does not reach this size; checked instead: radii and num_rendered are
+    per-Gaussian quantities, so the whole call must reproduce six 4 M-Gaussian calls on the same camera exactly; image,
+    depth and every gradient must be finite, non-trivial (also in the rows past the 4-GiB mark) and bit-identical
+    between two runs of the whole step."""
+    dev = _dev()
+    P, CH = 24_000_000, 4_000_000
+    c = Hh.make_case(P=P, W=1920, H=1080, deg=3, seed=2)
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+    assert R > 90_000_000
+    radii_all = radii.cpu().numpy()
+    del color, depth, gb, bb, ib, t
+    torch.cuda.empty_cache()
+    R_sum = 0
+    for k in range(P // CH):
+        sl = slice(k * CH, (k + 1) * CH)
+        ck = copy.copy(c)   # same camera / settings, a slice of the Gaussians
+        ck.P = CH
+        for name in ("means3D", "opacities", "shs", "scales", "rotations"):
+            setattr(ck, name, getattr(c, name)[sl].contiguous())
+        _, _, Rk, _, _, radii_k, _, _, _ = _native_forward(ck)
+        np.testing.assert_array_equal(radii_k.cpu().numpy(), radii_all[sl], err_msg=f"chunk {k}")
+        R_sum += Rk
+        del radii_k
+        torch.cuda.empty_cache()
+    assert R_sum == R
+    out = Hh.run_hip(c)
+    assert np.isfinite(out.color).all() and np.isfinite(out.depth).all() and float(out.color.max()) > 0.1
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        gk = getattr(out.grads, k)
+        assert np.isfinite(gk).all() and float(np.abs(gk).max()) > 0, k
+        assert float(np.abs(gk[-1_000_000:]).max()) > 0, k          # the rows past the 4-GiB mark are written
+    out2 = Hh.run_hip(c)
+    np.testing.assert_array_equal(out2.color.view(np.uint32), out.color.view(np.uint32))
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         np.testing.assert_array_equal(getattr(out2.grads, k).view(np.uint32), getattr(out.grads, k).view(np.uint32), err_msg=k)
 
