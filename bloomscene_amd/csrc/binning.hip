@@ -27,6 +27,7 @@
 // The earlier version counted and appended instances with global integer atomics (~20 G/s when
 // lane-scattered on MI355X: 0.2 ms at C3, 1.4 ms at C5); this one is also fully deterministic.
 #include "common.h"
+#include <stdlib.h>
 
 namespace bsr {
 
@@ -890,9 +891,10 @@ __device__ __forceinline__ void merge_loaded_runs(uint64_t* keys, int n2, uint32
 // Wave-owned segment: load, pick the compare-exchange flavour, sort.  No workgroup barrier anywhere.
 template <int M>
 __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32_t start, int n, int lane,
-                                                  const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list)
+                                                  const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
+                                                  bool force_int)
 {
-	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems);
+	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems) && !force_int;
 	if (wave_ballot(!plain) == 0ull)
 		merge_loaded_runs<64, M, false, true>(keys, n2, start, n, lane, point_list);
 	else
@@ -902,9 +904,10 @@ __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32
 // Workgroup-owned segment (the wide classes): the same, with workgroup barriers and a workgroup vote.
 template <int NT, int M>
 __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint32_t start, int n, int tid,
-                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list)
+                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
+                                                   bool force_int)
 {
-	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems);
+	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems) && !force_int;
 	if (__syncthreads_and(plain))
 		merge_loaded_runs<NT, M, true, true>(keys, n2, start, n, tid, point_list);
 	else
@@ -916,7 +919,7 @@ __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint3
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const BinElem* __restrict__ elems,
-                                                          uint32_t* __restrict__ point_list)
+                                                          uint32_t* __restrict__ point_list, int force_int)
 {
 	__shared__ uint64_t s_keys[4][BSR_SORT_SMALL];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -927,7 +930,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	if (n > BSR_SORT_SMALL || n <= 0) return;   // on the big-tile list / empty
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
-	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list);   // (> 512 keys: two runs per lane)
+	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0);   // (> 512 keys: two runs per lane)
 }
 
 // Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
                                                         int capacity, const uint32_t* __restrict__ tile_start,
                                                         const uint32_t* __restrict__ big_tiles,
                                                         const int* __restrict__ flags, const BinElem* __restrict__ elems,
-                                                        uint32_t* __restrict__ point_list)
+                                                        uint32_t* __restrict__ point_list, int force_int)
 {
 	__shared__ uint64_t s_keys[CAP];
 	const int b = blockIdx.x;
@@ -947,7 +950,7 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
 	if (n <= min_n || n > CAP) return;   // another class (uniform over the workgroup)
 	int n2 = 1024;
 	while (n2 < n) n2 <<= 1;
-	sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list);
+	sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list, force_int != 0);
 }
 
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
@@ -961,7 +964,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
                                                                  const BinElem* __restrict__ elems, uint64_t* keys,
-                                                                 uint32_t* __restrict__ point_list)
+                                                                 uint32_t* __restrict__ point_list, int force_int)
 {
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
 	__shared__ uint64_t s_keys[CH];
@@ -974,7 +977,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 		const uint32_t start = tile_start[tile];
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= 4096 || n > CH) return;   // (uniform over the workgroup)
-		sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list);
+		sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list, force_int != 0);
 		return;
 	}
 	b -= g4;
@@ -1085,17 +1088,21 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
+	// test hook: BSR_SORT_FORCE_INT=1 sends every segment through the integer compare-exchange flavour, which real
+	// inputs reach only with NaN / non-positive depth bits (read once)
+	static const int force_int = [] { const char* v = getenv("BSR_SORT_FORCE_INT"); return v && v[0] == '1' ? 1 : 0; }();
+	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
+	                   force_int);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
 	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
 	const int g1 = min(T, n_bound / (BSR_SORT_SMALL + 1)), g4 = min(T, n_bound / 4097),
 	          g8 = min(T, n_bound / (BSR_SORT_CHUNK + 1));
 	if (g1 > 0)
 		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
-		                   tile_start, big_tiles, flags, elems, point_list);
+		                   tile_start, big_tiles, flags, elems, point_list, force_int);
 	if (g4 + g8 > 0)
 		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g4 + g8), dim3(BSR_SORT_NT), 0, s, T, g4, n_ptr, capacity, tile_start,
-		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list);
+		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int);
 }
 
 }  // namespace bsr
