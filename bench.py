@@ -385,6 +385,22 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     with torch.no_grad():
         res = views.render_view(cams[mine[0]], bufs, bg, deg)
         out["visible_first_view_rank0"] = int(res["visibility_filter"].sum().item())
+        # tile instances (the reference's num_rendered) of every view of this rank, for the algorithmic byte count
+        from bloomscene_amd.rasterizer import _rasterize_gaussians_native
+        e = torch.Tensor([])
+        R_mine = 0
+        for i in mine:
+            st = views.make_settings(cams[i], bg, deg)
+            R_mine += _rasterize_gaussians_native(st.bg, bufs["means3D"], e, bufs["opacities"], bufs["scales"],
+                                                  bufs["rotations"], 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
+                                                  st.tanfovy, H, W, bufs["shs"], deg, st.campos, False, False)[0]
+    R_all = sum(D.gather_ints(R_mine))
+    # SURVEY.md §8(d), forward only: (187 + 12 M) P + 48 R + 24 N per view.  The formula charges every view with all
+    # P Gaussians' inputs, as the reference's preprocess reads them; on this sweep ~95 % of them are culled after their
+    # 12-byte position, so the fraction says how fast the sweep is, not how busy the HBM was.
+    alg_bytes = n_views * ((187 + 12 * M) * P + 24 * W * H) + 48 * R_all
+    out["num_rendered_all_views"] = int(R_all)
+    out["algorithmic_bytes_all_views"] = int(alg_bytes)
     for batch in (1, 16):
         def sweep():
             return views.render_views_sharded(cams, bufs, bg, deg, rank=D.rank, world=D.world, batch=batch)
@@ -400,7 +416,8 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
         out[f"views_per_call_{batch}"] = {
             "sweep_ms": round(t * 1e3, 3), "ms_per_view_per_rank": round(t / max(len(mine), 1) * 1e3, 4),
             "value": round(n_views * P / t / 1e6, 1),
-            "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1)}
+            "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1),
+            "roofline_frac_algorithmic": round(alg_bytes / t / 1e9 / (HBM_PEAK_GBS * D.world), 5)}
     del bufs
     torch.cuda.empty_cache()
     return out
