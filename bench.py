@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the rasterizer hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or plain -- the parent
+                                                            then starts the N ranks itself as child processes)
 
 Headline metric (BASELINE.json): Msplats/s forward+backward @ 1 M Gaussians, 1920x1080, SH degree 3
 (config C3, synthetic scene A of SURVEY.md §8d), colour + depth targets with upstream gradients.
@@ -99,6 +100,21 @@ def measured_traffic(config, stage):
         return None, None, None
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes under
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and leave with their exit code.  Nothing in this
+    parent has touched the GPU (importing torch does not), and it never execs: rank 0 of the children prints the
+    JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+
+
 class Dist:
     """RANK / WORLD_SIZE plumbing; BSR_BENCH_FORCE_DIST=1 takes the N > 1 code path (RCCL init, broadcast, barrier,
     all-reduce) with one rank."""
@@ -108,8 +124,6 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != gpus:
-            if self.world == 1 and gpus > 1:
-                raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
             raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback in bloomscene_amd)")
@@ -160,7 +174,7 @@ class Dist:
             dist.destroy_process_group()
 
 
-def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None):
+def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewarm_ms=0.0):
     """The contract's timing: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
     ranks.  Also one torch event per step (on the launch stream) for the median step time.  -> dict.
 
@@ -169,6 +183,22 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None):
     step made the sampled steps 0.26 ms (20 %) longer -- 5 % off the very throughput being measured.  The stage table
     comes from a short untimed pass after the timed region, every stage of every step bracketed."""
     from bloomscene_amd import _capi
+    prewarm_steps = 0
+    if prewarm_ms > 0:
+        # clock ramp: the same number of untimed steps on every rank (a step may hold a collective), sized from four
+        # timed ones to fill prewarm_ms
+        t_pre = time.perf_counter()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        est_ms = max((time.perf_counter() - t_pre) * 1e3 / 4, 1e-3)
+        n_more = int(D.max_over_ranks(min(math.ceil(prewarm_ms / est_ms), 2000)))
+        for i in range(n_more):
+            step()
+            if i % 8 == 7:
+                torch.cuda.synchronize()   # bound the queue: the loop is paced by the GPU, not by enqueue speed
+        torch.cuda.synchronize()
+        prewarm_steps = 4 + n_more
     for _ in range(warmup):
         step()
     D.fence()
@@ -211,7 +241,7 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None):
         if dominant in prof_timed:
             prof[dominant] = prof_timed[dominant]   # the dominant stage: as measured inside the timed region
     return {"seconds": D.max_over_ranks(dt), "median_ms": per_step[len(per_step) // 2], "prof": prof,
-            "device_allocs": int(device_allocs), "max_host_ms": max(host_step_ms),
+            "device_allocs": int(device_allocs), "max_host_ms": max(host_step_ms), "prewarm_steps": prewarm_steps,
             "timed_region_events": {"stage": dominant, "every_nth_step": sample_every,
                                     "launches": prof_timed.get(dominant, (0.0, 0))[1] if dominant else None}}
 
@@ -274,7 +304,8 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
 
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
-    tm = timed_steps(D, step, steps, warmup, dominant="render_bwd" if do_bwd else "render_fwd")
+    tm = timed_steps(D, step, steps, warmup, dominant="render_bwd" if do_bwd else "render_fwd",
+                     prewarm_ms=args.prewarm_ms if label == args.config else 0.0)
     # instances of this rank's first view, for the algorithmic byte count
     from bloomscene_amd.rasterizer import _rasterize_gaussians_native
     e = torch.Tensor([])
@@ -296,7 +327,7 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
            "ms_per_step_median": tm["median_ms"], "steps": steps, "warmup": warmup, "stages": stages, "alg": alg,
            "prof": tm["prof"], "R": R, "visible": visible, "step_bytes": sb, "bcast_ms": bcast_ms, "M": M, "deg": deg,
            "device_allocs": tm["device_allocs"], "max_host_ms": tm["max_host_ms"],
-           "timed_region_events": tm["timed_region_events"],
+           "timed_region_events": tm["timed_region_events"], "prewarm_steps": tm["prewarm_steps"],
            "allreduce_ms_per_step": state.get("allreduce_ms", 0.0) / max(steps + warmup, 1),
            "workload": f"{label}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
                        f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
@@ -442,12 +473,27 @@ def main():
     ap.add_argument("--depth-gradient", action="store_true",
                     help="opt-in extension: also backpropagate the depth target (bsr_backward_depth); the metric "
                          "is quoted without it (the reference ignores grad_depth)")
+    ap.add_argument("--lib", default="", help="measurement only: time another build of the same C ABI (A/B runs, the "
+                                                "diagnostic builds of csrc/Makefile) instead of the in-tree product library")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 rotate360 sweep leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (N = 1) workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--exact-exp", action="store_true",
+                    help="bsr_set_option('exact_exp', 1): the pinned exp on every evaluation of the forward blend (bit-equal "
+                         "to the CPU oracle); the metric is quoted on the library's default")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps run for this long BEFORE the W warm-up steps of the headline workload, so that the "
+                         "GPU clocks have ramped when the K timed steps start (reported as prewarm_steps)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)   # does not return
 
+    from bloomscene_amd import _capi
+    if args.lib:
+        _capi.use_library(args.lib)
+    if args.exact_exp:
+        _capi.set_option("exact_exp", 1)
     D = Dist(args.gpus)
     P, W, H, deg, do_bwd = CONFIGS[args.config]
     if args.gaussians:
@@ -491,13 +537,15 @@ def main():
             "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if headline
             else f"Msplats/s ({args.config})",
             "value": round(r["value"], 3), "unit": "Msplats/s", "n_gpus": D.world, "steps": r["steps"],
-            "warmup": r["warmup"], "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True,
+            "warmup": r["warmup"], "prewarm_steps": r["prewarm_steps"], "ms_per_step": round(r["ms_per_step"], 4),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["workload"], "gaussians": P, "width": W, "height": H, "sh_degree": r["deg"],
                        "num_rendered": r["R"], "visible": r["visible"],
                        "parallelism": f"view-parallel x{D.world}" + (" + gradient all-reduce" if args.allreduce_grads
                                                                       and D.multi and do_bwd else ""),
-                       "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256()},
+                       "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256(),
+                       "exact_exp": int(_capi.get_option("exact_exp"))},
             "ms_per_step_median": round(r["ms_per_step_median"], 4),
             "roofline": roofline,
             "roofline_step": {"algorithmic_bytes": r["step_bytes"], "achieved": round(whole, 2),

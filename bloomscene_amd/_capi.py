@@ -12,8 +12,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BSR_LIB_PATH: development only (A/B runs of two builds on one GPU box, tools/walk_stats.py's diagnostic build)
-LIB_PATH = os.environ.get("BSR_LIB_PATH") or os.path.join(_HERE, "libbloomscene_rast.so")
+LIB_PATH = os.path.join(_HERE, "libbloomscene_rast.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
@@ -56,6 +55,8 @@ SIGNATURES = {
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "bsr_transmittance_offset": (C.c_size_t, [C.c_void_p]),
+    "bsr_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "bsr_get_option": (C.c_int, [C.c_char_p]),
     "bsr_profile_enable": (C.c_int, [C.c_int]),
     "bsr_profile_only": (C.c_int, [C.c_char_p]),
     "bsr_profile_reset": (C.c_int, []),
@@ -92,6 +93,25 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def use_library(path: str):
+    """Measurement tools only (A/B runs of two builds on one GPU box, the diagnostic builds of csrc/Makefile): load
+    another build of the SAME C ABI instead of the in-tree product library.  Must precede the first native call of
+    the process; the product never calls this and reads no environment variable to find its library."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is first used")
+    LIB_PATH = os.path.abspath(path)
+
+
+def set_option(name: str, value) -> None:
+    """bsr_set_option (include/bloomscene_rast.h): "exact_exp", "sort_force_int"."""
+    check(lib().bsr_set_option(name.encode(), int(bool(value))), "bsr_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(lib().bsr_get_option(name.encode()))
 
 
 def last_error() -> str:

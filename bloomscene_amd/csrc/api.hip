@@ -155,6 +155,19 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
                        float4* slab, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- options (bsr_set_option)
+static std::atomic<int> g_opt_exact_exp{0};
+static std::atomic<int> g_opt_sort_force_int{0};
+int opt_exact_exp() { return g_opt_exact_exp.load(std::memory_order_relaxed); }
+int opt_sort_force_int() { return g_opt_sort_force_int.load(std::memory_order_relaxed); }
+static std::atomic<int>* find_option(const char* name)
+{
+	if (!name) return nullptr;
+	if (!strcmp(name, "exact_exp")) return &g_opt_exact_exp;
+	if (!strcmp(name, "sort_force_int")) return &g_opt_sort_force_int;
+	return nullptr;
+}
+
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
 
@@ -424,9 +437,15 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		sc->last_P = P; sc->last_W = width; sc->last_H = height; sc->last_V = V;
 		sc->last_R = h_R > decayed ? h_R : decayed;
 	}
-	if (!guess || (size_t)h_kept > cap) {
-		// first call of this shape, or more kept instances than the guessed scratch holds (the kernels of the
-		// first attempt then returned without touching anything)
+	// The backward is handed R, not the capacity this call carved with: it finds point_list at the buffer's start and
+	// puts its slab (48 B per KEPT instance) right behind point_list[R].  A guessed buffer serves it only if that
+	// R-based carve ends inside it -- with kept <= cap < R the slab could otherwise run past the end (cap + 512 Ki < R
+	// is enough to get past the 2 MB of histogram space behind the work section).
+	const bool backward_fits = V != 1 || align_up((size_t)R * sizeof(uint32_t), 256) + align_up((size_t)h_kept * 48, 256) <=
+	                                         BinState::bytes(cap, true) - 256;
+	if (!guess || (size_t)h_kept > cap || !backward_fits) {
+		// first call of this shape, more kept instances than the guessed scratch holds (the kernels of the first
+		// attempt then returned without touching anything), or a buffer the backward's carve would overrun
 		if (run_tail((size_t)R)) return 1;
 	}
 	STAGE_CHECK("render_fwd", debug, s);
@@ -449,6 +468,22 @@ size_t bsr_image_bytes(int W, int H)
 {
 	const size_t gx = (W + BSR_TILE - 1) / BSR_TILE, gy = (H + BSR_TILE - 1) / BSR_TILE;
 	return ImgState::bytes((size_t)W * H, gx * gy);
+}
+
+int bsr_set_option(const char* name, int value)
+{
+	std::atomic<int>* o = find_option(name);
+	if (!o) {
+		g_err[0] = 0;
+		return fail("bsr_set_option: unknown option '%s'", name ? name : "(null)");
+	}
+	o->store(value != 0, std::memory_order_relaxed);
+	return 0;
+}
+int bsr_get_option(const char* name)
+{
+	std::atomic<int>* o = find_option(name);
+	return o ? o->load(std::memory_order_relaxed) : -1;
 }
 
 int bsr_profile_enable(int on)
@@ -656,8 +691,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0), true);
 
 	// slab[R][12] f32: per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows), in the
-	// caller's binning buffer over the forward's dead radix ping-pong buffers.  The buffer was sized by the forward for
-	// a capacity >= R, and the section starts right behind point_list[R], so the R-based carve stays inside it.
+	// caller's binning buffer over the forward's dead radix ping-pong buffers.  The forward sized the buffer for R or for
+	// a guessed capacity it checked against this very carve (forward_impl: backward_fits): point_list[R], then the rows
+	// of the kept instances, end inside it.
 	float4* slab = bin.slab;
 
 	if (R > 0) {

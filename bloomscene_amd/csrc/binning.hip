@@ -1088,9 +1088,9 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s)
 {
-	// test hook: BSR_SORT_FORCE_INT=1 sends every segment through the integer compare-exchange flavour, which real
-	// inputs reach only with NaN / non-positive depth bits (read once)
-	static const int force_int = [] { const char* v = getenv("BSR_SORT_FORCE_INT"); return v && v[0] == '1' ? 1 : 0; }();
+	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
+	// which real inputs reach only with NaN / non-positive depth bits
+	const int force_int = opt_sort_force_int();
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
 	                   force_int);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the

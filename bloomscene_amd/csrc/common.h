@@ -135,6 +135,10 @@ struct BwdArgs {
 // Records the calling thread's error message (read back by bsr_last_error) and returns 1.  api.hip
 int fail(const char* fmt, ...);
 
+// Process-wide options of bsr_set_option (include/bloomscene_rast.h), read by the launchers.  api.hip
+int opt_exact_exp();
+int opt_sort_force_int();
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
 
 // ---- pinned exp: identical algorithm to bsro_expf in oracle/bsr_oracle.c (<= 1 ulp) ----

@@ -215,6 +215,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	float T = T_final;
 	const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
 	float Srec = 0.f;   // sum_ch accum_rec[ch] * dL_dpixel[ch] (+ the depth channel in the extension)
+#ifdef BSR_BWD_CHANNEL_ACCUM
+	float acc_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f}, last_alpha = 0.f;
+	(void)Srec;
+#endif
 	float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
 	if (inside) {
 		dpx0 = dL_dpixels[pix_id];
@@ -333,7 +337,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// "inside the band" is voted on |power - centre| < 1.1e-3 (centre = cut + 1e-3, staged in q2.w) over ALL lanes (a vote on an AND with `cand`
 			// makes hipcc materialise the mask in a VGPR): a lane that is not a candidate can only add a harmless
 			// trip through the pinned exp.
-			const bool in_band = wave_ballot(fabsf(power - q2.w) < 1.1e-3f) != 0ull;   // rare: ~1 % of the visits
+			// The vote is `!(|power - centre| >= 1.1e-3)`: a NaN centre (opacity <= 0 or NaN, whose power_cut is NaN and
+			// lets every lane through `cand`) or a NaN power counts as inside the band, so those pairs get the alpha <
+			// 1/255 test below, which skipped them in the forward (alpha < 0) -- the fast path would blend them.
+#ifdef BSR_BWD_EXACT_EXP
+			const bool in_band = true;   // attribution build: the pinned exp on every visit
+#else
+			const bool in_band = wave_ballot(!(fabsf(power - q2.w) >= 1.1e-3f)) != 0ull;   // rare: ~1 % of the visits
+#endif
 			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
 			if (in_band) Gx = bsr_expf_walk(power);
 			// Lanes that must not blend carry G = 0, hence alpha = 0: every recurrence below then leaves their state
@@ -361,23 +372,51 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
 				// unordered), so this block may fuse multiply-adds and use a refined reciprocal
 				// instead of the reference's two IEEE divisions (:521,:557).
+				// Attribution builds (make attrib, tools/attribute_gradient_error.py) switch the shortcuts off one by one:
+				// BSR_BWD_NO_CONTRACT, BSR_BWD_IEEE_DIV, BSR_BWD_PAIR_PRODUCTS, BSR_BWD_CHANNEL_ACCUM (+ BSR_BWD_EXACT_EXP above).
+#ifndef BSR_BWD_NO_CONTRACT
 #pragma clang fp contract(fast)
+#endif
 				const float om = 1.f - alpha;
+#ifdef BSR_BWD_IEEE_DIV
+				const float inv = 1.0f / om;
+				T = T / om;                                     // reference :521
+#else
 				const float inv = __builtin_amdgcn_rcpf(om);   // 1 ulp
 				// T/(1-alpha): quotient estimate + one residual correction (the residual T - om * qT is exact in the
 				// fma, so the 1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare
 				// cases: the T chain (hundreds of steps in dense tiles) does not drift.
 				const float qT = T * inv;
 				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);   // (plain T * inv: -2 % time, +20 % elements off by > 1e-4)
+#endif
 				// The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it
 				// only through sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so
 				// the projection Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence
 				// Srec' = alpha * u + (1 - alpha) * Srec with u = sum_ch c[ch] * dL_dpixel[ch]: one scalar
 				// instead of three channels (the depth extension adds its term d_i to u).
+#ifdef BSR_BWD_CHANNEL_ACCUM
+				// reference :527-536 channel by channel (attribution build; the depth extension is not carried here):
+				// accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, then (c - accum_rec) * dL_dpixel.
+				// A pair the reference skips must leave (accum_rec, last_color, last_alpha) standing.
+				float S = 0.f;
+				{
+					const bool live = G != 0.f;
+					const float c3[3] = {q2.x, q2.y, q2.z}, dp[3] = {dpx0, dpx1, dpx2};
+#pragma unroll
+					for (int ch = 0; ch < 3; ch++) {
+						const float ar = last_alpha * last_color[ch] + (1.f - last_alpha) * acc_rec[ch];
+						acc_rec[ch] = live ? ar : acc_rec[ch];
+						last_color[ch] = live ? c3[ch] : last_color[ch];
+						S += (c3[ch] - acc_rec[ch]) * dp[ch];
+					}
+					last_alpha = live ? alpha : last_alpha;
+				}
+#else
 				float u = q2.x * dpx0 + q2.y * dpx1 + q2.z * dpx2;
 				if (DEPTH) u += __builtin_fmaf(gz, q1.w, g1);
 				const float S = u - Srec;
 				Srec = Srec + alpha * S;
+#endif
 				const float dL_dalpha = T * S + neg_Tfinal_bg * inv;
 				// Per pair the reference adds (:574-583), with gd = G * dL_dalpha and w = o * gd:
 				//   dL_dmean2D.x += -w * ddelx_dx * (a dx + b dy)      dL_dconic.x += -0.5 w dx dx
@@ -387,12 +426,28 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				// moments of gd over its pixels (1, dx, dy, dx dx, dx dy, dy dy); the entry's row is assembled from
 				// the four quadrants' moments once, when it is written (5 multiplies per pair instead of 13).
 				const float gd = G * dL_dalpha;
+#ifdef BSR_BWD_PAIR_PRODUCTS
+				{
+					// the reference's per-pair terms (:561-580), summed as they are; the epilogue passes them through
+					const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x;
+					const float dL_dG = q1.z * dL_dalpha;
+					const float gdx = G * dx, gdy = G * dy;
+					const float dG_ddelx = -gdx * ca - gdy * cb;
+					const float dG_ddely = -gdy * cc - gdx * cb;
+					v0 = dL_dG * dG_ddelx * ddelx_dx;
+					v1 = dL_dG * dG_ddely * ddely_dy;
+					v2 = -0.5f * gdx * dx * dL_dG;
+					v3 = -0.5f * gdx * dy * dL_dG;
+					v4 = -0.5f * gdy * dy * dL_dG;
+				}
+#else
 				const float gx = gd * dx, gy = gd * dy;
 				v0 = gx;
 				v1 = gy;
 				v2 = gx * dx;
 				v3 = gx * dy;
 				v4 = gy * dy;
+#endif
 				v5 = gd;
 				const float aT = alpha * T;
 				v6 = aT * dpx0;
@@ -429,9 +484,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float no = -e1.z;
 			const float h = 0.5f * no;
 			float4* row = slab + (size_t)my_row * 3;
+#ifdef BSR_BWD_PAIR_PRODUCTS
+			(void)ca; (void)cb; (void)cc; (void)h;
+			row[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
+			row[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+#else
 			row[0] = make_float4(no * ddelx_dx * (ca * a9[0] + cb * a9[1]), no * ddely_dy * (cc * a9[1] + cb * a9[0]),
 			                     h * a9[2], h * a9[3]);
 			row[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
+#endif
 			row[2] = make_float4(a9[8], a9[9], 0.f, 0.f);
 		}
 		__syncthreads();

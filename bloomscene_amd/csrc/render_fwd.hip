@@ -3,7 +3,10 @@
 // Semantics: reference renderCUDA, cuda_rasterizer/forward.cu:341-471 (under
 // /root/reference/submodules/depth-diff-gaussian-rasterization).  Per pixel the arithmetic and
 // every decision (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4, depth normalisation) are
-// evaluated in the reference's order, so results match the CPU oracle bit for bit.
+// evaluated in the reference's order.  EXACT = true (bsr_set_option("exact_exp", 1)): exp(power) is the pinned
+// bsr_expf on every evaluation and the results match the CPU oracle bit for bit.  EXACT = false (the default):
+// the VALUE of exp(power) comes from v_exp_f32 (1 ulp, 2 issue slots instead of 13) and only a wave with a pixel
+// inside the decision band around the alpha >= 1/255 cut evaluates the pinned exp -- see the visit below.
 //
 // MI355X mapping: one tile = one 256-thread workgroup = 4 wave64; each wave owns an 8x8 pixel
 // quadrant.  List entries are staged 256 at a time: each thread gathers one 48-byte splat record
@@ -32,7 +35,7 @@ __device__ unsigned long long g_fwd_times[4 * 70000];
 
 // View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
 // row tyv belongs to view tyv / gy; pixel coordinates, image outputs and the per-pixel state are per view.
-template <int NS, int FB>
+template <int NS, int FB, bool EXACT>
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
+			r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
 		}
 		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 		FSTAT_ADD(6, 1);      // batches (per wave)
@@ -120,14 +124,35 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				if (wave_ballot(cand) == 0ull) return;
 				FSTAT_ADD(1, 1);   // ... with a candidate lane
 				const float2 od = srec_q1hi<FB>(rec);    // opacity, depth
-				const float4 q2 = srec_q2<FB>(rec);
+				const float4 q2 = srec_q2<FB>(rec);      // r, g, b, centre of the decision band
 				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
 				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
 				//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
 				//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
 				// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
-				const float alpha_raw = fminf(0.99f, od.x * bsr_expf_walk(power));   // all lanes: no exec games
-				const bool c2 = cand && !(alpha_raw < 1.0f / 255.0f) && !done;
+				float alpha_raw;
+				bool c2;
+				if (EXACT) {
+					alpha_raw = fminf(0.99f, od.x * bsr_expf_walk(power));   // all lanes: no exec games
+					c2 = cand && !(alpha_raw < 1.0f / 255.0f) && !done;
+				} else {
+					// `alpha >= 1/255` is decided on alpha = min(0.99, o E(power)) with the pinned exp E.  A candidate has
+					// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
+					// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
+					// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
+					// Only a wave with a lane inside that 2.1e-3 wide band (centre staged in q2.w) needs E to decide, and it
+					// then uses E for all its lanes; every other visit takes the VALUE from v_exp_f32.  The vote is
+					// `!(|power - centre| >= 1.1e-3)` so that a NaN (centre: opacity <= 0 or NaN; power: NaN conic) counts
+					// as inside -- those lanes get the exact path's arithmetic, e.g. alpha < 0 is skipped as in the reference.
+					// The backward takes the same decision the same way (render_bwd.hip).
+					const bool in_band = wave_ballot(!(fabsf(power - q2.w) >= 1.1e-3f)) != 0ull;   // rare: ~1 % of the visits
+					float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
+					if (in_band) Gx = bsr_expf_walk(power);
+					alpha_raw = fminf(0.99f, od.x * Gx);
+					c2 = cand && !done;
+					if (in_band) c2 = c2 && !(alpha_raw < 1.0f / 255.0f);
+					FSTAT_ADD(2, in_band ? 1 : 0);   // ... decided by the pinned exp
+				}
 				const float a_eff = c2 ? alpha_raw : 0.0f;
 				const float test_T = T * (1 - a_eff);
 				const bool stop = test_T < 0.0001f;
@@ -205,12 +230,16 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	// (a dozen entries per tile, most tiles empty) their 8 box tests per entry and the padding are pure overhead.
 	// Both instantiations produce identical bits.
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD");
-	if ((long long)capacity >= 48ll * n_tiles)
-		hipLaunchKernelGGL((k_render_fwd<2, BSR_BLOCK>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, n_ptr,
-		                   capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
-	else
-		hipLaunchKernelGGL((k_render_fwd<1, BSR_BLOCK>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, n_ptr,
-		                   capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth);
+	const bool split = (long long)capacity >= 48ll * n_tiles;
+	const bool exact = opt_exact_exp() != 0;
+#define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
+	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_BLOCK, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
+	                   n_ptr, capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth)
+	if (split && exact) BSR_LAUNCH_FWD(2, true);
+	else if (split) BSR_LAUNCH_FWD(2, false);
+	else if (exact) BSR_LAUNCH_FWD(1, true);
+	else BSR_LAUNCH_FWD(1, false);
+#undef BSR_LAUNCH_FWD
 }
 
 }  // namespace bsr

@@ -8,12 +8,17 @@ namespace bsr {
 
 // Measurement hook of the occupancy sweep (BASELINE config C5: "LDS-tile occupancy + rocprof HBM-GB/s sweep",
 // tools/sweep_occupancy.sh): extra dynamic LDS bytes per workgroup of a tile renderer, unused by the kernel, which
-// only lowers the number of workgroups a CU can hold.  Read once from the environment; 0 (unset) in normal use.
+// only lowers the number of workgroups a CU can hold.  Compiled in only by the sweep build (make sweep ->
+// libbsr_rast_sweep.so, -DBSR_OCCUPANCY_SWEEP); the product library reads no environment variable on its launch paths.
+#ifdef BSR_OCCUPANCY_SWEEP
 static inline unsigned occupancy_sweep_lds_pad(const char* env_name)
 {
 	const char* v = getenv(env_name);
 	return v ? (unsigned)strtoul(v, nullptr, 10) : 0u;
 }
+#else
+static inline constexpr unsigned occupancy_sweep_lds_pad(const char*) { return 0u; }
+#endif
 
 // Can the splat reach alpha >= 1/255 at ANY point of an axis-aligned box of pixel centres
 // [bx, bx+EXT] x [by, by+EXT]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with

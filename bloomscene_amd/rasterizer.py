@@ -10,7 +10,6 @@ There is no CPU path here: tensors must live on the GPU and the HIP library must
 from __future__ import annotations
 
 import ctypes as C
-import threading
 from typing import NamedTuple
 
 import torch
@@ -308,19 +307,17 @@ def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_m
 
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, depth_gradient=False):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, depth_gradient)
-
-
-_tls = threading.local()   # .last_final_T: final_T view of this thread's most recent forward call (return_alpha)
+                        raster_settings, depth_gradient=False, return_final_T=False):
+    out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                    cov3Ds_precomp, raster_settings, depth_gradient, return_final_T)
+    return out if return_final_T else out[:3]
 
 
 class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, depth_gradient=False):
+                raster_settings, depth_gradient=False, return_final_T=False):
         # same argument order as the reference hands to its C++ lib (PYW:60-80)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -342,18 +339,23 @@ class _RasterizeGaussians(torch.autograd.Function):
             num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
                 _rasterize_gaussians_native(*args)
 
-        # accumulated opacity of the call (extension): a view of final_T inside the image buffer, where the library
-        # says it is; nothing is computed unless GaussianRasterizer.forward(return_alpha=True) asks for it
-        n_pix = raster_settings.image_height * raster_settings.image_width
-        if imgBuffer.numel() >= 4 * n_pix:
-            off = int(_capi.lib().bsr_transmittance_offset(imgBuffer.data_ptr()))
-            _tls.last_final_T = imgBuffer[off:off + 4 * n_pix].view(torch.float32).view(
-                1, raster_settings.image_height, raster_settings.image_width)
-        else:   # P == 0: nothing was rendered
-            _tls.last_final_T = None
+        # accumulated opacity of the call (extension, GaussianRasterizer.forward(return_alpha=True)): final_T lives in the
+        # image buffer, where the library says it is; the view is handed out as a fourth, non-differentiable output
+        if return_final_T:
+            n_pix = raster_settings.image_height * raster_settings.image_width
+            if imgBuffer.numel() >= 4 * n_pix:
+                off = int(_capi.lib().bsr_transmittance_offset(imgBuffer.data_ptr()))
+                final_T = imgBuffer[off:off + 4 * n_pix].view(torch.float32).view(
+                    1, raster_settings.image_height, raster_settings.image_width)
+            else:   # P == 0: nothing was rendered, nothing absorbed
+                final_T = torch.ones((1, raster_settings.image_height, raster_settings.image_width),
+                                     dtype=torch.float32, device=color.device)
         # radii is an index output, and unused outputs need no zero gradients: without these two lines autograd
         # fills an int32 [P] zero tensor for grad_radii on every backward (the reference pays that fill, PYW:101)
-        ctx.mark_non_differentiable(radii)
+        if return_final_T:
+            ctx.mark_non_differentiable(radii, final_T)
+        else:
+            ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
@@ -362,10 +364,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                               binningBuffer, imgBuffer)
         if ctx.depth_gradient:
             ctx.out_depth = depth.detach().clone()   # the extension differentiates through this image
-        return color, radii, depth
+        return color, radii, depth, (final_T if return_final_T else None)
 
     @staticmethod
-    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, _grad_final_T=None):
         num_rendered = ctx.num_rendered
         raster_settings = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
@@ -410,6 +412,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _fit(grad_scales, scales),
             _fit(grad_rotations, rotations),
             _fit(grad_cov3Ds_precomp, cov3Ds_precomp),
+            None,
             None,
             None,
         )
@@ -461,11 +464,10 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
         if not return_alpha:
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, raster_settings, self.depth_gradient)
-        color, radii, depth = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
-                                                  rotations, cov3D_precomp, raster_settings, self.depth_gradient)
-        final_T = getattr(_tls, "last_final_T", None)
-        alpha = torch.zeros_like(depth) if final_T is None else (1.0 - final_T)
-        return color, radii, depth, alpha.detach()
+        color, radii, depth, final_T = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
+                                                           rotations, cov3D_precomp, raster_settings,
+                                                           self.depth_gradient, return_final_T=True)
+        return color, radii, depth, (1.0 - final_T).detach()
 
     def visible_filter_indices(self, means3D, scales=None, rotations=None, cov3D_precomp=None):
         """EXTENSION: ``visible_filter`` that also returns the ascending indices of the visible points,

@@ -294,6 +294,23 @@ size_t bsr_image_bytes(int width, int height);
  * used by the host's opt-in return_alpha extension. */
 size_t bsr_transmittance_offset(const void* image_buffer);
 
+/* ---- process-wide options (no reference counterpart) ------------------------------------
+ * bsr_set_option(name, value) -> 0, or 1 for an unknown name; bsr_get_option(name) -> value, or -1.
+ *   "exact_exp"       0 (default): the forward blend takes exp(power) from the hardware's v_exp_f32 (1 ulp) wherever
+ *                     only its VALUE is needed, and from the library's pinned, correctly-ordered exp (the one the CPU
+ *                     oracle restates) wherever the `alpha >= 1/255` decision of forward.cu:423-428 could depend on
+ *                     the last bit (a wave with a pixel within 1e-3 of the cut in the exponent): every such decision,
+ *                     radii, num_rendered and the per-tile lists are identical to the exact mode; colour / depth /
+ *                     final_T move by a few ulp (<= 1e-6 relative, the reference's own CUDA expf is a 2-ulp function),
+ *                     and the `T (1 - alpha) < 1e-4` stop of :433-437 sees a T that differs by those ulps.
+ *                     1: the pinned exp on every evaluation -- the forward then matches the CPU oracle bit for bit
+ *                     (what the parity tests switch on to prove every other operation of the forward exact).
+ *   "sort_force_int"  test hook, default 0: 1 sends every per-tile sort through the integer compare-exchange flavour
+ *                     that real inputs reach only with NaN / non-positive depth bits.
+ * Options are read at every launch (atomics); calls already enqueued keep the value they were launched with. */
+int bsr_set_option(const char* name, int value);
+int bsr_get_option(const char* name);
+
 /* ---- measurement hooks (no reference counterpart; used by bench.py only) ------------------
  * bsr_profile_enable(1) makes every kernel stage of subsequent calls be bracketed by hipEvents
  * on the call's stream (bsr_profile_enable(N), N > 1: only of every Nth forward call and

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -77,8 +78,14 @@ static bool write_from_device(FILE* f, const T* d, size_t n)
 
 int main(int argc, char** argv)
 {
-	if (argc != 3) {
-		fprintf(stderr, "usage: %s inputs.bin outputs.bin\n", argv[0]);
+	if (argc != 3 && argc != 4) {
+		fprintf(stderr, "usage: %s inputs.bin outputs.bin [exact]\n", argv[0]);
+		return 2;
+	}
+	// "exact": the pinned exp on every evaluation of the forward blend, for a bit-for-bit comparison with the CPU
+	// oracle; without it the library's default (hardware exp outside the decision bands)
+	if (argc == 4 && bsr_set_option("exact_exp", strcmp(argv[3], "exact") == 0) != 0) {
+		fprintf(stderr, "bsr_set_option failed: %s\n", bsr_last_error());
 		return 2;
 	}
 	FILE* fi = fopen(argv[1], "rb");

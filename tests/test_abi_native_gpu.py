@@ -40,7 +40,7 @@ def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
         for a in (c.bg, c.means3D, c.shs if use_sh else c.colors_precomp, c.opacities, c.scales, c.rotations,
                   c.cam.world_view_transform, c.cam.full_proj_transform, c.cam.camera_center, c.gC, c.gD):
             _f32(a).tofile(f)
-    r = subprocess.run([EXE, str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([EXE, str(inp), str(outp), "exact"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_roundtrip ok" in r.stdout
     N = W * H

@@ -60,6 +60,16 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     assert "secondary" not in d and "cpu_baseline" not in d
 
 
+def test_bench_launches_its_own_ranks_when_typed_plainly():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the form the driver uses for N = 1): the parent must start the
+    two ranks itself as child processes under torch.distributed.run and relay rank 0's JSON line (round 2: it exited
+    with rc 1).  Both ranks on this box's one GPU over gloo, as in the control-flow test above."""
+    d = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--gaussians", "100000", "--no-cpu-baseline",
+                    "--prewarm-ms", "20"], env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 4
+    assert d["c4"]["n_gpus"] == 2 and d["c4"]["views_per_rank"] == [32, 32]
+
+
 def test_bench_headline_line_has_the_contract_keys():
     """The default invocation's JSON (shortened): contract keys, roofline, C4 and the secondary workloads."""
     d = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-sample", "20000"])

@@ -886,14 +886,15 @@ def test_a_few_optimiser_steps_reduce_the_loss():
 def test_integer_flavour_of_the_tile_sort():
     """The tile sort compares keys as binary64 (v_min_f64 / v_max_f64) when every depth of a segment is a positive,
     normal, finite float, and as integers otherwise -- which real inputs only reach with NaN or non-positive depth
-    bits (such Gaussians are culled before).  BSR_SORT_FORCE_INT=1 (read once per process, hence a child process) sends
-    every segment through the integer flavour: the forward results of all three size classes must stay bit-exact."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BSR_SORT_FORCE_INT="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_parity_gpu.py"), "-q", "-x",
-                        "-k", "test_forward_bit_exact_vs_oracle and (sh3 or lists_gt_1024 or lists_gt_8192 or "
-                              "clustered_84k_list or c2_100k_800x800 or huge_splats)"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+    bits (such Gaussians are culled before).  bsr_set_option("sort_force_int", 1) sends every segment through the
+    integer flavour: the forward results of all three size classes must stay bit-exact."""
+    from bloomscene_amd import _capi
+    _capi.set_option("sort_force_int", 1)
+    try:
+        assert _capi.get_option("sort_force_int") == 1
+        for name in ("sh3", "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "c2_100k_800x800", "huge_splats"):
+            c = Hh.make_case(**CASES[name])
+            st, _ = Hh.run_oracle(c, backward=False)
+            _assert_forward_bit_exact(c, st)
+    finally:
+        _capi.set_option("sort_force_int", 0)

@@ -1,0 +1,287 @@
+"""GPU tests added in round 3:
+
+* the library's DEFAULT forward (bsr_set_option("exact_exp", 0): hardware exp outside the decision bands) against the
+  oracle and against its own exact mode -- every discrete result identical, images within a few ulp;
+* the backward's slab inside a binning buffer the forward sized from a GUESS (kept <= guess < R);
+* opacities <= 0 / NaN: pairs the forward skipped must be skipped by the backward;
+* data-parallel training over views: two ranks, two different views, the packed all-reduce must
+  leave oracle-gradient(view 0) + oracle-gradient(view 1) on every rank.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from test_parity_gpu import CASES, _assert_forward_bit_exact, _dev, _native_forward, _raw_backward
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ default (fast exp) forward
+FAST_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "shell_view", "lists_gt_1024", "lists_gt_8192",
+              "clustered_84k_list", "free_camera_sh3", "huge_splats", "c2_100k_800x800", "c1_10k_256x256", "one_gaussian"]
+
+
+def _compare_default_with_exact(c, st, label):
+    """Runs the forward in both modes.  Asserted: radii, num_rendered, the per-tile lists are IDENTICAL; n_contrib
+    differs on at most a 1e-5 share of the pixels (+2) -- the `T (1 - alpha) < 1e-4` stop sees a T that differs by ulps;
+    colour / depth / final_T of the default mode within 2e-5 of the image's scale of the oracle (1e-4 on pixels whose
+    stop decision moved: one more or one fewer entry of weight < 1e-4)."""
+    from bloomscene_amd import _capi
+    assert _capi.get_option("exact_exp") == 0
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+    b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    _capi.set_option("exact_exp", 1)
+    try:
+        rs2, t2, R2, color2, depth2, radii2, gb2, bb2, ib2 = _native_forward(c)
+        b2 = Hh.decode_buffers(c.P, c.W, c.H, R2, gb2, bb2, ib2)
+    finally:
+        _capi.set_option("exact_exp", 0)
+    # the exact mode is the oracle, bit for bit
+    np.testing.assert_array_equal(color2.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
+    np.testing.assert_array_equal(depth2.cpu().numpy().view(np.uint32), st.depth.view(np.uint32))
+    # discrete results
+    assert R == R2 == st.num_rendered
+    np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+    np.testing.assert_array_equal(b.tile_start, b2.tile_start)
+    np.testing.assert_array_equal(b.point_list, b2.point_list)
+    flips = b.n_contrib != b2.n_contrib
+    n_flip = int(flips.sum())
+    assert n_flip <= 2 + 1e-5 * flips.size, (label, n_flip, flips.size)
+    fl = flips.reshape(c.H, c.W)
+    col, dep = color.cpu().numpy(), depth.cpu().numpy()
+    worst = {}
+    for name, got, ref in (("color", col, st.color), ("depth", dep, st.depth),
+                           ("final_T", b.final_T.reshape(1, c.H, c.W), st.final_T.reshape(1, c.H, c.W))):
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        err = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / scale
+        m = np.broadcast_to(fl, err.shape)
+        worst[name] = float(err[~m].max()) if (~m).any() else 0.0
+        assert worst[name] <= 2e-5, (label, name, worst[name])
+        if m.any():
+            assert float(err[m].max()) <= (5e-2 if name == "depth" else 2e-4), (label, name, float(err[m].max()))
+    print(f"[fast-exp] {label:24s} stop decisions moved on {n_flip} of {flips.size} pixels; max err / scale: "
+          + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    return n_flip
+
+
+@pytest.mark.fast_exp
+@pytest.mark.parametrize("name", FAST_CASES)
+def test_default_forward_against_oracle_and_exact_mode(name):
+    c = Hh.make_case(**CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    _compare_default_with_exact(c, st, name)
+
+
+@pytest.mark.fast_exp
+@pytest.mark.parametrize("name", ["sh3", "precomp_color", "shell_view", "free_camera_sh3", "lists_gt_1024",
+                                  "c2_100k_800x800"])
+def test_default_mode_gradients_against_oracle(name):
+    """End to end through torch.autograd in the library's default mode: same bars as the exact mode
+    (helpers.assert_gradient_parity: norm-wise < 1e-5, elementwise share bounded by the reference's own f32-order
+    spread)."""
+    c = Hh.make_case(**CASES[name])
+    st, g = Hh.run_oracle(c)
+    out = Hh.run_hip(c)
+    np.testing.assert_array_equal(out.radii, st.radii)
+    Hh.assert_gradient_parity(c, st, g, out.grads, label="default:" + name)
+
+
+@pytest.mark.fast_exp
+def test_default_mode_full_size_c3():
+    """BASELINE config C3 at full size in the default mode: discrete results identical to the exact mode and the
+    oracle, images within 2e-5 of scale, gradients at the exact mode's bars."""
+    c = Hh.make_case(P=1_000_000, W=1920, H=1080, deg=3, seed=0)
+    st, g = Hh.run_oracle(c)
+    _compare_default_with_exact(c, st, "c3")
+    out = Hh.run_hip(c)
+    Hh.assert_gradient_parity(c, st, g, out.grads, label="default:c3")
+
+
+# ------------------------------------------------------------------ slab inside a guessed binning buffer
+class _CanaryScratch:
+    """Stand-in for rasterizer._Scratch whose tensor carries 8 MiB of 0xA5 behind the bytes the library asked for."""
+    CANARY = 8 << 20
+    made = []
+
+    def __init__(self, device):
+        from bloomscene_amd import _capi
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.requests = []
+        box = self
+
+        def _resize(_user, nbytes):
+            box.requests.append(int(nbytes))
+            box.tensor = torch.full((int(nbytes) + _CanaryScratch.CANARY,), 0xA5, dtype=torch.uint8, device=device)
+            return box.tensor.data_ptr()
+
+        self.callback = _capi.ALLOC_FN(_resize)
+        _CanaryScratch.made.append(self)
+
+    def canary_intact(self):
+        if not self.requests:
+            return True
+        return bool((self.tensor[self.requests[-1]:] == 0xA5).all().item())
+
+
+def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
+    """the forward may size the binning buffer from a guess `cap` and keep it when the KEPT instances
+    fit; the backward carves it for R = num_rendered (it is not told cap) and writes 48 B per kept instance behind
+    point_list[R].  With kept <= cap and cap + 512 Ki < R that ran past the buffer.  Here: a 1 M-Gaussian view with R1
+    instances, then the same shape with all scales multiplied so that kept2 <= 1.25 R1 + 4096 and R2 is > 1 Mi above
+    it; every scratch buffer carries a canary behind the bytes the library asked for, which forward + backward must
+    leave intact, and the gradients must equal those of a call that sized its buffer exactly."""
+    from bloomscene_amd import rasterizer as RZ
+    P, W, H = 1_000_000, 1920, 1080
+    base = Hh.make_case(P=P, W=W, H=H, deg=0, seed=0, color_mode="precomp")
+
+    def variant(scale_mul):
+        c = Hh.make_case(P=P, W=W, H=H, deg=0, seed=0, color_mode="precomp")
+        c.scales = (base.scales * scale_mul).contiguous()
+        return c
+
+    def reset_hint():   # another shape: the next call of (P, W, H) has no guess
+        _native_forward(Hh.make_case(P=1000, W=64, H=64, deg=0, seed=1, color_mode="precomp"))
+
+    def measure(c):
+        reset_hint()
+        rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+        return R, Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib).kept
+
+    c1 = variant(1.0)
+    R1, kept1 = measure(c1)
+    cap = R1 + R1 // 4 + 4096
+    chosen = None
+    for s in (1.25, 1.3, 1.35, 1.4, 1.5, 1.6):
+        R2, kept2 = measure(variant(s))
+        if kept2 <= cap and R2 > cap + (1 << 20):
+            chosen = (s, R2, kept2)
+            break
+    assert chosen is not None, ("no scale puts (kept2, R2) on both sides of the guess", R1, kept1)
+    s2, R2, kept2 = chosen
+    c2 = variant(s2)
+    # reference result: exact sizing (no guess)
+    reset_hint()
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c2)
+    want, _ = _raw_backward(c2, rs, t, R, radii, gb, bb, ib, c2.gC, c2.gD)
+    # guessed sizing, canaries behind every scratch buffer
+    monkeypatch.setattr(RZ, "_Scratch", _CanaryScratch)
+    _CanaryScratch.made.clear()
+    reset_hint()
+    _native_forward(c1)                                   # hint = R1
+    _CanaryScratch.made.clear()
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c2)
+    geom_s, bin_s, img_s = _CanaryScratch.made[:3]
+    assert R == R2
+    assert bin_s.requests[0] < 52 * R2                    # the first request WAS the guess ...
+    need = (4 * R2 + 255) // 256 * 256 + 48 * kept2
+    assert bin_s.requests[-1] >= need, (bin_s.requests, need)   # ... and what the backward got holds its carve
+    got, _ = _raw_backward(c2, rs, t, R, radii, gb, bb, ib, c2.gC, c2.gD)
+    for sc in (geom_s, bin_s, img_s):
+        assert sc.canary_intact(), "forward/backward wrote behind a scratch buffer"
+    for k in want:
+        np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=k)
+    print(f"[slab] R1 {R1} guess {cap}; scales x{s2}: R2 {R2} kept2 {kept2}; binning requests {bin_s.requests}")
+
+
+# ------------------------------------------------------------------ opacities the forward never blends
+@pytest.mark.parametrize("mode", ["exact", "default"])
+def test_non_positive_and_nan_opacity(mode):
+    """API-level inputs no sigmoid produces: opacity < 0, == 0 and NaN.  power_cut = -ln(255 o) is NaN (or inf) for
+    them; the forward skips a pair with alpha < 1/255 (forward.cu:423-428) -- o < 0 gives alpha < 0 -- and the backward
+    must skip the same pairs (outside its decision band it took every candidate as blended)."""
+    from bloomscene_amd import _capi
+    c = Hh.make_case(P=3000, W=160, H=96, deg=1, seed=31, scale_mul=3.0)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randperm(c.P, generator=g)
+    c.opacities = c.opacities.clone()
+    c.opacities[idx[:300]] = -torch.rand(300, 1, generator=g)
+    c.opacities[idx[300:400]] = 0.0
+    c.opacities[idx[400:420]] = float("nan")
+    st, gr = Hh.run_oracle(c)
+    _capi.set_option("exact_exp", 1 if mode == "exact" else 0)
+    out = Hh.run_hip(c)
+    np.testing.assert_array_equal(out.radii, st.radii)
+    if mode == "exact":
+        np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+        np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+    else:
+        assert np.abs(out.color - st.color).max() <= 2e-5 * np.abs(st.color).max()
+    og = Hh.oracle_grads(c, gr)
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        ref, got = getattr(og, k), getattr(out.grads, k)
+        fin = np.isfinite(ref)
+        assert (np.isfinite(got) == fin).all(), k
+        assert Hh.max_err_over_scale(got[fin], ref[fin]) < 1e-5, k
+    # a Gaussian the forward never blends gets no gradient through the blend
+    dead = (c.opacities[:, 0] <= 0).numpy()
+    assert not out.grads.means2D[dead].any()
+
+
+# ------------------------------------------------------------------ §8f-3: gradient all-reduce, values
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _f3_worker(rank, world, port, q):
+    """One rank of the data-parallel step: its OWN view of the shared Gaussians, forward + backward on the GPU, then
+    views.allreduce_gradients (sum).  Both ranks sit on the one GPU of the box, so the process group is gloo (RCCL
+    refuses two ranks on one device); the packing / unpacking under test is backend-independent."""
+    import torch.distributed as dist
+    import helpers as H2
+    from bloomscene_amd import GaussianRasterizer, views
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        c = H2.make_case(P=20000, W=320, H=200, deg=2, seed=77, scene="b", view=3 * rank + 1, scale_mul=4.0)
+        names = ("means3D", "opacities", "shs", "scales", "rotations")
+        leaves = {k: getattr(c, k).to(dev).clone().requires_grad_(True) for k in names}
+        rast = GaussianRasterizer(H2.hip_settings(c, dev))
+        means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        color, radii, depth = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"],
+                                   shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        torch.autograd.backward((color, depth), (c.gC.to(dev), c.gD.to(dev)))
+        ms = views.allreduce_gradients(leaves, average=False)
+        torch.cuda.synchronize()
+        q.put((rank, ms, {k: v.grad.detach().cpu().numpy() for k, v in leaves.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduced_gradients_equal_the_sum_of_the_per_view_oracle_gradients():
+    """SURVEY.md §8(f)-3 / bloomscene.py:232-359 batched over views: after allreduce_gradients(sum) EVERY rank holds
+    sum_views dL/dtheta.  Oracle: the per-view gradients of the CPU oracle, added in float64."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_f3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = None
+    for rank in range(world):
+        c = Hh.make_case(P=20000, W=320, H=200, deg=2, seed=77, scene="b", view=3 * rank + 1, scale_mul=4.0)
+        st, g = Hh.run_oracle(c)
+        assert (st.radii > 0).sum() > 500                      # both views see a good part of the shell
+        og = Hh.oracle_grads(c, g)
+        per = {k: np.asarray(getattr(og, k), dtype=np.float64) for k in ("means3D", "opacities", "shs", "scales",
+                                                                         "rotations")}
+        want = per if want is None else {k: want[k] + per[k] for k in per}
+    for rank, ms, grads in results:
+        assert ms > 0.0
+        for k, ref in want.items():
+            assert Hh.max_err_over_scale(grads[k], ref) < 1e-5, (rank, k)   # the §8(d) norm-wise bound
+    for k in want:                                              # and the ranks agree bit for bit
+        np.testing.assert_array_equal(results[0][2][k].view(np.uint32), results[1][2][k].view(np.uint32))

@@ -6,7 +6,7 @@ while getopts "r:a:" o; do case $o in r) ROUNDS=$OPTARG;; a) ARGS=$OPTARG;; esac
 shift $((OPTIND-1))
 for i in $(seq $ROUNDS); do
   for L in "$@"; do
-    BSR_LIB_PATH=$PWD/$L python bench.py --no-cpu-baseline --no-c4 --no-secondary --steps 40 --warmup 10 $ARGS 2>/dev/null | python -c "
+    python bench.py --lib $PWD/$L --no-cpu-baseline --no-c4 --no-secondary --steps 40 --warmup 10 $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline())
 print('%-40s %8.1f %7.4f  ' % ('$L', d['value'], d['ms_per_step']) + ' '.join('%s=%.4f' % kv for kv in d['stage_ms'].items()))"

@@ -18,9 +18,9 @@ python tools/bench_anchors.py 2>/dev/null | tail -1 > "$OUT/bench_anchors.json"
 python tools/sweep_c5.py 2>/dev/null > "$OUT/sweep_c5.jsonl"
 python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp > "$OUT/parity_report.jsonl" 2>/dev/null
 if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then
-  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py 2>/dev/null | tail -1 > "$OUT/walk_stats_c3.json"
-  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"
-  BSR_LIB_PATH=$ROOT/bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py --config c5 2>/dev/null | tail -1 > "$OUT/walk_stats_c5.json"
+  python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so 2>/dev/null | tail -1 > "$OUT/walk_stats_c3.json"
+  python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"
+  python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --config c5 2>/dev/null | tail -1 > "$OUT/walk_stats_c5.json"
 fi
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-secondary > "$OUT/bench_under_rocprof.log" 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace_c5" -- python3 "$ROOT/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 > "$OUT/bench_c5_under_rocprof.log" 2>&1 )

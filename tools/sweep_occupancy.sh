@@ -1,7 +1,8 @@
 #!/bin/bash
 # BASELINE config C5, "LDS-tile occupancy + rocprof HBM-GB/s sweep": the two tile renderers at 5 M Gaussians with
 #   * the backward's LDS batch at 64 / 128 / 256 staged entries (make -C bloomscene_amd/csrc batch BATCH=64|256), and
-#   * the workgroups a CU can hold capped by unused dynamic LDS (BSR_SWEEP_LDS_PAD_FWD / _BWD, tile_common.h),
+#   * the workgroups a CU can hold capped by unused dynamic LDS (BSR_SWEEP_LDS_PAD_FWD / _BWD, read only by the sweep
+#     build libbsr_rast_sweep.so: make -C bloomscene_amd/csrc sweep; tile_common.h),
 # each point: bench.py --config c5 (stage times from hipEvents) + rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
 # in separate passes, SQ counters in a third) -> tools/sweep_occupancy.py prints one JSON line per point.
 # usage (GPU box, repo root): bash tools/sweep_occupancy.sh <outdir>
@@ -11,14 +12,14 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # name lib pad_fwd pad_bwd
 POINTS=(
- "native            libbloomscene_rast.so 0     0"
- "bwd_wg5           libbloomscene_rast.so 0     5800"
- "bwd_wg4           libbloomscene_rast.so 0     14000"
- "bwd_wg3           libbloomscene_rast.so 0     27700"
- "bwd_wg2           libbloomscene_rast.so 0     55000"
- "fwd_wg6           libbloomscene_rast.so 10800 0"
- "fwd_wg4           libbloomscene_rast.so 24000 0"
- "fwd_wg2           libbloomscene_rast.so 65000 0"
+ "native            libbsr_rast_sweep.so  0     0"
+ "bwd_wg5           libbsr_rast_sweep.so  0     5800"
+ "bwd_wg4           libbsr_rast_sweep.so  0     14000"
+ "bwd_wg3           libbsr_rast_sweep.so  0     27700"
+ "bwd_wg2           libbsr_rast_sweep.so  0     55000"
+ "fwd_wg6           libbsr_rast_sweep.so  10800 0"
+ "fwd_wg4           libbsr_rast_sweep.so  24000 0"
+ "fwd_wg2           libbsr_rast_sweep.so  65000 0"
  "bwd_batch64       libbsr_batch64.so     0     0"
  "bwd_batch64_wg6   libbsr_batch64.so     0     13700"
  "bwd_batch256      libbsr_batch256.so    0     0"
@@ -27,12 +28,12 @@ for p in "${POINTS[@]}"; do
   set -- $p
   name=$1; lib=$2; export BSR_SWEEP_LDS_PAD_FWD=$3; export BSR_SWEEP_LDS_PAD_BWD=$4
   [ -f "$ROOT/bloomscene_amd/$lib" ] || { echo "skip $name: $lib missing"; continue; }
-  export BSR_LIB_PATH=$ROOT/bloomscene_amd/$lib
+  LIBARG="--lib $ROOT/bloomscene_amd/$lib"
   d=$ROOT/$OUT/$name; mkdir -p "$d"
-  ( cd "$ROOT" && python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$d/bench.json" )
+  ( cd "$ROOT" && python bench.py $LIBARG --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$d/bench.json" )
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "grbm GRBM_GUI_ACTIVE"; do
     set -- $pass; pn=$1; shift
-    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" --config c5 --steps 3 --warmup 1 --no-cpu-baseline --no-c4 > "$d/$pn.log" 2>&1 )
+    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" $LIBARG --config c5 --steps 3 --warmup 1 --no-cpu-baseline --no-c4 > "$d/$pn.log" 2>&1 )
   done
   python "$ROOT/tools/pmc_summary.py" "$d" > "$d/pmc_summary.json"
   find "$d" -name "*.csv" -delete

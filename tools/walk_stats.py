@@ -3,7 +3,7 @@
 `make -C bloomscene_amd/csrc stats` (libbsr_rast_stats.so: per-wave counters + a per-workgroup timeline; the product
 library carries neither).  Run on the GPU box:
 
-    BSR_LIB_PATH=bloomscene_amd/libbsr_rast_stats.so python tools/walk_stats.py [--config c3] [--scale-mul 1.0]
+    python tools/walk_stats.py [--lib bloomscene_amd/libbsr_rast_stats.so] [--config c3] [--scale-mul 1.0]
 
 Prints one JSON object: visits per staged entry, share of visits passing each vote, live lanes per reducing visit
 (mean + histogram), and from the timeline: workgroup duration spread, concurrency over time, tail idle.
@@ -27,8 +27,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--scale-mul", type=float, default=1.0, help="scene A with all scales multiplied (denser lists)")
+    ap.add_argument("--lib", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                  "bloomscene_amd", "libbsr_rast_stats.so"))
     args = ap.parse_args()
     from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
+    _capi.use_library(args.lib)
     from bloomscene_amd.synthetic import scene_a, upstream_grads
     lib = _capi.lib()
     fn = lib.bsr_debug_walk_stats   # AttributeError here = not the diagnostic build
