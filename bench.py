@@ -449,7 +449,58 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
             "value": round(n_views * P / t / 1e6, 1),
             "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1),
             "roofline_frac_algorithmic": round(alg_bytes / t / 1e9 / (HBM_PEAK_GBS * D.world), 5)}
-    del bufs
+    # ---- the MI355X-native distribution: every rank gets ONLY what its block of neighbouring views can see, over its
+    # own xGMI link (views.scatter_visible_gaussians), instead of the 236 B/Gaussian broadcast on every link ----
+    D.fence()
+    t0 = time.perf_counter()
+    local, my_views, info = views.scatter_visible_gaussians(bufs if D.rank == 0 else None, cams, src=0,
+                                                            assignment="contiguous", device=dev)
+    D.fence()
+    dist_s = D.max_over_ranks(time.perf_counter() - t0)
+    sc_out = {"assignment": "contiguous blocks of views", "rows_per_rank": info["counts"],
+              "bytes_per_rank": info["bytes"], "filter_ms": round(info["filter_ms"], 3), "pack_ms": round(info["pack_ms"], 3),
+              "comm_ms": round(D.max_over_ranks(info["comm_ms"]), 3), "distribution_ms": round(dist_s * 1e3, 3)}
+
+    def sweep_local():
+        return views.render_views_sharded(cams, local, bg, deg, rank=D.rank, world=D.world, batch=16, views=my_views)
+    sweep_local()
+    times = []
+    for _ in range(repeats):
+        D.fence()
+        t0 = time.perf_counter()
+        sweep_local()
+        D.fence()
+        times.append(D.max_over_ranks(time.perf_counter() - t0))
+    t = sorted(times)[len(times) // 2]
+    sc_out["views_per_call_16"] = {"sweep_ms": round(t * 1e3, 3),
+                                   "ms_per_view_per_rank": round(t / max(len(my_views), 1) * 1e3, 4),
+                                   "value": round(n_views * P / t / 1e6, 1),
+                                   "value_including_distribution": round(n_views * P / (t + dist_s) / 1e6, 1)}
+    out["scatter_visible"] = sc_out
+    # ---- stated model for the first SCALE record to be checked against: t(N) = filter + pack + max_r bytes_r / link rate
+    # + ceil(views / N) * ms per view (this run's, rendering from a rank's subset); broadcast path: 236 B P / link rate
+    if D.rank == 0:
+        LINK_GBS = 153.0   # xGMI, one link (MI355X guide); point-to-point mesh: the N - 1 sends run on their own links
+        rows = views.visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment="contiguous")
+        row_bytes = (3 + 3 + 4 + 1 + 3 * M) * 4
+        per_view_ms = sc_out["views_per_call_16"]["ms_per_view_per_rank"]
+        per_view_bcast_ms = out["views_per_call_16"]["ms_per_view_per_rank"]
+        prep_ms = info["filter_ms"] + info["pack_ms"]
+        pred = {"model": "t(N) = filter_ms + pack_ms + max_r(rows_r * row_bytes) / 153 GB/s + ceil(views / N) * ms_per_view "
+                         "(N = 1: no transfer); broadcast path: t(N) = P * row_bytes / 153 GB/s + ceil(views / N) * "
+                         "ms_per_view_broadcast_path; ms per view as measured in THIS run", "row_bytes": row_bytes,
+                "link_GBs": LINK_GBS, "ms_per_view": per_view_ms, "ms_per_view_broadcast_path": per_view_bcast_ms}
+        t1 = None
+        for w, rr in rows.items():
+            comm = 0.0 if w == 1 else max(rr[1:] or [0]) * row_bytes / (LINK_GBS * 1e6)
+            tw = prep_ms + comm + math.ceil(n_views / w) * per_view_ms
+            tb = (0.0 if w == 1 else P * row_bytes / (LINK_GBS * 1e6)) + math.ceil(n_views / w) * per_view_bcast_ms
+            t1 = tw if t1 is None else t1
+            pred[str(w)] = {"rows_max": max(rr), "transfer_ms": round(comm, 3), "sweep_ms_scatter": round(tw, 3),
+                            "speedup_scatter": round(t1 / tw, 2), "sweep_ms_broadcast": round(tb, 3),
+                            "Msplats_per_s_scatter": round(n_views * P / (tw * 1e-3) / 1e6, 1)}
+        out["predicted"] = pred
+    del bufs, local
     torch.cuda.empty_cache()
     return out
 
@@ -505,6 +556,11 @@ def main():
                         cycle_views=args.cycle_views, label=args.config, allreduce=args.allreduce_grads,
                         depth_gradient=args.depth_gradient)
     c4 = None if args.no_c4 else c4_sweep(D, args)
+    if c4 is not None and headline:
+        # the reference's own rotate360 preset: 180 views, 2 degrees apart (utils/trajectory.py:102-126)
+        c4_180 = c4_sweep(D, args, n_views=180, repeats=3)
+        c4["preset_180_views"] = {k: c4_180[k] for k in ("workload", "views", "views_per_rank", "broadcast_ms",
+                                                        "views_per_call_16", "scatter_visible", "predicted") if k in c4_180}
     secondary = None
     if D.world == 1 and headline and not args.no_secondary:
         sec_steps = max(20, args.steps // 2)

@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			r1 = r[1];
 			r2 = r[2];
 			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-			r2.w = r1.y + 1.0e-3f;   // staged q2.w (the mask half is used up): centre of the decision band, -ln(255 o)
+			r2.w = r1.y + 2.1e-3f;   // staged q2.w (the mask half is used up): upper end of the decision band, -ln(255 o) + 1.1e-3
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -334,19 +334,23 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// candidate inside that 2e-3 wide band evaluates E to decide; everywhere else the VALUE of exp(power) is
 			// all that is needed, and gradients are compared with a tolerance (the reference's sums are unordered),
 			// so it comes from v_exp_f32: 2 issue slots instead of 13.
-			// "inside the band" is voted on |power - centre| < 1.1e-3 (centre = cut + 1e-3, staged in q2.w) over ALL lanes (a vote on an AND with `cand`
-			// makes hipcc materialise the mask in a VGPR): a lane that is not a candidate can only add a harmless
-			// trip through the pinned exp.
-			// The vote is `!(|power - centre| >= 1.1e-3)`: a NaN centre (opacity <= 0 or NaN, whose power_cut is NaN and
-			// lets every lane through `cand`) or a NaN power counts as inside the band, so those pairs get the alpha <
-			// 1/255 test below, which skipped them in the forward (alpha < 0) -- the fast path would blend them.
+			// A lane is "inside the band" iff it is a candidate and !(power >= hi), hi = power_cut + 2.1e-3 staged in q2.w:
+			// with a NaN hi (opacity <= 0 or NaN, whose NaN power_cut also lets every lane through `cand`) or a NaN power
+			// the lane counts as inside, so those pairs get the alpha < 1/255 test below, which skipped them in the forward
+			// (alpha < 0) -- the fast path would blend them.
 #ifdef BSR_BWD_EXACT_EXP
-			const bool in_band = true;   // attribution build: the pinned exp on every visit
+			const bool lane_in_band = true, in_band = true;   // attribution build: the pinned exp on every visit
 #else
-			const bool in_band = wave_ballot(!(fabsf(power - q2.w) >= 1.1e-3f)) != 0ull;   // rare: ~1 % of the visits
+			const bool lane_in_band = cand && !(power >= q2.w);
+			const bool in_band = wave_ballot(lane_in_band) != 0ull;   // rare: ~1 % of the visits
 #endif
+			// per lane the same exp the forward's default mode used on this pair (a lane inside the band: the pinned one,
+			// any other: v_exp_f32 of the same power), so alpha is the forward's alpha bit for bit
 			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
-			if (in_band) Gx = bsr_expf_walk(power);
+			if (in_band) {
+				const float Ge = bsr_expf_walk(power);
+				Gx = lane_in_band ? Ge : Gx;
+			}
 			// Lanes that must not blend carry G = 0, hence alpha = 0: every recurrence below then leaves their state
 			// unchanged (T / 1 = T, Srec + 0 * S = Srec) and all nine contributions are exactly 0 (G * dL_dalpha and
 			// alpha * T; dL_dalpha itself is finite there).

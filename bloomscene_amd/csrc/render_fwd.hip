@@ -100,93 +100,121 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
-			r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
+			r2.w = r1.y + 2.1e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): upper end of the decision band, -ln(255 o) + 1.1e-3
 		}
 		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 		FSTAT_ADD(6, 1);      // batches (per wave)
 		FSTAT_ADD(7, cnt);    // staged entries (every wave sees the batch)
 
 		if (!wave_done) {
-			// Wave-uniform walk over this quadrant's compacted list.  The fast path (no lane is a
-			// candidate) is one ballot; the slow path is fully predicated -- no per-lane branches.
+			// Walk over this wave's compacted list(s), FOUR entries per trip as one straight-line block: no vote and
+			// no branch per entry.  (The predecessor voted "any candidate lane?" per entry and returned early: 2 % of the
+			// visits took that exit, and every visit paid two dependent LDS round trips and three branches in a chain
+			// the seven waves of a SIMD could not cover -- once v_exp_f32 had cut the arithmetic, a quarter fewer
+			// instructions bought 4 %.)  Here the four entries' LDS reads and their power / exp / alpha chains are
+			// independent and the scheduler interleaves them; only the blend itself is serial in T.  The rows are
+			// sentinel-padded to a multiple of four, and a sentinel is never a candidate.
+			// Fully predicated by value: a lane that must not blend carries alpha 0.
+			//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
+			//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
+			// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
 			int n_lim = __builtin_amdgcn_readfirstlane(n_mine);   // set to 0 to leave (single loop exit)
-			const uint32_t base16 = (uint32_t)(base + 1) << 4;
-			auto visit = [&](const unsigned int joff) {
-				const char* rec = reinterpret_cast<const char*>(&st.q0[0]) + joff;
-				const float4 q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
-				const float2 ct = srec_q1lo<FB>(rec);    // -c/2, power cut
-				const float dx = q0.x - pixfx;
-				const float dy = q0.y - pixfy;
-				const float power = (q0.z * dx * dx + ct.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
+			uint32_t lastj = 0xffffffffu;
+			const char* const rec0 = reinterpret_cast<const char*>(&st.q0[0]);
+			struct Ent { float4 q0, q1, q2; float power; bool cand; };
+			auto load = [&](const unsigned int joff) {
+				Ent e;
+				const char* rec = rec0 + joff;
+				e.q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
+				e.q1 = srec_q1<FB>(rec);      // -c/2, power cut, opacity, depth
+				e.q2 = srec_q2<FB>(rec);      // r, g, b, upper end of the decision band
+				const float dx = e.q0.x - pixfx;
+				const float dy = e.q0.y - pixfy;
+				e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
 				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
-				const bool cand = !(power > 0.0f) && !(power < ct.y);
-				FSTAT_ADD(0, 1);   // visits (incl. sentinel padding)
-				if (wave_ballot(cand) == 0ull) return;
-				FSTAT_ADD(1, 1);   // ... with a candidate lane
-				const float2 od = srec_q1hi<FB>(rec);    // opacity, depth
-				const float4 q2 = srec_q2<FB>(rec);      // r, g, b, centre of the decision band
-				// Predication by value instead of by mask (selects and compares issue at half the FMA rate on
-				// gfx950, and votes on AND-ed masks cost two more): a lane that must not blend carries alpha 0.
-				//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
-				//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
-				// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
-				float alpha_raw;
-				bool c2;
-				if (EXACT) {
-					alpha_raw = fminf(0.99f, od.x * bsr_expf_walk(power));   // all lanes: no exec games
-					c2 = cand && !(alpha_raw < 1.0f / 255.0f) && !done;
-				} else {
-					// `alpha >= 1/255` is decided on alpha = min(0.99, o E(power)) with the pinned exp E.  A candidate has
-					// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
-					// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
-					// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
-					// Only a wave with a lane inside that 2.1e-3 wide band (centre staged in q2.w) needs E to decide, and it
-					// then uses E for all its lanes; every other visit takes the VALUE from v_exp_f32.  The vote is
-					// `!(|power - centre| >= 1.1e-3)` so that a NaN (centre: opacity <= 0 or NaN; power: NaN conic) counts
-					// as inside -- those lanes get the exact path's arithmetic, e.g. alpha < 0 is skipped as in the reference.
-					// The backward takes the same decision the same way (render_bwd.hip).
-					const bool in_band = wave_ballot(!(fabsf(power - q2.w) >= 1.1e-3f)) != 0ull;   // rare: ~1 % of the visits
-					float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
-					if (in_band) Gx = bsr_expf_walk(power);
-					alpha_raw = fminf(0.99f, od.x * Gx);
-					c2 = cand && !done;
-					if (in_band) c2 = c2 && !(alpha_raw < 1.0f / 255.0f);
-					FSTAT_ADD(2, in_band ? 1 : 0);   // ... decided by the pinned exp
-				}
+				e.cand = !(e.power > 0.0f) && !(e.power < e.q1.y);
+				return e;
+			};
+			// c2: this lane blends the entry unless the stop test below fires
+			auto blend = [&](const Ent& e, const float alpha_raw, const bool c2, const unsigned int joff) {
 				const float a_eff = c2 ? alpha_raw : 0.0f;
 				const float test_T = T * (1 - a_eff);
 				const bool stop = test_T < 0.0001f;
 				const float a = stop ? 0.0f : a_eff;
 				// reference :439-446 as its nvcc build evaluates them (and the oracle restates them): c * alpha rounded, then
 				// ONE fused multiply-add with T.  fma(c * 0, T, x) == x exactly for every finite c.
-				C0 = __builtin_fmaf(q2.x * a, T, C0);
-				C1 = __builtin_fmaf(q2.y * a, T, C1);
-				C2 = __builtin_fmaf(q2.z * a, T, C2);
-				D = __builtin_fmaf(od.y * a, T, D);
+				C0 = __builtin_fmaf(e.q2.x * a, T, C0);
+				C1 = __builtin_fmaf(e.q2.y * a, T, C1);
+				C2 = __builtin_fmaf(e.q2.z * a, T, C2);
+				D = __builtin_fmaf(e.q1.w * a, T, D);
 				acc = __builtin_fmaf(a, T, acc);
 				T = stop ? T : test_T;
+				lastj = (c2 && !stop) ? joff : lastj;   // byte offset of the last entry of THIS batch the lane blended
+				done = done || stop;
 #ifdef BSR_WALK_STATS
 				{
 					const int live = __popcll(wave_ballot(c2 && !stop));
+					FSTAT_ADD(0, 1);                                        // visits (incl. sentinel padding)
+					FSTAT_ADD(1, wave_ballot(e.cand) != 0ull ? 1 : 0);      // ... with a candidate lane
 					FSTAT_ADD(5, live);                                     // lanes that blend
 					if (live) { FSTAT_ADD(3, 1); FSTAT_ADD(8 + ((live - 1) >> 3), 1); }   // blending visits + histogram
 				}
 #endif
-				last16 = (c2 && !stop) ? joff + base16 : last16;   // 16 * (list position + 1)
-				if (wave_ballot(stop) != 0ull) {   // rare
-					pixfx = stop ? 1.0e15f : pixfx;
-					done = done || stop;
-					if (wave_ballot(!done) == 0ull) n_lim = 0;   // every pixel of the quadrant is done: leave
-				}
 			};
-			// four list entries per trip: one address computation and the four 16-bit list reads up front
 			for (int i = 0; i < n_lim; i += 4) {
 				const uint4 l = *reinterpret_cast<const uint4*>(my_list + i);   // (the row is sentinel-padded to a multiple of 4)
-				visit(l.x);
-				if (i + 1 < n_lim) visit(l.y);
-				if (i + 2 < n_lim) visit(l.z);
-				if (i + 3 < n_lim) visit(l.w);
+				const Ent e0 = load(l.x), e1 = load(l.y), e2 = load(l.z), e3 = load(l.w);
+				float g0, g1, g2, g3;
+				bool decide = true;   // false: alpha >= 1/255 is already proven for every candidate lane of the trip
+				if (EXACT) {
+					g0 = bsr_expf_walk(e0.power);
+					g1 = bsr_expf_walk(e1.power);
+					g2 = bsr_expf_walk(e2.power);
+					g3 = bsr_expf_walk(e3.power);
+				} else {
+					// `alpha >= 1/255` is decided on alpha = min(0.99, o E(power)) with the pinned exp E.  A candidate has
+					// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
+					// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
+					// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
+					// Only a candidate below that bound (`hi` = power_cut + 2.1e-3, staged in q2.w) needs E to decide, and only
+					// a trip holding such a lane evaluates E at all (a few % of the trips); every other one takes the VALUE
+					// from v_exp_f32.  Which exp a lane uses depends on ITS power alone -- never on the lanes or entries it
+					// shares a trip with -- so the image is the same whichever instantiation (NS, view batching, scratch
+					// capacity) renders it.  The test is `cand && !(power >= hi)` so that a NaN (hi: opacity <= 0 or NaN,
+					// whose NaN cut also lets every lane through `cand`; power: NaN conic) counts as inside -- those lanes
+					// get the exact path's arithmetic, e.g. alpha < 0 is skipped as in the reference.  The backward takes
+					// the same decision the same way (render_bwd.hip) and so sees the same alpha.
+					const bool b0 = e0.cand && !(e0.power >= e0.q2.w), b1 = e1.cand && !(e1.power >= e1.q2.w);
+					const bool b2 = e2.cand && !(e2.power >= e2.q2.w), b3 = e3.cand && !(e3.power >= e3.q2.w);
+					g0 = __builtin_amdgcn_exp2f(e0.power * 1.44269504088896341f);
+					g1 = __builtin_amdgcn_exp2f(e1.power * 1.44269504088896341f);
+					g2 = __builtin_amdgcn_exp2f(e2.power * 1.44269504088896341f);
+					g3 = __builtin_amdgcn_exp2f(e3.power * 1.44269504088896341f);
+					decide = (wave_ballot(b0) | wave_ballot(b1) | wave_ballot(b2) | wave_ballot(b3)) != 0ull;   // rare
+					if (decide) {
+						FSTAT_ADD(2, 1);   // trips decided by the pinned exp
+						g0 = b0 ? bsr_expf_walk(e0.power) : g0;
+						g1 = b1 ? bsr_expf_walk(e1.power) : g1;
+						g2 = b2 ? bsr_expf_walk(e2.power) : g2;
+						g3 = b3 ? bsr_expf_walk(e3.power) : g3;
+					}
+				}
+				const float a0 = fminf(0.99f, e0.q1.z * g0), a1 = fminf(0.99f, e1.q1.z * g1);
+				const float a2 = fminf(0.99f, e2.q1.z * g2), a3 = fminf(0.99f, e3.q1.z * g3);
+				if (decide) {
+					blend(e0, a0, e0.cand && !(a0 < 1.0f / 255.0f) && !done, l.x);
+					blend(e1, a1, e1.cand && !(a1 < 1.0f / 255.0f) && !done, l.y);
+					blend(e2, a2, e2.cand && !(a2 < 1.0f / 255.0f) && !done, l.z);
+					blend(e3, a3, e3.cand && !(a3 < 1.0f / 255.0f) && !done, l.w);
+				} else {
+					blend(e0, a0, e0.cand && !done, l.x);
+					blend(e1, a1, e1.cand && !done, l.y);
+					blend(e2, a2, e2.cand && !done, l.z);
+					blend(e3, a3, e3.cand && !done, l.w);
+				}
+				if (wave_ballot(!done) == 0ull) n_lim = 0;   // every pixel of the quadrant is done: leave
 			}
+			last16 = lastj != 0xffffffffu ? lastj + ((uint32_t)(base + 1) << 4) : last16;   // 16 * (list position + 1)
 		}
 	}
 

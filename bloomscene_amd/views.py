@@ -28,6 +28,20 @@ def shard_views(n_views: int, rank: int, world: int):
     return list(range(rank, n_views, world))
 
 
+def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin"):
+    """View indices of `rank`.  "round_robin": {i : i mod world == rank} (balances a yaw-dependent load; every rank sees
+    the whole sweep, so it needs nearly every Gaussian any view sees).  "contiguous": the rank's block of ceil(n / world)
+    neighbouring views -- neighbouring views of a rotate360 sweep overlap (utils/trajectory.py:110-121: 360 / n degrees
+    apart against a ~57 degree field of view), so the Gaussians ONE rank needs are a small part of the scene; what
+    `scatter_visible_gaussians` sends."""
+    if mode == "round_robin":
+        return list(range(rank, n_views, world))
+    if mode == "contiguous":
+        per = -(-n_views // world)
+        return list(range(rank * per, min(n_views, (rank + 1) * per)))
+    raise ValueError(f"unknown view assignment '{mode}'")
+
+
 def yawed_camera(width, height, fovx, yaw_deg=0.0, device="cpu") -> MiniCam:
     """Camera at the origin whose axes are the world's turned by ``yaw_deg`` about +Y: its optical axis is
     (sin yaw, 0, cos yaw) (the scene-A camera when 0)."""
@@ -60,6 +74,120 @@ def broadcast_gaussians(bufs: dict, src: int = 0, force: bool = False) -> float:
             bufs[k].copy_(flat[off:off + n].view_as(bufs[k]))
         off += n
     return ms
+
+
+def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "contiguous", masks=None,
+                              scaling_modifier: float = 1.0, device=None):
+    """Hand every rank ONLY the Gaussians its views can see, instead of broadcasting all of them.
+
+    xGMI is a point-to-point mesh: rank `src` reaches each of its peers over a link of its own (7 x ~153 GB/s on an
+    8-GPU MI355X node).  A broadcast puts the same 236 B per Gaussian on every link (1.5 ms per million Gaussians at SH
+    degree 3, whatever the algorithm: per-link bound); but a rank that renders a block of neighbouring views needs only
+    the Gaussians inside that block's frusta -- ~8 % of scene B for 8 of 64 views -- and the subsets of different
+    ranks travel on different links at the same time.  So: `src` runs the reference's own visibility filter
+    (prefilter_voxel's kernel, gaussian_renderer/__init__.py:342-349) once for ALL cameras
+    (`bsr_visible_filter_views`), forms one mask per rank (any of the rank's views has radii > 0), compacts each rank's
+    rows in ascending id order into one packed fp32 matrix, and posts all sends together (RCCL send/recv =
+    `dist.batch_isend_irecv`).  A Gaussian a view's own preprocess would cull contributes nothing to that view and
+    ascending compaction keeps the (depth, id) tie order, so every frame rendered from the subset is bit-identical to
+    the frame rendered from all Gaussians (tests/test_round3_gpu.py, tests/test_multigpu_gloo.py).
+
+    ``bufs``: on `src` the dict of full per-Gaussian tensors ([P, ...] fp32; must hold means3D, scales, rotations for
+    the filter); ignored elsewhere (pass None).  ``cams``: the whole camera path, on every rank.  ``masks``
+    (optional, `src` only): bool [world, P] to use instead of running the filter (CPU plumbing tests).  ``device``:
+    where a receiving rank wants its tensors (default: the device of its cameras).
+    Returns (local_bufs, my_views, info): the rank's compacted tensors, its view indices, and
+    info = {"counts": rows per rank, "bytes": bytes per rank, "filter_ms", "pack_ms", "comm_ms"} (host-clock, synchronised).
+    Without a process group it is the single-rank case: the union over all views, no communication."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+    world = dist.get_world_size() if multi else 1
+    my_views = assign_views(len(cams), rank, world, assignment)
+    info = {"filter_ms": 0.0, "pack_ms": 0.0, "comm_ms": 0.0}
+
+    def sync(dev):
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    meta = [None]
+    flat_all = None
+    offsets = None
+    if rank == src:
+        keys = sorted(bufs)
+        dev = bufs[keys[0]].device
+        P = bufs[keys[0]].shape[0]
+        sync(dev)
+        t0 = time.perf_counter()
+        if masks is None:
+            vis = prefilter_views(list(cams), bufs["means3D"], bufs["scales"], bufs["rotations"], scaling_modifier)  # [V, P]
+            masks = torch.stack([vis[assign_views(len(cams), r, world, assignment)].any(dim=0) if
+                                 assign_views(len(cams), r, world, assignment) else
+                                 torch.zeros(P, dtype=torch.bool, device=dev) for r in range(world)])
+        masks = masks.to(dev)
+        pairs = masks.nonzero()                     # (rank, id), rank-major, ids ascending: ONE host synchronisation
+        counts = torch.bincount(pairs[:, 0], minlength=world).tolist()
+        sync(dev)
+        t1 = time.perf_counter()
+        idx_all = pairs[:, 1].contiguous()
+        trail = {k: tuple(bufs[k].shape[1:]) for k in keys}
+        flat_all = torch.cat([bufs[k].detach().index_select(0, idx_all).reshape(idx_all.numel(), -1).float()
+                              for k in keys], dim=1).contiguous()          # [sum counts, floats per Gaussian]
+        sync(dev)
+        t2 = time.perf_counter()
+        info["filter_ms"], info["pack_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+        meta = [{"keys": keys, "trail": trail, "counts": counts}]
+        offsets = [0]
+        for c in counts:
+            offsets.append(offsets[-1] + c)
+    if multi:
+        dist.broadcast_object_list(meta, src=src)
+    keys, trail, counts = meta[0]["keys"], meta[0]["trail"], meta[0]["counts"]
+    widths = [int(np.prod(trail[k], dtype=np.int64)) if trail[k] else 1 for k in keys]
+    row = sum(widths)
+    if rank == src:
+        dev = flat_all.device
+        mine = flat_all[offsets[rank]:offsets[rank + 1]]
+    else:
+        dev = torch.device(device) if device is not None else cams[0].world_view_transform.device
+        mine = torch.empty((counts[rank], row), dtype=torch.float32, device=dev)
+    if multi:
+        sync(dev)
+        t0 = time.perf_counter()
+        # gloo moves host memory only (CPU test backend; two ranks on one GPU in the -m gpu tests): stage through it
+        via_host = dist.get_backend() == "gloo" and dev.type == "cuda"
+        ops, landing = [], None
+        if rank == src:
+            wire = flat_all.cpu() if via_host else flat_all
+            ops = [dist.P2POp(dist.isend, wire[offsets[r]:offsets[r + 1]], r) for r in range(world)
+                   if r != src and counts[r] > 0]
+        elif counts[rank] > 0:
+            landing = torch.empty(mine.shape, dtype=torch.float32) if via_host else mine
+            ops = [dist.P2POp(dist.irecv, landing, src)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if landing is not None and via_host:
+            mine.copy_(landing)
+        sync(dev)
+        info["comm_ms"] = (time.perf_counter() - t0) * 1e3
+    local, off = {}, 0
+    for k, w in zip(keys, widths):
+        local[k] = mine[:, off:off + w].reshape((mine.shape[0],) + tuple(trail[k])).contiguous()
+        off += w
+    info["counts"] = list(counts)
+    info["bytes"] = [c * row * 4 for c in counts]
+    return local, my_views, info
+
+
+def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0):
+    """{world: [rows rank 0 .. world-1 would receive from scatter_visible_gaussians]} for several node sizes, from ONE
+    run of the visibility filter on this GPU (bench.py's scaling prediction)."""
+    vis = prefilter_views(list(cams), bufs["means3D"], bufs["scales"], bufs["rotations"], scaling_modifier)
+    out = {}
+    for w in worlds:
+        out[int(w)] = [int(vis[assign_views(len(cams), r, w, assignment)].any(dim=0).sum().item())
+                       if assign_views(len(cams), r, w, assignment) else 0 for r in range(w)]
+    return out
 
 
 def allreduce_gradients(params, average: bool = True, force: bool = False) -> float:
@@ -271,18 +399,19 @@ def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_m
 
 
 def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, world=None, keep_outputs=False,
-                         batch=1):
+                         batch=1, views=None):
     """The rotate360 loop of BloomScene.render_video (reference bloomscene.py:191-211), sharded:
     this rank renders its round-robin share of ``cams`` with torch.no_grad() and returns
     {view index: (frame [3,H,W], depth [1,H,W])} (or only the indices when not keeping outputs).
-    ``batch`` > 1 renders that many of the rank's views per native call (``render_views_batched``)."""
+    ``batch`` > 1 renders that many of the rank's views per native call (``render_views_batched``).
+    ``views``: this rank's view indices when they are not the round-robin share (``scatter_visible_gaussians``)."""
     if rank is None:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     if world is None:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     out = {}
     dev = gaussians["means3D"].device
-    mine = list(shard_views(len(cams), rank, world))
+    mine = list(shard_views(len(cams), rank, world)) if views is None else list(views)
     with torch.no_grad():
         if batch > 1:
             for b0 in range(0, len(mine), batch):

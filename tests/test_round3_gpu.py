@@ -285,3 +285,67 @@ def test_allreduced_gradients_equal_the_sum_of_the_per_view_oracle_gradients():
             assert Hh.max_err_over_scale(grads[k], ref) < 1e-5, (rank, k)   # the §8(d) norm-wise bound
     for k in want:                                              # and the ranks agree bit for bit
         np.testing.assert_array_equal(results[0][2][k].view(np.uint32), results[1][2][k].view(np.uint32))
+
+
+# ------------------------------------------------------------------ C4: per-rank visible subsets instead of a broadcast
+def _scatter_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import helpers as H2
+    from bloomscene_amd import views
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        P, W, H, deg, V = 60000, 320, 180, 2, 12
+        sc = H2.scene_b(P, W, H, deg, n_views=V, seed=3)
+        sc.scales = sc.scales * 4.0
+        cams = [c.to(dev) for c in sc.cameras]
+        names = ("means3D", "scales", "rotations", "opacities", "shs")
+        full = {k: getattr(sc, k).to(dev) for k in names}          # every rank holds the full scene here: the control
+        bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+        local, mine, info = views.scatter_visible_gaussians(full if rank == 0 else None, cams, src=0,
+                                                            assignment="contiguous", device=dev)
+        got = views.render_views_sharded(cams, local, bg, deg, rank=rank, world=world, keep_outputs=True, batch=3,
+                                         views=mine)
+        ok = sorted(got) == mine and info["counts"][rank] == local["means3D"].shape[0] < P
+        for i in mine:
+            ref = views.render_view(cams[i], full, bg, deg)
+            ok = ok and torch.equal(got[i][0], ref["render"]) and torch.equal(got[i][1], ref["depth"])
+            ok = ok and int(ref["visibility_filter"].sum()) > 0
+        q.put((rank, bool(ok), info["counts"], mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frames_from_scattered_visible_subsets_equal_frames_from_all_gaussians():
+    """views.scatter_visible_gaussians (the MI355X-native distribution of the rotate360 sweep): rank 0 runs
+    the visibility filter for all cameras, every rank receives only the rows its block of neighbouring views can see
+    and renders its views from them -- frames and depths bit-identical to rendering from all Gaussians.  Two ranks on
+    the box's one GPU over gloo."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True], results
+    assert results[0][2] == results[1][2] and results[0][3] == list(range(0, 6)) and results[1][3] == list(range(6, 12))
+    assert all(0 < c < 60000 for c in results[0][2])      # each rank got a strict subset
+
+
+@pytest.mark.fast_exp
+def test_default_mode_is_reproducible_and_independent_of_the_instantiation():
+    """Which exp a pixel uses on a pair depends on that pair alone (render_fwd.hip), never on the lanes it shares a wave
+    with: the default mode's images are bit-identical between the split-list and single-list kernels, between a view
+    rendered alone and inside a view batch, between a first call (exact scratch size) and later ones (guessed size),
+    and run to run -- the self-comparisons of the exact-mode suite, repeated in the default mode."""
+    import test_parity_gpu as TP
+    TP.test_view_batched_forward_equals_per_view_calls()
+    TP.test_gradients_and_outputs_are_bit_reproducible()

@@ -3,7 +3,10 @@
     max over elements of |a - b| / max(|b|, 1e-6 * max|b|)   and the fraction of elements above 1e-4
 for colour, depth and every gradient, plus the norm-wise max|a - b| / max|b|.  Runs on the GPU box:
 
-    python tools/parity_report.py [c1 c2 c3 c5 dense ...]  > profiles/<round>/parity_report.jsonl
+    python tools/parity_report.py [--lib build.so] [--exact-exp] [c1 c2 c3 c5 dense ...]  > profiles/<round>/parity_report.jsonl
+
+--lib: another build of the same C ABI (the attribution builds of csrc/Makefile); --exact-exp: the forward with the
+pinned exp everywhere (bit-equal to the oracle) instead of the library's default.
 """
 import json
 import os
@@ -25,11 +28,26 @@ CASES = {
     "dense": dict(P=200_000, W=960, H=540, deg=3, seed=4, scale_mul=4.0),
     "free_camera": dict(P=100_000, W=640, H=360, deg=2, seed=13, scale_mul=3.0, free_camera=True),
     "precomp": dict(P=200_000, W=512, H=512, deg=1, seed=2, color_mode="precomp", scale_mul=2.0),
+    "lists": dict(P=20_000, W=48, H=48, deg=1, seed=7, scale_mul=12.0),   # ~2000 entries per tile: long T chains
 }
 
 
 def main():
-    names = sys.argv[1:] or ["c1", "c2", "c3"]
+    argv = sys.argv[1:]
+    lib = None
+    exact = False
+    while argv and argv[0].startswith("--"):
+        if argv[0] == "--lib":
+            lib, argv = argv[1], argv[2:]
+        elif argv[0] == "--exact-exp":
+            exact, argv = True, argv[1:]
+        else:
+            raise SystemExit(f"unknown option {argv[0]}")
+    from bloomscene_amd import _capi
+    if lib:
+        _capi.use_library(lib)
+    _capi.set_option("exact_exp", exact)
+    names = argv or ["c1", "c2", "c3"]
     for name in names:
         c = Hh.make_case(**CASES[name])
         t0 = time.time()
@@ -37,7 +55,8 @@ def main():
         t_or = time.time() - t0
         out = Hh.run_hip(c)
         rec = {"case": name, **{k: v for k, v in CASES[name].items()}, "num_rendered": int(st.num_rendered),
-               "oracle_s": round(t_or, 1),
+               "oracle_s": round(t_or, 1), "lib": os.path.basename(lib) if lib else "product",
+               "exact_exp": bool(exact),
                "radii_equal": bool((out.radii == st.radii).all()),
                "color_bit_exact": bool((out.color.view(np.uint32) == st.color.view(np.uint32)).all()),
                "depth_bit_exact": bool((out.depth.view(np.uint32) == st.depth.view(np.uint32)).all()),
