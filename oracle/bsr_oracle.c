@@ -517,6 +517,17 @@ static int g_sum_f32 = 0;
 void bsro_set_sum_mode(int f32) { g_sum_f32 = f32; }
 #define ACC(dst, v) do { if (g_sum_f32) (dst) = (double)((float)(dst) + (float)(v)); else (dst) += (v); } while (0)
 
+/* -DBSRO_CONTRACT_RENDER_BWD (make fma -> libbsr_oracle_fma.so, measurement only): THIS function alone is compiled with
+ * floating-point contraction, i.e. the compiler may fuse a * b + c into one FMA wherever it likes -- what nvcc does to
+ * the reference by default (RAST/setup.py passes no -fmad=false).  Both builds are legal evaluations of backward.cu:
+ * 496-586; the distance between their results (tools/parity_report.py: "reference_contracted_vs_source_order") is the
+ * floor for comparing ANY implementation's per-pair terms with this file's, next to the summation-order floor above. */
+#ifdef BSRO_CONTRACT_RENDER_BWD
+#define BSRO_RB_ATTR __attribute__((optimize("fp-contract=fast")))
+#else
+#define BSRO_RB_ATTR
+#endif
+BSRO_RB_ATTR
 void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* point_list, int W, int H,
                           const float* bg_color, const float* points_xy_image, const float* conic_opacity,
                           const float* colors, const float* final_Ts, const uint32_t* n_contrib,

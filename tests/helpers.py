@@ -170,6 +170,35 @@ def rel_err(a, b):
 GRAD_KEYS = ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
 
 
+def contracted_oracle_grads(c):
+    """The oracle's gradients of case `c` from oracle/libbsr_oracle_fma.so (make -C oracle fma): bsro_render_backward
+    compiled WITH fp contraction -- what nvcc does to the reference by default (its setup.py passes no -fmad=false).
+    Source order and contracted are two LEGAL evaluations of backward.cu:496-586 whose per-pair terms differ in their
+    last bits; how far their f64-summed results lie apart is the floor for comparing any implementation's terms with
+    the oracle's.  Runs in a child process (one process loads one oracle build); None if the build is unavailable."""
+    import pickle
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "oracle", "libbsr_oracle_fma.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "fma"], capture_output=True)
+    if not os.path.exists(lib):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "case.pkl"), "wb") as f:
+            pickle.dump(c, f)
+        code = ("import pickle, sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import helpers as H; "
+                "c = pickle.load(open(sys.argv[1], 'rb')); st, g = H.run_oracle(c); og = H.oracle_grads(c, g); "
+                "np.savez(sys.argv[2], **{k: getattr(og, k) for k in H.GRAD_KEYS if getattr(og, k) is not None})"
+                % (ROOT, os.path.join(ROOT, "tests")))
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "case.pkl"), os.path.join(d, "g.npz")],
+                           env=dict(os.environ, BSR_ORACLE_LIB=lib), capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        with np.load(os.path.join(d, "g.npz")) as z:
+            return SimpleNamespace(**{k: (z[k] if k in z.files else None) for k in GRAD_KEYS})
+
+
 def assert_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS, report=None):
     """SURVEY.md §8(d) on every gradient tensor of one case, HIP (`grads`) against the oracle (`g`):
 
@@ -177,15 +206,24 @@ def assert_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS, report=Non
       scale   = max |a - b| / max |b|                     (norm-wise)
 
     §8(d) asks for max_rel <= 1e-4 up to a 1e-5 share of outliers.  For the nine pair sums the reference forms with
-    unordered float atomicAdds that is not attainable even by the reference against itself: two LEGAL outcomes of it --
-    the same fp32 terms added in binary32 in one fixed order (oracle, f32_sums=True) or in binary64 -- differ by more
-    than 1e-4 on a 1e-4 .. 9e-4 share of the elements (heavily cancelling sums), 10 to 90 times §8(d)'s allowance.
-    That measured spread is the floor of any elementwise comparison, so the assertions are
-      scale < 1e-5                                  (every tensor, every case; observed <= 5e-6)
-      frac  <= 8 * floor_frac + 5e-4 + 8 / numel    and   frac <= 4e-3   (twice the largest share observed, C3)
-    and max_rel / frac / floor are printed (pytest -s) and returned for the parity report."""
+    unordered float atomicAdds that is not attainable even by the reference against itself, for two reasons that are
+    both measured here on the case at hand:
+      * summation order -- the same fp32 terms added in binary32 in one fixed order (oracle, f32_sums=True) or in
+        binary64 differ by more than 1e-4 on a 1e-4 .. 9e-4 share of the elements (heavily cancelling sums);
+      * the last bits of the TERMS -- the reference's source compiled with fp contraction (nvcc's default) or without
+        gives per-pair terms that differ by an ulp here and there, and the f64 sums of the two then differ by more
+        than 1e-4 on a 4e-4 .. 2e-3 share (contracted_oracle_grads).  Any implementation whose per-pair arithmetic is
+        not operation-for-operation the oracle's lands there too: round 3's attribution builds show every
+        single shortcut of k_render_bwd switched off alone changing the share by < 15 %, all of them off together
+        bringing it to 0.5x the summation floor.
+    The larger of the two measured shares is the floor of any elementwise comparison, so the assertions are
+      scale < 1e-5                                  (every tensor, every case; observed <= 6e-6)
+      frac  <= 2 * floor + 2e-4 + 8 / numel         (round 2: 8 * summation floor + 5e-4)   and   frac <= 4e-3
+    and max_rel / frac / floors are printed (pytest -s) and returned for the parity report."""
     og = oracle_grads(c, g)
     og32 = oracle_grads(c, O.backward(st, c.gC, c.gD, f32_sums=True))
+    ogc = contracted_oracle_grads(c)
+    assert ogc is not None, "oracle/libbsr_oracle_fma.so missing and not buildable (make -C oracle fma)"
     rows = {}
     for k in keys:
         ref, got = getattr(og, k), getattr(grads, k)
@@ -196,12 +234,15 @@ def assert_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS, report=Non
         assert np.isfinite(got).all(), k
         m, frac = rel_err(got, ref)
         mf, fracf = rel_err(getattr(og32, k), ref)
+        mc, fracc = rel_err(getattr(ogc, k), ref)
         scale = max_err_over_scale(got, ref)
-        rows[k] = dict(max_rel=m, frac=frac, scale=scale, floor_max_rel=mf, floor_frac=fracf, numel=int(ref.size))
-        print(f"[8d] {label:28s} dL_d{k:14s} max_rel {m:.2e} frac>1e-4 {frac:.2e} norm-wise {scale:.1e} | "
-              f"reference f32-order vs f64: max_rel {mf:.2e} frac {fracf:.2e}")
+        floor = max(fracf, fracc)
+        rows[k] = dict(max_rel=m, frac=frac, scale=scale, floor_max_rel=mf, floor_frac=fracf, contraction_max_rel=mc,
+                       contraction_frac=fracc, numel=int(ref.size))
+        print(f"[8d] {label:28s} dL_d{k:14s} max_rel {m:.2e} frac>1e-4 {frac:.2e} norm-wise {scale:.1e} | reference "
+              f"against itself: f32-order vs f64 sums frac {fracf:.2e}, contracted vs source-order terms frac {fracc:.2e}")
         assert scale < 1e-5, (label, k, scale)
-        assert frac <= 8.0 * fracf + 5e-4 + 8.0 / ref.size, (label, k, frac, fracf)
+        assert frac <= 2.0 * floor + 2e-4 + 8.0 / ref.size, (label, k, frac, fracf, fracc)
         assert frac <= 4e-3, (label, k, frac)
     if report is not None:
         report[label] = rows

@@ -64,6 +64,7 @@ def main():
         print("| build | render_bwd ms (C3) | " + " | ".join(t[4:] for t in TENSORS) + " |")
         print("|---|---|" + "---|" * len(TENSORS))
         floor = None
+        floor2 = None
         for b, row in rows.items():
             ten = row["cases"].get(case, {})
             cells = []
@@ -75,10 +76,16 @@ def main():
                 cells.append(f"{f:.2e} ({f / fl:.1f}x)" if fl > 0 else f"{f:.2e}")
                 floor = floor or {}
                 floor[t] = fl
+                if "reference_contracted_vs_source_order" in ten[t]:
+                    floor2 = floor2 or {}
+                    floor2[t] = ten[t]["reference_contracted_vs_source_order"]["frac_above_1e-4"]
             ms = row["render_bwd_ms_c3"]
             print(f"| {b} | {ms if ms is not None else '-'} | " + " | ".join(cells) + " |")
         if floor:
             print("| *floor: reference f32 order vs f64* | | " + " | ".join(f"{floor.get(t, 0):.2e}" for t in TENSORS) + " |")
+        if floor2:
+            print("| *reference with fp contraction (nvcc default) vs without, f64 sums* | | "
+                  + " | ".join(f"{floor2.get(t, 0):.2e}" for t in TENSORS) + " |")
 
 
 if __name__ == "__main__":

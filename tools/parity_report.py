@@ -32,6 +32,9 @@ CASES = {
 }
 
 
+GRADS = ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
+
+
 def main():
     argv = sys.argv[1:]
     lib = None
@@ -66,7 +69,8 @@ def main():
         # fixed order against the order-free binary64 sums (same terms) -- the floor of any elementwise comparison
         from oracle import oracle as O
         og32 = Hh.oracle_grads(c, O.backward(st, c.gC, c.gD, f32_sums=True))
-        for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        ogc = Hh.contracted_oracle_grads(c)
+        for k in GRADS:
             ref, got = getattr(og, k), getattr(out.grads, k)
             if ref is None:
                 continue
@@ -78,6 +82,12 @@ def main():
             rec["tensors"]["dL_d" + k]["reference_f32_order_vs_f64"] = {
                 "max_rel_8d": float("%.3g" % m32), "frac_above_1e-4": float("%.3g" % frac32),
                 "max_err_over_scale": float("%.3g" % Hh.max_err_over_scale(getattr(og32, k), ref))}
+            if ogc is not None and getattr(ogc, k) is not None:
+                # two legal evaluations of the reference's per-pair terms: fp contraction on (nvcc's default) / off
+                mc, fracc = Hh.rel_err(getattr(ogc, k), ref)
+                rec["tensors"]["dL_d" + k]["reference_contracted_vs_source_order"] = {
+                    "max_rel_8d": float("%.3g" % mc), "frac_above_1e-4": float("%.3g" % fracc),
+                    "max_err_over_scale": float("%.3g" % Hh.max_err_over_scale(getattr(ogc, k), ref))}
         print(json.dumps(rec), flush=True)
 
 
