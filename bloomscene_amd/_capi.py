@@ -66,6 +66,14 @@ SIGNATURES = {
     "bsr_anchor_select": (C.c_int, [C.c_int, C.c_int, _F, _F, _F, C.POINTER(C.c_int), C.c_void_p]),
     "bsr_anchor_expand": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_F] * 12 + [C.c_void_p]),
     "bsr_anchor_expand_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_F] * 16 + [C.c_void_p]),
+    "bsr_anchor_gaussian_bytes": (C.c_size_t, [C.c_int]),
+    "bsr_anchor_gradient_bytes": (C.c_size_t, [C.c_int]),
+    "bsr_anchor_render_forward": (C.c_int, [C.c_int, C.c_int] + [_F] * 8 + [ALLOC_FN, C.c_void_p] * 4
+                                  + [_F, C.c_int, C.c_int, C.c_float, _F, _F, _F, C.c_float, C.c_float, _F, _F, C.c_int,
+                                     C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bsr_anchor_render_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_F] * 6 + [_F, _F, _F]
+                                   + [_F, C.c_int, C.c_int, C.c_float, _F, _F, _F, C.c_float, C.c_float]
+                                   + [_F] * 3 + [_F] * 5 + [_F] + [_F] * 6 + [C.c_int, C.c_void_p]),
 }
 
 _lib = None

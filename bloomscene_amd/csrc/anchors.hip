@@ -252,6 +252,12 @@ __global__ void __launch_bounds__(BSR_ANCHOR_BLOCK) k_anchor_expand_bwd(
 
 using namespace bsr;
 
+__global__ void __launch_bounds__(256) k_add_into(size_t n, const float* __restrict__ src, float* __restrict__ dst)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) dst[i] += src[i];
+}
+
 namespace {
 struct Partition { int per_wg, n_wg; long long n_cand; };
 inline bool make_partition(int N, int K, Partition* p)
@@ -376,6 +382,105 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected, c
 	const hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return fail("bsr_anchor_expand_backward: launch failed: %s", hipGetErrorString(e));
 	return 0;
+}
+
+// ---- the fused front end: selection + expansion + rasterizer in ONE native call ------------------------------------
+// Layout (float offsets) of the packed per-Gaussian buffer of the S selected Gaussians: rot first, its rows are read
+// as 16-byte vectors.  radii are int32.
+//   rot[S,4] 0 | xyz[S,3] 4S | color[S,3] 7S | scaling[S,3] 10S | opacity[S] 13S | radii[S] 14S          (15 S words)
+// and of the gradient scratch the backward fills:
+//   dL_drot[S,4] 0 | dL_dxyz[S,3] 4S | dL_dcolor[S,3] 7S | dL_dscaling[S,3] 10S | dL_dopacity[S] 13S | dL_dmean2D[S,3] 14S   (17 S)
+size_t bsr_anchor_gaussian_bytes(int num_selected) { return (size_t)(num_selected > 0 ? num_selected : 0) * 15 * sizeof(float); }
+size_t bsr_anchor_gradient_bytes(int num_selected) { return (size_t)(num_selected > 0 ? num_selected : 0) * 17 * sizeof(float); }
+
+int bsr_anchor_render_forward(int n_anchors, int n_offsets, const float* anchor, const float* grid_scaling,
+                              const float* grid_offsets, const float* neural_opacity, const float* color,
+                              const float* scale_rot, uint8_t* mask, void* anchor_scratch, bsr_alloc_fn gaussianBuffer,
+                              void* gaussian_user, bsr_alloc_fn geometryBuffer, void* geometry_user,
+                              bsr_alloc_fn binningBuffer, void* binning_user, bsr_alloc_fn imageBuffer, void* image_user,
+                              const float* background, int width, int height, float scale_modifier,
+                              const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                              float tan_fovy, float* out_color, float* out_depth, int debug, void* stream,
+                              int* num_selected, int* num_rendered)
+{
+	if (!num_selected || !num_rendered) return fail("bsr_anchor_render_forward: num_selected / num_rendered is NULL");
+	*num_rendered = 0;
+	if (!gaussianBuffer) return fail("bsr_anchor_render_forward: gaussianBuffer callback is NULL");
+	// the one blocking read of the selection (torch's boolean index has the same one); everything after it is
+	// enqueued from here, without going back to the caller: expansion, preprocess, ... follow the count by microseconds
+	if (bsr_anchor_select(n_anchors, n_offsets, neural_opacity, mask, anchor_scratch, num_selected, stream)) return 1;
+	const int S = *num_selected;
+	float* g = nullptr;
+	if (S > 0) {
+		g = (float*)gaussianBuffer(gaussian_user, bsr_anchor_gaussian_bytes(S));
+		if (!g) return fail("bsr_anchor_render_forward: gaussianBuffer returned null");
+		if (((uintptr_t)g & 15) != 0) return fail("bsr_anchor_render_forward: gaussianBuffer must be 16-byte aligned");
+	}
+	const size_t s = (size_t)S;
+	float* rot = g, *xyz = g + 4 * s, *rgb = g + 7 * s, *scaling = g + 10 * s, *opacity = g + 13 * s;
+	int* radii = (int*)(g + 14 * s);
+	if (bsr_anchor_expand(n_anchors, n_offsets, S, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot,
+	                      anchor_scratch, xyz, rgb, opacity, scaling, rot, stream))
+		return 1;
+	// gaussian_renderer.render's call (GR:235-262): colors_precomp, sh_degree 1 (unused without SHs), prefiltered False
+	return bsr_forward(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, S, 1, 0,
+	                   background, width, height, S ? xyz : nullptr, nullptr, S ? rgb : nullptr, S ? opacity : nullptr,
+	                   S ? scaling : nullptr, scale_modifier, S ? rot : nullptr, nullptr, viewmatrix, projmatrix, cam_pos,
+	                   tan_fovx, tan_fovy, 0, out_color, out_depth, S ? radii : nullptr, debug, stream, num_rendered);
+}
+
+int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, int num_rendered,
+                               const float* grid_scaling, const float* grid_offsets, const float* neural_opacity,
+                               const float* scale_rot, const void* anchor_scratch, const float* gaussians,
+                               char* geom_buffer, char* binning_buffer, char* image_buffer, const float* background,
+                               int width, int height, float scale_modifier, const float* viewmatrix,
+                               const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                               const float* dL_dpix, const float* out_depth, const float* dL_depths,
+                               const float* g_xyz, const float* g_color, const float* g_opacity, const float* g_scaling,
+                               const float* g_rot, float* gradient_scratch, float* dL_danchor, float* dL_dgrid_scaling,
+                               float* dL_dgrid_offsets, float* dL_dneural_opacity, float* dL_dcolor,
+                               float* dL_dscale_rot, int debug, void* stream)
+{
+	const int S = num_selected;
+	const size_t s = (size_t)(S > 0 ? S : 0);
+	float* gs = gradient_scratch;
+	if (S > 0) {
+		if (!gaussians || !gs) return fail("bsr_anchor_render_backward: gaussians / gradient_scratch is NULL");
+		if (((uintptr_t)gs & 15) != 0) return fail("bsr_anchor_render_backward: gradient_scratch must be 16-byte aligned");
+		const float* rot = gaussians, *xyz = gaussians + 4 * s, *rgb = gaussians + 7 * s, *scaling = gaussians + 10 * s;
+		const int* radii = (const int*)(gaussians + 14 * s);
+		float* d_rot = gs, *d_xyz = gs + 4 * s, *d_rgb = gs + 7 * s, *d_scaling = gs + 10 * s, *d_opacity = gs + 13 * s,
+		     *d_mean2D = gs + 14 * s;
+		int rc;
+		if (out_depth)
+			rc = bsr_backward_depth(S, 1, 0, num_rendered, background, width, height, xyz, nullptr, rgb, scaling,
+			                        scale_modifier, rot, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+			                        geom_buffer, binning_buffer, image_buffer, out_depth, dL_dpix, dL_depths, d_mean2D, nullptr,
+			                        d_opacity, d_rgb, d_xyz, nullptr, nullptr, d_scaling, d_rot, debug, stream);
+		else
+			rc = bsr_backward(S, 1, 0, num_rendered, background, width, height, xyz, nullptr, rgb, scaling, scale_modifier,
+			                  rot, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer,
+			                  binning_buffer, image_buffer, dL_dpix, dL_depths, d_mean2D, nullptr, d_opacity, d_rgb, d_xyz,
+			                  nullptr, nullptr, d_scaling, d_rot, debug, stream);
+		if (rc) return rc;
+		// gradients that reached the expanded tensors from outside the rasterizer (BloomScene's scaling regulariser
+		// reads `scaling`, bloomscene.py:296-297): added before they are pulled back through the expansion
+		const float* extra[5] = {g_rot, g_xyz, g_color, g_scaling, g_opacity};
+		float* into[5] = {d_rot, d_xyz, d_rgb, d_scaling, d_opacity};
+		const size_t width_of[5] = {4, 3, 3, 3, 1};
+		for (int i = 0; i < 5; i++)
+			if (extra[i]) {
+				const size_t n = s * width_of[i];
+				hipLaunchKernelGGL(k_add_into, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
+				                   extra[i], into[i]);
+			}
+		if (hipGetLastError() != hipSuccess) return fail("bsr_anchor_render_backward: launch failed");
+	}
+	return bsr_anchor_expand_backward(n_anchors, n_offsets, S, grid_scaling, grid_offsets, neural_opacity, scale_rot,
+	                                  anchor_scratch, S ? gs + 4 * s : nullptr, S ? gs + 7 * s : nullptr,
+	                                  S ? gs + 13 * s : nullptr, S ? gs + 10 * s : nullptr, S ? gs : nullptr, dL_danchor,
+	                                  dL_dgrid_scaling, dL_dgrid_offsets, dL_dneural_opacity, dL_dcolor, dL_dscale_rot,
+	                                  stream);
 }
 
 }  // extern "C"

@@ -265,25 +265,35 @@ def render_view(cam: MiniCam, gaussians: dict, bg_color, sh_degree=0, scaling_mo
 
 
 def render_neural(cam: MiniCam, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, bg_color,
-                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False):
+                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False, fused=True):
     """gaussian_renderer.render for BloomScene's anchor representation (GR:211-291) from the point
     where the MLP heads have produced their outputs: fused anchor expansion (GR:165-203,
     ``neural_gaussians.expand_anchors``) -> rasterizer with ``colors_precomp`` and ``sh_degree=1``
     (GR:235-262).  Returns the training-mode result dict of GR:266-279 minus the entropy-coder rates
     (``bit_per_*`` come from the out-of-scope context model): render, viewspace_points,
-    visibility_filter, radii, depth, selection_mask, neural_opacity, scaling."""
-    from .neural_gaussians import expand_anchors
+    visibility_filter, radii, depth, selection_mask, neural_opacity, scaling.  ``fused`` (default): one native call
+    each way (``neural_gaussians.render_anchors``); False: expand_anchors and the rasterizer as separate autograd nodes.
+    Either way ``viewspace_points.grad`` holds the screen-space gradient after backward."""
+    from .neural_gaussians import expand_anchors, render_anchors
     from .rasterizer import GaussianRasterizer
-    xyz, rgb, opacity, scaling, rot, mask = expand_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color,
-                                                           scale_rot)
-    screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device) + 0
-    if retain_grad:
-        try:
-            screenspace_points.retain_grad()
-        except Exception:
-            pass
+    if fused and not debug:
+        # one native call for selection + expansion + rasterizer (and one for their backward): no interpreter time
+        # between the blocking read of the selection count and the rasterizer's first launch
+        image, depth, radii, mask, xyz, rgb, opacity, scaling, rot, viewspace = render_anchors(
+            anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot,
+            make_settings(cam, bg_color, 1, scaling_modifier, debug), depth_gradient)
+        return {"render": image, "viewspace_points": viewspace, "visibility_filter": radii > 0, "radii": radii,
+                "depth": depth, "selection_mask": mask, "neural_opacity": neural_opacity, "scaling": scaling}
+    # the same as two autograd nodes (what fused=True is tested against, bit for bit).  Everything that does not depend
+    # on the number of selected Gaussians first: expand_anchors blocks the host on that count, and whatever python runs
+    # between its return and the rasterizer's first launch is GPU idle time
     rasterizer = GaussianRasterizer(raster_settings=make_settings(cam, bg_color, 1, scaling_modifier, debug),
                                     depth_gradient=depth_gradient)
+    xyz, rgb, opacity, scaling, rot, mask = expand_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color,
+                                                           scale_rot)
+    # GR:224-229 builds `zeros_like(xyz, requires_grad=True) + 0` and calls retain_grad(): a leaf receives .grad as well,
+    # without the second kernel and the extra autograd node
+    screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device)
     rendered_image, radii, depth = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=rgb,
                                               opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
@@ -315,7 +325,7 @@ def training_view(cam: MiniCam, anchor, anchor_scaling, anchor_rotation, grid_of
     ``(neural_opacity [n*K,1], color [n*K,3], scale_rot [n*K,7])`` for the ``n`` visible anchors ``idx``.
     Returns render_neural's dict plus ``visible_mask`` (= prefilter_voxel's result), ``visible_idx`` and
     ``anchor_radii``; every output is bit-identical to the separate calls (tests/test_anchors_gpu.py)."""
-    from .neural_gaussians import expand_anchors
+    from .neural_gaussians import expand_anchors, render_anchors
     from .rasterizer import GaussianRasterizer
     rasterizer = GaussianRasterizer(raster_settings=make_settings(cam, bg_color, 1, scaling_modifier, debug),
                                     depth_gradient=depth_gradient)
@@ -325,16 +335,17 @@ def training_view(cam: MiniCam, anchor, anchor_scaling, anchor_rotation, grid_of
     vis_scaling = anchor_scaling.index_select(0, idx)
     vis_offsets = grid_offsets.index_select(0, idx)
     neural_opacity, color, scale_rot = heads(idx)
-    xyz, rgb, opacity, scaling, rot, mask = expand_anchors(vis_anchor, vis_scaling, vis_offsets, neural_opacity, color,
-                                                           scale_rot)
-    screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device) + 0
-    if retain_grad:
-        try:
-            screenspace_points.retain_grad()
-        except Exception:
-            pass
-    rendered_image, radii, depth = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None, colors_precomp=rgb,
-                                              opacities=opacity, scales=scaling, rotations=rot, cov3D_precomp=None)
+    if not debug:   # selection + expansion + rasterizer: one native call each way (render_neural, fused=True)
+        rendered_image, depth, radii, mask, xyz, rgb, opacity, scaling, rot, screenspace_points = render_anchors(
+            vis_anchor, vis_scaling, vis_offsets, neural_opacity, color, scale_rot, rasterizer.raster_settings,
+            depth_gradient)
+    else:
+        xyz, rgb, opacity, scaling, rot, mask = expand_anchors(vis_anchor, vis_scaling, vis_offsets, neural_opacity,
+                                                               color, scale_rot)
+        screenspace_points = torch.zeros_like(xyz, dtype=anchor.dtype, requires_grad=True, device=xyz.device)
+        rendered_image, radii, depth = rasterizer(means3D=xyz, means2D=screenspace_points, shs=None,
+                                                  colors_precomp=rgb, opacities=opacity, scales=scaling, rotations=rot,
+                                                  cov3D_precomp=None)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth, "selection_mask": mask, "neural_opacity": neural_opacity,
             "scaling": scaling, "visible_mask": radii_pure > 0, "visible_idx": idx, "anchor_radii": radii_pure}

@@ -26,6 +26,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "bloomscene_rast.h"   /* bsr_alloc_fn */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -67,6 +69,58 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected,
                                float* dL_danchor, float* dL_dgrid_scaling, float* dL_dgrid_offsets,
                                float* dL_dneural_opacity, float* dL_dcolor, float* dL_dscale_rot,
                                void* stream);
+
+/* ---- the fused front end: selection + expansion + rasterizer forward (and their backward) in ONE native call --------
+ * gaussian_renderer.render on the anchor representation (GR:165-203 then GR:235-262) needs the number S of selected
+ * Gaussians on the HOST (it shapes every tensor downstream), and the host is blocked on that read while the GPU waits
+ * for whatever is launched next.  Called separately (bsr_anchor_select, bsr_anchor_expand, bsr_forward), the
+ * interpreter's work between the three calls is GPU idle time: 100 us of a 630 us step at 100 k anchors x 10, 512^2.
+ * Here the library reads S, asks for the one S-sized buffer through `gaussianBuffer`, and enqueues the expansion and
+ * the whole rasterizer forward without returning to the caller.
+ *
+ * gaussianBuffer(user, bsr_anchor_gaussian_bytes(S)) must return 16-byte aligned device memory; the library lays the
+ * selected Gaussians out in it as fp32 words  rot[S,4] at 0 | xyz[S,3] at 4S | color[S,3] at 7S | scaling[S,3] at 10S |
+ * opacity[S] at 13S | radii[S] (int32) at 14S,  i.e. the outputs of bsr_anchor_expand and the radii of bsr_forward.
+ * The rasterizer call is the reference's: colors_precomp = color, sh_degree 1, prefiltered False (GR:244-262).
+ * Everything else as bsr_anchor_select / bsr_anchor_expand / bsr_forward. */
+size_t bsr_anchor_gaussian_bytes(int num_selected);
+int bsr_anchor_render_forward(int n_anchors, int n_offsets,
+                              const float* anchor, const float* grid_scaling, const float* grid_offsets,
+                              const float* neural_opacity, const float* color, const float* scale_rot,
+                              uint8_t* mask, void* anchor_scratch,
+                              bsr_alloc_fn gaussianBuffer, void* gaussian_user,
+                              bsr_alloc_fn geometryBuffer, void* geometry_user,
+                              bsr_alloc_fn binningBuffer, void* binning_user,
+                              bsr_alloc_fn imageBuffer, void* image_user,
+                              const float* background, int width, int height, float scale_modifier,
+                              const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                              float tan_fovx, float tan_fovy,
+                              float* out_color, float* out_depth, int debug, void* stream,
+                              int* num_selected, int* num_rendered);
+
+/* Backward of bsr_anchor_render_forward: bsr_backward (bsr_backward_depth when out_depth is non-NULL) into
+ * `gradient_scratch`, then bsr_anchor_expand_backward from it.  gradient_scratch: bsr_anchor_gradient_bytes(S) bytes,
+ * 16-byte aligned, laid out as  dL_drot[S,4] at 0 | dL_dxyz[S,3] at 4S | dL_dcolor[S,3] at 7S | dL_dscaling[S,3] at 10S |
+ * dL_dopacity[S] at 13S | dL_dmean2D[S,3] at 14S;  it is left filled -- dL_dmean2D is the screen-space gradient the
+ * caller reads through `viewspace_points.grad` (GR:224-229, scene/gaussian_model.py:756).
+ * g_xyz .. g_rot (each may be NULL): gradients that reached the expanded tensors from OUTSIDE the rasterizer, added to
+ * the rasterizer's before the expansion is differentiated (BloomScene's scaling regulariser reads `scaling`). */
+size_t bsr_anchor_gradient_bytes(int num_selected);
+int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, int num_rendered,
+                               const float* grid_scaling, const float* grid_offsets,
+                               const float* neural_opacity, const float* scale_rot,
+                               const void* anchor_scratch, const float* gaussians,
+                               char* geom_buffer, char* binning_buffer, char* image_buffer,
+                               const float* background, int width, int height, float scale_modifier,
+                               const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy,
+                               const float* dL_dpix, const float* out_depth, const float* dL_depths,
+                               const float* g_xyz, const float* g_color, const float* g_opacity,
+                               const float* g_scaling, const float* g_rot,
+                               float* gradient_scratch,
+                               float* dL_danchor, float* dL_dgrid_scaling, float* dL_dgrid_offsets,
+                               float* dL_dneural_opacity, float* dL_dcolor, float* dL_dscale_rot,
+                               int debug, void* stream);
 
 #ifdef __cplusplus
 }

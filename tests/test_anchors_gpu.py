@@ -197,6 +197,54 @@ def test_render_neural_result_dict():
         assert leaf.grad is not None and torch.isfinite(leaf.grad).all()
 
 
+@pytest.mark.parametrize("depth_gradient", [False, True])
+def test_fused_native_render_equals_the_two_autograd_nodes(depth_gradient):
+    """neural_gaussians.render_anchors = bsr_anchor_render_forward / _backward: selection + expansion + rasterizer in
+    one native call each way (no interpreter time between the blocking read of the selection count and the
+    rasterizer's first launch).  Image, depth, radii, mask, the expanded tensors and every gradient -- with a loss that
+    also reads `scaling` and `opacity` directly, as BloomScene's regularisers do -- must be bit-identical to
+    expand_anchors followed by GaussianRasterizer, and viewspace_points.grad must be the rasterizer's dL_dmean2D.
+    Also: nothing selected, and no anchors at all."""
+    import math
+    from bloomscene_amd import cameras, views
+    from bloomscene_amd.synthetic import upstream_grads
+    dev = _dev()
+    W, H = 160, 96
+    cam = cameras.identity_camera(W, H, math.radians(60)).to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    gC, gD = upstream_grads(W, H, seed=3)
+    gC, gD = gC.to(dev), gD.to(dev)
+    for N, K, seed in ((3001, 10, 31), (500, 7, 32)):    # (odd selection counts: the packed sections stay aligned)
+        inp = list(OA.synthetic_anchor_inputs(N, K, seed=seed))
+        inp[0] = inp[0] * torch.tensor([0.6, 0.35, 0.0]) + torch.tensor([0.0, 0.0, 6.0])
+        results = []
+        for fused in (True, False):
+            leaves = [t.to(dev).clone().requires_grad_(True) for t in inp]
+            res = views.render_neural(cam, *leaves, bg, depth_gradient=depth_gradient, fused=fused)
+            loss_extra = res["scaling"].prod(dim=1).mean() * 3.0
+            torch.autograd.backward((res["render"], res["depth"], loss_extra), (gC, gD, torch.ones((), device=dev)))
+            results.append((res, [t.grad.clone() for t in leaves], res["viewspace_points"].grad.clone()))
+        (ra, ga, va), (rb, gb, vb) = results
+        for k in ("render", "depth", "radii", "selection_mask", "scaling", "visibility_filter"):
+            assert torch.equal(ra[k], rb[k]), k
+        assert int(ra["radii"].numel()) % 2 == 1 or N == 500
+        for name, x, y in zip(IN_NAMES, ga, gb):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), name
+        assert torch.equal(va.view(torch.int32), vb.view(torch.int32)) and bool(va.abs().sum() > 0)
+    # nothing selected / no anchors: zero images, empty per-Gaussian outputs, zero gradients
+    for N, K in ((40, 10), (0, 10)):
+        inp = list(OA.synthetic_anchor_inputs(max(N, 1), K, seed=1))
+        inp = [t[:N] if i < 3 else t[:N * K] for i, t in enumerate(inp)]
+        inp[3] = -inp[3].abs() - 1.0
+        leaves = [t.to(dev).clone().requires_grad_(True) for t in inp]
+        res = views.render_neural(cam, *leaves, bg, fused=True)
+        assert res["radii"].numel() == 0 and res["scaling"].shape == (0, 3) and not res["selection_mask"].any()
+        assert not res["render"].any() and not res["depth"].any()   # P == 0: zero images (rasterize_points.cu:68-82)
+        res["render"].sum().backward()
+        for leaf in leaves:
+            assert leaf.grad is not None and not leaf.grad.any()
+
+
 def test_training_view_equals_the_separate_calls():
     """SURVEY.md §8f rank 2, per-iteration half (bloomscene.py:240-243): views.training_view -- one rasterizer object,
     bsr_visible_filter_indices, index gathers, fused expansion, render -- against the reference's shape of the same

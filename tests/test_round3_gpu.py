@@ -131,8 +131,8 @@ def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
     """the forward may size the binning buffer from a guess `cap` and keep it when the KEPT instances
     fit; the backward carves it for R = num_rendered (it is not told cap) and writes 48 B per kept instance behind
     point_list[R].  With kept <= cap and cap + 512 Ki < R that ran past the buffer.  Here: a 1 M-Gaussian view with R1
-    instances, then the same shape with all scales multiplied so that kept2 <= 1.25 R1 + 4096 and R2 is > 1 Mi above
-    it; every scratch buffer carries a canary behind the bytes the library asked for, which forward + backward must
+    instances, then the same shape with all scales multiplied so that kept2 <= 1.25 R1 + 4096 while point_list[R2] plus
+    the slab rows end behind the guessed buffer; every scratch buffer carries a canary behind the bytes the library asked for, which forward + backward must
     leave intact, and the gradients must equal those of a call that sized its buffer exactly."""
     from bloomscene_amd import rasterizer as RZ
     P, W, H = 1_000_000, 1920, 1080
@@ -151,16 +151,27 @@ def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
         rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
         return R, Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib).kept
 
+    from bloomscene_amd import _capi
     c1 = variant(1.0)
     R1, kept1 = measure(c1)
     cap = R1 + R1 // 4 + 4096
+    guess_bytes = int(_capi.lib().bsr_binning_bytes(cap))
+
+    def carve_end(R, kept):   # where the backward's R-based carve ends: point_list[R], then 48 B per kept instance
+        return (4 * R + 255) // 256 * 256 + 48 * kept
+
+    # the dangerous window: the kept instances still fit the guess (no re-run for THAT reason) but the R-based carve of
+    # the backward ends behind the guessed buffer; with kept / R ~ 0.62 that is R2 ~ 1.54 .. 1.61 x the guess
     chosen = None
-    for s in (1.25, 1.3, 1.35, 1.4, 1.5, 1.6):
-        R2, kept2 = measure(variant(s))
-        if kept2 <= cap and R2 > cap + (1 << 20):
-            chosen = (s, R2, kept2)
+    for k in range(40):
+        s_mul = 1.6 + 0.02 * k
+        R2, kept2 = measure(variant(s_mul))
+        if kept2 > cap:
             break
-    assert chosen is not None, ("no scale puts (kept2, R2) on both sides of the guess", R1, kept1)
+        if carve_end(R2, kept2) > guess_bytes:
+            chosen = (s_mul, R2, kept2)
+            break
+    assert chosen is not None, ("no scale puts the carve behind the guess while the kept instances fit", R1, kept1, cap)
     s2, R2, kept2 = chosen
     c2 = variant(s2)
     # reference result: exact sizing (no guess)
@@ -176,9 +187,9 @@ def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
     rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c2)
     geom_s, bin_s, img_s = _CanaryScratch.made[:3]
     assert R == R2
-    assert bin_s.requests[0] < 52 * R2                    # the first request WAS the guess ...
-    need = (4 * R2 + 255) // 256 * 256 + 48 * kept2
-    assert bin_s.requests[-1] >= need, (bin_s.requests, need)   # ... and what the backward got holds its carve
+    assert bin_s.requests[0] == guess_bytes               # the first request WAS the guess, too small for the carve ...
+    assert len(bin_s.requests) == 2 and bin_s.requests[-1] >= carve_end(R2, kept2), (bin_s.requests, carve_end(R2, kept2))
+    #                                                       ... so the forward asked again, for what the backward needs
     got, _ = _raw_backward(c2, rs, t, R, radii, gb, bb, ib, c2.gC, c2.gD)
     for sc in (geom_s, bin_s, img_s):
         assert sc.canary_intact(), "forward/backward wrote behind a scratch buffer"
