@@ -300,9 +300,7 @@ int bsr_visible_filter_indices(int P, int M, int width, int height, const float*
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return fail("bsr_visible_filter_indices: launch failed: %s", hipGetErrorString(e));
 	uint32_t total = 0;
-	e = hipMemcpyAsync(&total, wg + n_wg, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-	if (e == hipSuccess) e = hipStreamSynchronize(s);
-	if (e != hipSuccess) return fail("bsr_visible_filter_indices: reading the count failed: %s", hipGetErrorString(e));
+	if (read_u32_blocking(wg + n_wg, &total, s)) return 1;
 	*num_visible = (int)total;
 	return 0;
 }
@@ -332,9 +330,7 @@ int bsr_anchor_select(int n_anchors, int n_offsets, const float* neural_opacity,
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) return fail("bsr_anchor_select: launch failed: %s", hipGetErrorString(e));
 	uint32_t total = 0;
-	e = hipMemcpyAsync(&total, wg + p.n_wg, sizeof(total), hipMemcpyDeviceToHost, s);
-	if (e == hipSuccess) e = hipStreamSynchronize(s);
-	if (e != hipSuccess) return fail("bsr_anchor_select: reading the count failed: %s", hipGetErrorString(e));
+	if (read_u32_blocking(wg + p.n_wg, &total, s)) return 1;
 	*num_selected = (int)total;
 	return 0;
 }
@@ -406,16 +402,29 @@ int bsr_anchor_render_forward(int n_anchors, int n_offsets, const float* anchor,
 	if (!num_selected || !num_rendered) return fail("bsr_anchor_render_forward: num_selected / num_rendered is NULL");
 	*num_rendered = 0;
 	if (!gaussianBuffer) return fail("bsr_anchor_render_forward: gaussianBuffer callback is NULL");
+	// While the GPU counts, ask for the S-sized buffer with a GUESS (the calling thread's previous selection of this
+	// shape + 25 %, as the forward sizes its binning scratch): the callback -- interpreter time on the python host --
+	// then runs beside the selection kernels instead of behind the blocking read.  A guess that turns out short costs
+	// a second callback.  The layout inside the buffer depends on S alone.
+	static thread_local int hint_N = -1, hint_K = -1, hint_S = 0;
+	float* g = nullptr;
+	long long cap = 0;
+	if (hint_N == n_anchors && hint_K == n_offsets && hint_S > 0) {
+		cap = (long long)hint_S + hint_S / 4 + 1024;
+		if (cap > (long long)n_anchors * n_offsets) cap = (long long)n_anchors * n_offsets;
+		g = (float*)gaussianBuffer(gaussian_user, bsr_anchor_gaussian_bytes((int)cap));
+		if (!g) return fail("bsr_anchor_render_forward: gaussianBuffer returned null");
+	}
 	// the one blocking read of the selection (torch's boolean index has the same one); everything after it is
 	// enqueued from here, without going back to the caller: expansion, preprocess, ... follow the count by microseconds
 	if (bsr_anchor_select(n_anchors, n_offsets, neural_opacity, mask, anchor_scratch, num_selected, stream)) return 1;
 	const int S = *num_selected;
-	float* g = nullptr;
-	if (S > 0) {
+	hint_N = n_anchors; hint_K = n_offsets; hint_S = S;
+	if (S > 0 && (!g || S > cap)) {
 		g = (float*)gaussianBuffer(gaussian_user, bsr_anchor_gaussian_bytes(S));
 		if (!g) return fail("bsr_anchor_render_forward: gaussianBuffer returned null");
-		if (((uintptr_t)g & 15) != 0) return fail("bsr_anchor_render_forward: gaussianBuffer must be 16-byte aligned");
 	}
+	if (S > 0 && ((uintptr_t)g & 15) != 0) return fail("bsr_anchor_render_forward: gaussianBuffer must be 16-byte aligned");
 	const size_t s = (size_t)S;
 	float* rot = g, *xyz = g + 4 * s, *rgb = g + 7 * s, *scaling = g + 10 * s, *opacity = g + 13 * s;
 	int* radii = (int*)(g + 14 * s);

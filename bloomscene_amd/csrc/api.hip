@@ -101,7 +101,7 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 // of the previous forward call on this thread (the size guess of the next one).  Nothing here carries
 // results between calls.
 struct SyncCache {
-	int* pinned = nullptr;       // [4] = flags[0..3]
+	int* pinned = nullptr;       // [4] = flags[0..3] of the forward; [4] = landing word of read_u32_blocking
 	hipEvent_t copied = nullptr;
 	int device = -1;
 	int last_P = -1, last_W = -1, last_H = -1, last_V = -1;
@@ -115,7 +115,7 @@ static SyncCache* sync_cache()
 	if (c.device != dev) {   // first use on this thread, or the thread moved to another GPU
 		if (c.copied) (void)hipEventDestroy(c.copied);
 		c.copied = nullptr;
-		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
 			c.pinned = nullptr;
 			fail("hipHostMalloc failed");
 			return nullptr;
@@ -129,6 +129,20 @@ static SyncCache* sync_cache()
 		c.last_P = -1;
 	}
 	return &c;
+}
+
+// One 4-byte device->host read the caller blocks on (selection / visibility counts, anchors.hip): through the calling
+// thread's PINNED landing buffer -- an asynchronous copy into pageable memory is staged by the runtime and signals
+// later -- and waited for on an event.  Returns 0 on success.
+int read_u32_blocking(const uint32_t* dev, uint32_t* out, hipStream_t s)
+{
+	SyncCache* sc = sync_cache();
+	if (!sc) return 1;
+	if (hipMemcpyAsync(sc->pinned + 4, dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+	    hipEventRecord(sc->copied, s) != hipSuccess || hipEventSynchronize(sc->copied) != hipSuccess)
+		return fail("reading a count back failed: %s", hipGetErrorString(hipGetLastError()));
+	*out = (uint32_t)sc->pinned[4];
+	return 0;
 }
 
 // ---------------------------------------------------------------- kernels (other translation units)

@@ -135,6 +135,9 @@ struct BwdArgs {
 // Records the calling thread's error message (read back by bsr_last_error) and returns 1.  api.hip
 int fail(const char* fmt, ...);
 
+// One blocking 4-byte device->host read through the calling thread's pinned landing buffer.  api.hip
+int read_u32_blocking(const uint32_t* dev, uint32_t* out, hipStream_t s);
+
 // Process-wide options of bsr_set_option (include/bloomscene_rast.h), read by the launchers.  api.hip
 int opt_exact_exp();
 int opt_sort_force_int();

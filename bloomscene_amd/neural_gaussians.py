@@ -178,7 +178,8 @@ class _NeuralRender(torch.autograd.Function):
                 C.byref(S), C.byref(R))
         _capi.check(rc, "bsr_anchor_render_forward")
         S, R = S.value, R.value
-        packed = packed_box[0] if packed_box else torch.empty(0, dtype=torch.float32, device=dev)
+        # (the last buffer asked for: the first request may have been a guess made before the count was known)
+        packed = packed_box[-1] if packed_box else torch.empty(0, dtype=torch.float32, device=dev)
         rot = packed[:4 * S].view(S, 4)
         xyz = packed[4 * S:7 * S].view(S, 3)
         rgb = packed[7 * S:10 * S].view(S, 3)

@@ -78,7 +78,10 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected,
  * Here the library reads S, asks for the one S-sized buffer through `gaussianBuffer`, and enqueues the expansion and
  * the whole rasterizer forward without returning to the caller.
  *
- * gaussianBuffer(user, bsr_anchor_gaussian_bytes(S)) must return 16-byte aligned device memory; the library lays the
+ * gaussianBuffer may be called BEFORE S is known, with a size guessed from the calling thread's previous call of the
+ * same (N, K), and a second time with bsr_anchor_gaussian_bytes(S) if that guess was short (the callback's time then
+ * overlaps the selection kernels); the last buffer returned is the one used, and it holds >= bsr_anchor_gaussian_bytes(S).
+ * gaussianBuffer(user, bytes) must return 16-byte aligned device memory; the library lays the
  * selected Gaussians out in it as fp32 words  rot[S,4] at 0 | xyz[S,3] at 4S | color[S,3] at 7S | scaling[S,3] at 10S |
  * opacity[S] at 13S | radii[S] (int32) at 14S,  i.e. the outputs of bsr_anchor_expand and the radii of bsr_forward.
  * The rasterizer call is the reference's: colors_precomp = color, sh_degree 1, prefiltered False (GR:244-262).
