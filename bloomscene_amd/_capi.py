@@ -45,6 +45,8 @@ SIGNATURES = {
                                              C.c_void_p]),
     "bsr_visible_filter_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                            C.c_float, C.c_float, _F, C.c_int, C.c_void_p]),
+    "bsr_visible_filter_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
+                                            C.c_float, C.c_float, _F, _F, C.c_int, C.c_void_p]),
     "bsr_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
                                _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
                                _F, _F, _F, _F, C.c_int, C.c_void_p]),

@@ -151,7 +151,7 @@ void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* 
 void launch_visible_filter_views(int P, int V, const float* means3D, const float* scales, float scale_modifier,
                                  const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
-                                 hipStream_t s);
+                                 const int* group_of_view, int n_groups, uint8_t* group_mask, hipStream_t s);
 void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
@@ -631,9 +631,31 @@ int bsr_visible_filter_views(int P, int n_views, int width, int height, const fl
 	{
 		StageTimer t("visible_filter_views", s);
 		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
-		                            projmatrices, width, height, tan_fovx, tan_fovy, radii, s);
+		                            projmatrices, width, height, tan_fovx, tan_fovy, radii, nullptr, 0, nullptr, s);
 	}
 	STAGE_CHECK("visible_filter_views", debug, s);
+	return 0;
+}
+
+int bsr_visible_filter_groups(int P, int n_views, int n_groups, int width, int height, const float* means3D,
+                              const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrices, const float* projmatrices,
+                              float tan_fovx, float tan_fovy, const int* group_of_view, uint8_t* group_mask, int debug,
+                              void* stream)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (n_views < 0 || n_groups < 0 || n_groups > 64) return fail("bsr_visible_filter_groups: need 0 <= n_groups <= 64");
+	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrices, projmatrices)) return 1;
+	if (P == 0 || n_groups == 0) return 0;
+	if (!group_mask || (n_views > 0 && !group_of_view)) return fail("bsr_visible_filter_groups: NULL buffer");
+	{
+		StageTimer t("visible_filter_groups", s);
+		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
+		                            projmatrices, width, height, tan_fovx, tan_fovy, nullptr, group_of_view, n_groups,
+		                            group_mask, s);
+	}
+	STAGE_CHECK("visible_filter_groups", debug, s);
 	return 0;
 }
 

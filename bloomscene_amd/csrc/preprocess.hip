@@ -389,10 +389,15 @@ __global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, cons
                                                               const float* __restrict__ viewmatrices,
                                                               const float* __restrict__ projmatrices, int W, int H,
                                                               float focal_x, float focal_y, float tan_fovx,
-                                                              float tan_fovy, int gx, int gy, int* __restrict__ radii)
+                                                              float tan_fovy, int gx, int gy, int* __restrict__ radii,
+                                                              const int* __restrict__ group_of_view, int n_groups,
+                                                              uint8_t* __restrict__ group_mask)
 {
+	// group mode (bsr_visible_filter_groups): views carry a group id (the rank that renders them) and the kernel writes
+	// group_mask[g][idx] = "some view of group g sees the Gaussian" instead of (or beside) the V radii per Gaussian
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= P) return;
+	unsigned long long seen = 0ull;
 	const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
 	float cov3D[6];
 	if (cov3D_precomp != nullptr) {
@@ -430,19 +435,22 @@ __global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, cons
 				if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) != 0) radius_out = (int)my_radius;
 			}
 		}
-		radii[(size_t)v * P + idx] = radius_out;
+		if (radii != nullptr) radii[(size_t)v * P + idx] = radius_out;
+		if (group_mask != nullptr && radius_out > 0) seen |= 1ull << group_of_view[v];
 	}
+	if (group_mask != nullptr)
+		for (int g = 0; g < n_groups; g++) group_mask[(size_t)g * P + idx] = (uint8_t)((seen >> g) & 1ull);
 }
 
 void launch_visible_filter_views(int P, int V, const float* means3D, const float* scales, float scale_modifier,
                                  const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
-                                 hipStream_t s)
+                                 const int* group_of_view, int n_groups, uint8_t* group_mask, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_visible_filter_views, dim3((P + 255) / 256), dim3(256), 0, s, P, V, means3D, scales,
 	                   scale_modifier, rotations, cov3D_precomp, viewmatrices, projmatrices, W, H,
 	                   W / (2.0f * tan_fovx), H / (2.0f * tan_fovy), tan_fovx, tan_fovy, (W + BSR_TILE - 1) / BSR_TILE,
-	                   (H + BSR_TILE - 1) / BSR_TILE, radii);
+	                   (H + BSR_TILE - 1) / BSR_TILE, radii, group_of_view, n_groups, group_mask);
 }
 
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s)

@@ -305,6 +305,37 @@ def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_m
     return radii
 
 
+def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
+                                              projmatrices, tan_fovx, tan_fovy, image_height, image_width,
+                                              group_of_view, n_groups, debug):
+    """Per-group visibility (bsr_visible_filter_groups): -> bool [n_groups, P], row g = "some view of group g has
+    radii > 0"; ``group_of_view`` int32 [V] on the device."""
+    _check_means3D(means3D)
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
+    dev = means3D.device
+    P = means3D.size(0)
+    if viewmatrices.dim() != 3 or tuple(viewmatrices.shape[1:]) != (4, 4) or viewmatrices.shape != projmatrices.shape:
+        raise RuntimeError("viewmatrices and projmatrices must both have dimensions (num_views, 4, 4)")
+    V = viewmatrices.size(0)
+    if group_of_view.numel() != V:
+        raise RuntimeError("group_of_view must hold one group id per view")
+    mask = torch.empty((int(n_groups), P), dtype=torch.bool, device=dev)
+    if P != 0 and n_groups != 0:
+        m = _dev_f32(means3D, "means3D", dev)
+        s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)
+        c = _dev_f32(cov3D_precomp, "cov3D_precomp", dev)
+        v, p = _dev_f32(viewmatrices, "viewmatrices", dev), _dev_f32(projmatrices, "projmatrices", dev)
+        gv = group_of_view.to(device=dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            rc = _capi.lib().bsr_visible_filter_groups(
+                P, V, int(n_groups), int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier),
+                _ptr(r), _ptr(c), _ptr(v), _ptr(p), float(tan_fovx), float(tan_fovy), gv.data_ptr() if V else None,
+                mask.data_ptr(), int(bool(debug)), _stream_handle(dev))
+        _capi.check(rc, "rasterize_gaussians_filter_groups")
+    return mask
+
+
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, depth_gradient=False, return_final_T=False):

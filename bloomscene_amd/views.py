@@ -84,9 +84,9 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     8-GPU MI355X node).  A broadcast puts the same 236 B per Gaussian on every link (1.5 ms per million Gaussians at SH
     degree 3, whatever the algorithm: per-link bound); but a rank that renders a block of neighbouring views needs only
     the Gaussians inside that block's frusta -- ~8 % of scene B for 8 of 64 views -- and the subsets of different
-    ranks travel on different links at the same time.  So: `src` runs the reference's own visibility filter
-    (prefilter_voxel's kernel, gaussian_renderer/__init__.py:342-349) once for ALL cameras
-    (`bsr_visible_filter_views`), forms one mask per rank (any of the rank's views has radii > 0), compacts each rank's
+    ranks travel on different links at the same time.  So: `src` runs the reference's own visibility test
+    (prefilter_voxel's, gaussian_renderer/__init__.py:342-349) once over the Gaussians for ALL cameras, reduced on the
+    fly to one mask per rank (`bsr_visible_filter_groups`: any of the rank's views has radii > 0), compacts each rank's
     rows in ascending id order into one packed fp32 matrix, and posts all sends together (RCCL send/recv =
     `dist.batch_isend_irecv`).  A Gaussian a view's own preprocess would cull contributes nothing to that view and
     ascending compaction keeps the (depth, id) tie order, so every frame rendered from the subset is bit-identical to
@@ -119,10 +119,8 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         sync(dev)
         t0 = time.perf_counter()
         if masks is None:
-            vis = prefilter_views(list(cams), bufs["means3D"], bufs["scales"], bufs["rotations"], scaling_modifier)  # [V, P]
-            masks = torch.stack([vis[assign_views(len(cams), r, world, assignment)].any(dim=0) if
-                                 assign_views(len(cams), r, world, assignment) else
-                                 torch.zeros(P, dtype=torch.bool, device=dev) for r in range(world)])
+            masks = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
+                                     [assign_views(len(cams), r, world, assignment) for r in range(world)], scaling_modifier)
         masks = masks.to(dev)
         pairs = masks.nonzero()                     # (rank, id), rank-major, ids ascending: ONE host synchronisation
         counts = torch.bincount(pairs[:, 0], minlength=world).tolist()
@@ -179,14 +177,38 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     return local, my_views, info
 
 
+def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier: float = 1.0, debug=False):
+    """bool [len(groups), P]: row g = "some camera of groups[g] (a list of indices into ``cams``) sees the Gaussian",
+    with prefilter_voxel's test (GR:342-349), in ONE pass over the Gaussians (bsr_visible_filter_groups) -- P bytes per
+    group written, instead of 4 P per view and the radii > 0 / any() passes behind them.  At most 64 groups."""
+    from .rasterizer import _rasterize_gaussians_filter_groups_native
+    dev = means3D.device
+    order = [i for g in groups for i in g]
+    if not order:
+        return torch.zeros((len(groups), means3D.shape[0]), dtype=torch.bool, device=dev)
+    c0 = cams[order[0]]
+    for i in order:
+        c = cams[i]
+        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx or c.FoVy != c0.FoVy:
+            raise ValueError("group_visibility needs cameras of one image size and field of view")
+    vms = torch.stack([cams[i].world_view_transform.to(dev) for i in order]).contiguous()
+    pms = torch.stack([cams[i].full_proj_transform.to(dev) for i in order]).contiguous()
+    gid = torch.tensor([g for g, members in enumerate(groups) for _ in members], dtype=torch.int32)
+    with torch.no_grad():
+        return _rasterize_gaussians_filter_groups_native(
+            means3D, scales[:, :3], rotations, scaling_modifier, torch.Tensor([]), vms, pms,
+            math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5), int(c0.image_height), int(c0.image_width), gid,
+            len(groups), debug)
+
+
 def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0):
-    """{world: [rows rank 0 .. world-1 would receive from scatter_visible_gaussians]} for several node sizes, from ONE
-    run of the visibility filter on this GPU (bench.py's scaling prediction)."""
-    vis = prefilter_views(list(cams), bufs["means3D"], bufs["scales"], bufs["rotations"], scaling_modifier)
+    """{world: [rows rank 0 .. world-1 would receive from scatter_visible_gaussians]} for several node sizes
+    (bench.py's scaling prediction): one pass of the per-group visibility filter per node size."""
     out = {}
     for w in worlds:
-        out[int(w)] = [int(vis[assign_views(len(cams), r, w, assignment)].any(dim=0).sum().item())
-                       if assign_views(len(cams), r, w, assignment) else 0 for r in range(w)]
+        groups = [assign_views(len(cams), r, w, assignment) for r in range(w)]
+        m = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], groups, scaling_modifier)
+        out[int(w)] = [int(x) for x in m.sum(dim=1).tolist()]
     return out
 
 

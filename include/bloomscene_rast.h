@@ -198,6 +198,20 @@ int bsr_visible_filter_views(int P, int n_views,
                              int debug,
                              void* stream);
 
+/* EXTENSION (views.scatter_visible_gaussians): the same per-view test as bsr_visible_filter_views, reduced on the fly to
+ * one mask per GROUP of views: group_mask[g][i] (uint8 [n_groups, P], fully written) = 1 iff some view v with
+ * group_of_view[v] == g has radii > 0 for Gaussian i.  group_of_view: DEVICE int[n_views], values in [0, n_groups),
+ * n_groups <= 64.  With groups = the ranks of a view-parallel sweep this is "which Gaussians does rank g need": P
+ * bytes per rank written instead of 4 P per view, and no radii > 0 / any() passes afterwards. */
+int bsr_visible_filter_groups(int P, int n_views, int n_groups,
+                              int width, int height,
+                              const float* means3D, const float* scales, float scale_modifier,
+                              const float* rotations, const float* cov3D_precomp,
+                              const float* viewmatrices, const float* projmatrices,
+                              float tan_fovx, float tan_fovy,
+                              const int* group_of_view, uint8_t* group_mask,
+                              int debug, void* stream);
+
 /* Backward pass for the forward call that produced (radii, geom/binning/image buffers, R).
  * dL_dpix is [3,H,W]; dL_depths [1,H,W] is accepted and ignored exactly like the reference
  * (backward.cu:457-463,539-554).  All nine gradient outputs are FULLY OVERWRITTEN (no pre-zeroing

@@ -360,3 +360,24 @@ def test_default_mode_is_reproducible_and_independent_of_the_instantiation():
     import test_parity_gpu as TP
     TP.test_view_batched_forward_equals_per_view_calls()
     TP.test_gradients_and_outputs_are_bit_reproducible()
+
+
+def test_group_visibility_equals_any_over_the_per_view_filter():
+    """bsr_visible_filter_groups: mask[g] == (visible_filter over the views of group g > 0).any(), for uneven groups, an
+    empty group, scale/rotation and cov3D inputs."""
+    from bloomscene_amd import views
+    dev = _dev()
+    P, W, H, V = 50001, 320, 180, 11
+    sc = Hh.scene_b(P, W, H, 1, n_views=V, seed=8)
+    cams = [c.to(dev) for c in sc.cameras]
+    means, scales, rots = sc.means3D.to(dev), (sc.scales * 3.0).to(dev), sc.rotations.to(dev)
+    groups = [[0, 1, 2, 3], [4], [], [5, 6, 7, 8, 9, 10]]
+    got = views.group_visibility(cams, means, scales, rots, groups)
+    per_view = views.prefilter_views(cams, means, scales, rots)           # bool [V, P]
+    assert got.shape == (4, P) and got.dtype == torch.bool
+    for g, members in enumerate(groups):
+        want = per_view[members].any(dim=0) if members else torch.zeros(P, dtype=torch.bool, device=dev)
+        assert torch.equal(got[g], want), g
+    assert 0 < int(got[0].sum()) < P and not got[2].any()
+    rows = views.visible_rows_per_rank(dict(means3D=means, scales=scales, rotations=rots), cams, worlds=(1, 2))
+    assert rows[1] == [int(per_view.any(dim=0).sum())] and len(rows[2]) == 2
