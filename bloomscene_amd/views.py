@@ -28,6 +28,55 @@ def shard_views(n_views: int, rank: int, world: int):
     return list(range(rank, n_views, world))
 
 
+class CameraPack:
+    """A camera path with its matrices stacked ON THE DEVICE once: world_view [V,4,4], full_proj [V,4,4], centers
+    [V,3].  The multi-view entry points take a list of MiniCams or a CameraPack; with a list they stack (and upload)
+    the matrices on every call, which for the 16 views of one batched native call is a quarter of a millisecond of
+    interpreter time -- as much as the kernels of a sparse view.  All cameras share image size and field of view
+    (they do in the rotate360 sweep: utils/trajectory.py:110-121)."""
+
+    def __init__(self, cams, device):
+        cams = list(cams)
+        if not cams:
+            raise ValueError("CameraPack needs at least one camera")
+        c0 = cams[0]
+        for c in cams:
+            if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx \
+                    or c.FoVy != c0.FoVy:
+                raise ValueError("a CameraPack needs cameras of one image size and field of view")
+        self.image_width, self.image_height, self.FoVx, self.FoVy = c0.image_width, c0.image_height, c0.FoVx, c0.FoVy
+        self.world_view = torch.stack([c.world_view_transform for c in cams]).to(device).contiguous()
+        self.full_proj = torch.stack([c.full_proj_transform for c in cams]).to(device).contiguous()
+        self.centers = torch.stack([c.camera_center for c in cams]).to(device).contiguous()
+
+    def __len__(self):
+        return self.world_view.shape[0]
+
+    def select(self, idx):
+        """(world_view, full_proj, centers) of the views ``idx``: a slice when they are consecutive, else a gather."""
+        idx = list(idx)
+        if idx and idx == list(range(idx[0], idx[0] + len(idx))):
+            sl = slice(idx[0], idx[0] + len(idx))
+            return self.world_view[sl], self.full_proj[sl], self.centers[sl]
+        t = torch.tensor(idx, dtype=torch.long, device=self.world_view.device)
+        return self.world_view.index_select(0, t), self.full_proj.index_select(0, t), self.centers.index_select(0, t)
+
+
+def _camera_stack(cams, idx, dev):
+    """(world_view [n,4,4], full_proj, centers, camera 0) of the views ``idx`` of a CameraPack or a MiniCam list."""
+    if isinstance(cams, CameraPack):
+        vms, pms, cps = cams.select(idx)
+        return vms, pms, cps, cams
+    sel = [cams[i] for i in idx]
+    c0 = sel[0]
+    for c in sel:
+        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx or c.FoVy != c0.FoVy:
+            raise ValueError("the multi-view entry points need cameras of one image size and field of view")
+    return (torch.stack([c.world_view_transform.to(dev) for c in sel]).contiguous(),
+            torch.stack([c.full_proj_transform.to(dev) for c in sel]).contiguous(),
+            torch.stack([c.camera_center.to(dev) for c in sel]).contiguous(), c0)
+
+
 def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin"):
     """View indices of `rank`.  "round_robin": {i : i mod world == rank} (balances a yaw-dependent load; every rank sees
     the whole sweep, so it needs nearly every Gaussian any view sees).  "contiguous": the rank's block of ceil(n / world)
@@ -146,7 +195,8 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         dev = flat_all.device
         mine = flat_all[offsets[rank]:offsets[rank + 1]]
     else:
-        dev = torch.device(device) if device is not None else cams[0].world_view_transform.device
+        dev = torch.device(device) if device is not None else (
+            cams.world_view.device if isinstance(cams, CameraPack) else cams[0].world_view_transform.device)
         mine = torch.empty((counts[rank], row), dtype=torch.float32, device=dev)
     if multi:
         sync(dev)
@@ -186,13 +236,7 @@ def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier:
     order = [i for g in groups for i in g]
     if not order:
         return torch.zeros((len(groups), means3D.shape[0]), dtype=torch.bool, device=dev)
-    c0 = cams[order[0]]
-    for i in order:
-        c = cams[i]
-        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx or c.FoVy != c0.FoVy:
-            raise ValueError("group_visibility needs cameras of one image size and field of view")
-    vms = torch.stack([cams[i].world_view_transform.to(dev) for i in order]).contiguous()
-    pms = torch.stack([cams[i].full_proj_transform.to(dev) for i in order]).contiguous()
+    vms, pms, _, c0 = _camera_stack(cams, order, dev)
     gid = torch.tensor([g for g, members in enumerate(groups) for _ in members], dtype=torch.int32)
     with torch.no_grad():
         return _rasterize_gaussians_filter_groups_native(
@@ -380,16 +424,10 @@ def prefilter_views(cams, means3D, scales, rotations, scaling_modifier=1.0, debu
     built, once for all V views.  All cameras must share image size and field of view (they do in
     the sweep: utils/trajectory.py:110-121)."""
     from .rasterizer import _rasterize_gaussians_filter_views_native
-    if not cams:
+    if not len(cams):
         return torch.zeros((0, means3D.shape[0]), dtype=torch.bool, device=means3D.device)
-    c0 = cams[0]
-    for c in cams:
-        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx \
-                or c.FoVy != c0.FoVy:
-            raise ValueError("prefilter_views needs cameras of one image size and field of view")
     dev = means3D.device
-    vms = torch.stack([c.world_view_transform.to(dev) for c in cams]).contiguous()
-    pms = torch.stack([c.full_proj_transform.to(dev) for c in cams]).contiguous()
+    vms, pms, _, c0 = _camera_stack(cams, range(len(cams)), dev)
     with torch.no_grad():
         radii = _rasterize_gaussians_filter_views_native(
             means3D, scales[:, :3], rotations, scaling_modifier, torch.Tensor([]), vms, pms,
@@ -397,22 +435,19 @@ def prefilter_views(cams, means3D, scales, rotations, scaling_modifier=1.0, debu
     return radii > 0
 
 
-def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_modifier=1.0, debug=False):
+def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_modifier=1.0, debug=False, idx=None):
     """Inference forward of several cameras in ONE native call (bsr_forward_views): returns
     (frames [V,3,H,W], depths [V,1,H,W], radii [V,P]), view by view bit-identical to ``render_view``.
     The views of a camera sweep see few Gaussians each, so one at a time they are launch/latency bound; batched,
-    binning, per-tile sort and render run once over all of them.  Cameras must share image size and field of view
-    (they do in the rotate360 sweep: utils/trajectory.py:110-121).  No gradients."""
+    binning, per-tile sort and render run once over all of them.  ``cams``: a list of MiniCams or a ``CameraPack``
+    (matrices already stacked on the device); ``idx``: which of them (default: all).  Cameras must share image size
+    and field of view (they do in the rotate360 sweep: utils/trajectory.py:110-121).  No gradients."""
     from .rasterizer import _rasterize_gaussians_views_native
     xyz = gaussians["means3D"]
     dev = xyz.device
-    if not cams:
+    idx = list(range(len(cams))) if idx is None else list(idx)
+    if not idx:
         raise ValueError("render_views_batched needs at least one camera")
-    c0 = cams[0]
-    for c in cams:
-        if (c.image_width, c.image_height) != (c0.image_width, c0.image_height) or c.FoVx != c0.FoVx \
-                or c.FoVy != c0.FoVy:
-            raise ValueError("render_views_batched needs cameras of one image size and field of view")
     if (gaussians.get("shs") is None) == (gaussians.get("colors_precomp") is None):
         raise Exception('Please provide excatly one of either SHs or precomputed colors!')
     e = torch.Tensor([])
@@ -420,9 +455,7 @@ def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_m
     def opt(k):
         v = gaussians.get(k)
         return e if v is None else v
-    vms = torch.stack([c.world_view_transform.to(dev) for c in cams]).contiguous()
-    pms = torch.stack([c.full_proj_transform.to(dev) for c in cams]).contiguous()
-    cps = torch.stack([c.camera_center.to(dev) for c in cams]).contiguous()
+    vms, pms, cps, c0 = _camera_stack(cams, idx, dev)
     with torch.no_grad():
         _, color, depth, radii = _rasterize_gaussians_views_native(
             bg_color, xyz, opt("colors_precomp"), gaussians["opacities"], opt("scales"), opt("rotations"),
@@ -437,7 +470,8 @@ def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, 
     this rank renders its round-robin share of ``cams`` with torch.no_grad() and returns
     {view index: (frame [3,H,W], depth [1,H,W])} (or only the indices when not keeping outputs).
     ``batch`` > 1 renders that many of the rank's views per native call (``render_views_batched``).
-    ``views``: this rank's view indices when they are not the round-robin share (``scatter_visible_gaussians``)."""
+    ``views``: this rank's view indices when they are not the round-robin share (``scatter_visible_gaussians``).
+    ``cams`` may be a ``CameraPack`` when ``batch`` > 1 (no per-call stacking and upload of the matrices)."""
     if rank is None:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     if world is None:
@@ -449,7 +483,7 @@ def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, 
         if batch > 1:
             for b0 in range(0, len(mine), batch):
                 idx = mine[b0:b0 + batch]
-                color, depth, _ = render_views_batched([cams[i].to(dev) for i in idx], gaussians, bg_color, sh_degree)
+                color, depth, _ = render_views_batched(cams, gaussians, bg_color, sh_degree, idx=idx)
                 for k, i in enumerate(idx):
                     out[i] = (color[k], depth[k]) if keep_outputs else None
             return out

@@ -315,9 +315,10 @@ def _scatter_worker(rank, world, port, q):
         names = ("means3D", "scales", "rotations", "opacities", "shs")
         full = {k: getattr(sc, k).to(dev) for k in names}          # every rank holds the full scene here: the control
         bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
-        local, mine, info = views.scatter_visible_gaussians(full if rank == 0 else None, cams, src=0,
+        pack = views.CameraPack(cams, dev)           # matrices stacked on the device once
+        local, mine, info = views.scatter_visible_gaussians(full if rank == 0 else None, pack, src=0,
                                                             assignment="contiguous", device=dev)
-        got = views.render_views_sharded(cams, local, bg, deg, rank=rank, world=world, keep_outputs=True, batch=3,
+        got = views.render_views_sharded(pack, local, bg, deg, rank=rank, world=world, keep_outputs=True, batch=3,
                                          views=mine)
         ok = sorted(got) == mine and info["counts"][rank] == local["means3D"].shape[0] < P
         for i in mine:
