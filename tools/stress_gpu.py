@@ -148,11 +148,57 @@ def stress_views(args, rng):
     print(f"view-batch stress ok: {n} random cases")
 
 
+def stress_neural(args, rng):
+    """views.render_neural fused (one native call each way) against the two autograd nodes: every output and gradient
+    bit-identical, random anchor counts / offsets / image shapes / selection rates, with and without depth gradient and
+    a regulariser on `scaling`."""
+    import math
+    from bloomscene_amd import cameras, views
+    from bloomscene_amd.synthetic import upstream_grads
+    from oracle import anchors as OA
+    dev = torch.device("cuda")
+    t_end = time.time() + args.seconds
+    n = 0
+    while time.time() < t_end:
+        N = int(rng.choice([1, 3, 100, 1000, 7777, 30000]))
+        K = int(rng.choice([1, 2, 5, 10, 13, 40]))
+        if N * K > 400000:
+            continue
+        W, H = int(rng.integers(1, 500)), int(rng.integers(1, 300))
+        cam = cameras.identity_camera(W, H, math.radians(60)).to(dev)
+        inp = list(OA.synthetic_anchor_inputs(N, K, seed=int(rng.integers(0, 1 << 30)), keep_fraction=float(rng.random())))
+        inp[0] = inp[0] * torch.tensor([0.6, 0.35, 0.0]) + torch.tensor([0.0, 0.0, float(rng.uniform(2.0, 8.0))])
+        bg = torch.rand(3, generator=torch.Generator().manual_seed(n)).to(dev)
+        gC, gD = upstream_grads(W, H, seed=n)
+        gC, gD = gC.to(dev), gD.to(dev)
+        dg, reg = bool(rng.random() < 0.4), bool(rng.random() < 0.5)
+        res = []
+        for fused in (True, False):
+            leaves = [t.to(dev).clone().requires_grad_(True) for t in inp]
+            r = views.render_neural(cam, *leaves, bg, depth_gradient=dg, fused=fused)
+            outs, ups = [r["render"], r["depth"]], [gC, gD]
+            if reg and r["scaling"].numel():
+                outs.append(r["scaling"].prod(dim=1).mean() + r["neural_opacity"].abs().mean())
+                ups.append(torch.ones((), device=dev))
+            torch.autograd.backward(outs, ups)
+            vg = r["viewspace_points"].grad
+            res.append((r, [t.grad for t in leaves], vg))
+        (ra, ga, va), (rb, gb, vb) = res
+        for k in ("render", "depth", "radii", "selection_mask", "scaling"):
+            assert torch.equal(ra[k], rb[k]), (k, N, K, W, H)
+        for x, y in zip(ga, gb):
+            assert (x is None) == (y is None) and (x is None or torch.equal(x.view(torch.int32), y.view(torch.int32))), (N, K, W, H, dg, reg)
+        if ra["radii"].numel():
+            assert torch.equal(va.view(torch.int32), vb.view(torch.int32)), (N, K, W, H)
+        n += 1
+    print(f"neural stress ok: {n} random cases (fused == separate, bit for bit)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mode", default="mixed", choices=["mixed", "hint", "big", "anchors", "views"],
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "hint", "big", "anchors", "views", "neural"],
                     help="mixed: everything random; hint: ONE (P, W, H), random content per call (exercises the "
                          "scratch-size guess: short, long, decaying); big: few large cases (0.1-0.5 M Gaussians)")
     args = ap.parse_args()
@@ -162,10 +208,14 @@ def main():
         return stress_anchors(args, rng)
     if args.mode == "views":
         return stress_views(args, rng)
+    if args.mode == "neural":
+        return stress_neural(args, rng)
+    from bloomscene_amd import _capi
     t_end = time.time() + args.seconds
     n = 0
     worst = (0.0, None, None)
     n_cond = 0
+    worst_img, n_img_loose = 0.0, 0
     while time.time() < t_end:
         if args.mode == "hint":
             P, W, H = 6000, 233, 141
@@ -200,11 +250,25 @@ def main():
             kw.pop("squeeze_xy", None)
         c = Hh.make_case(**kw)
         st, g = Hh.run_oracle(c, depth_gradient=dg)
+        # half the cases in the library's default mode (hardware exp outside the decision bands: images within ulps),
+        # half with the pinned exp everywhere (images bit-equal to the oracle)
+        exact = bool(rng.random() < 0.5)
+        _capi.set_option("exact_exp", exact)
         out = Hh.run_hip(c, depth_gradient=dg)
         out2 = Hh.run_hip(c, depth_gradient=dg)
         assert (out.radii == st.radii).all(), kw
-        assert (out.color.view(np.uint32) == st.color.view(np.uint32)).all(), kw
-        assert (out.depth.view(np.uint32) == st.depth.view(np.uint32)).all(), kw
+        if exact:
+            assert (out.color.view(np.uint32) == st.color.view(np.uint32)).all(), kw
+            assert (out.depth.view(np.uint32) == st.depth.view(np.uint32)).all(), kw
+        else:
+            for name, a, b in (("color", out.color, st.color), ("depth", out.depth, st.depth)):
+                e = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))
+                worst_img = max(worst_img, e)
+                # 2e-5 of scale unless a `T (1 - alpha) < 1e-4` stop moved (then one entry of weight < 1e-4 more or less;
+                # a pixel's depth = D / acc moves with it)
+                assert e <= (2e-5 if name == "color" else 5e-2), (name, e, kw)
+                n_img_loose += int(e > 2e-5)
+            assert np.array_equal(out.color, out2.color) and np.array_equal(out.depth, out2.depth), kw
         og = Hh.oracle_grads(c, g)
         for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
             ref, got, got2 = getattr(og, k), getattr(out.grads, k), getattr(out2.grads, k)
@@ -221,7 +285,8 @@ def main():
             assert np.array_equal(got, got2), (k, kw)
         n += 1
     print(f"stress ok: {n} random cases ({n_cond} tensors judged by conditioning), "
-          f"worst gradient error / scale = {worst[0]:.2e} ({worst[1]}, {worst[2]})")
+          f"worst gradient error / scale = {worst[0]:.2e} ({worst[1]}, {worst[2]}); default-mode images: worst error / "
+          f"scale {worst_img:.1e}, {n_img_loose} depth images above 2e-5 (a stop decision moved)")
 
 
 if __name__ == "__main__":
