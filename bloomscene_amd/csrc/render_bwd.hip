@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			r1 = r[1];
 			r2 = r[2];
 			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-			r2.w = r1.y + 2.1e-3f;   // staged q2.w (the mask half is used up): upper end of the decision band, -ln(255 o) + 1.1e-3
+			r2.w = r1.y + 2.2e-3f;   // staged q2.w (the mask half is used up): just above the decision band, -ln(255 o) + 1.2e-3
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
@@ -319,8 +319,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float dy = q0.y - pixfy;
 			const float power = (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic (common.h): the forward's bits
 			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
+			const uint64_t cand_mask = wave_ballot((int)joff > joff_min) & wave_ballot(!(power > 0.0f)) & wave_ballot(!(power < q1.y));
 			STAT_ADD(0, 1);                                  // visits
-			if (wave_ballot(cand) == 0ull) return;   // wave-uniform
+			if (cand_mask == 0ull) return;   // wave-uniform
 			STAT_ADD(1, 1);                                  // ... with a candidate lane
 			STAT_ADD(4, __popcll(wave_ballot(cand)));        // candidate lanes
 
@@ -334,20 +335,26 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// candidate inside that 2e-3 wide band evaluates E to decide; everywhere else the VALUE of exp(power) is
 			// all that is needed, and gradients are compared with a tolerance (the reference's sums are unordered),
 			// so it comes from v_exp_f32: 2 issue slots instead of 13.
-			// A lane is "inside the band" iff it is a candidate and !(power >= hi), hi = power_cut + 2.1e-3 staged in q2.w:
-			// with a NaN hi (opacity <= 0 or NaN, whose NaN power_cut also lets every lane through `cand`) or a NaN power
-			// the lane counts as inside, so those pairs get the alpha < 1/255 test below, which skipped them in the forward
-			// (alpha < 0) -- the fast path would blend them.
+			// The wave votes on `candidate && !(power >= hi)`, hi = power_cut + 2.2e-3 staged in q2.w: a superset of the lanes
+			// the forward's test |power - centre| < 1.1e-3 (centre = power_cut + 1e-3) puts inside the band, assembled on the
+			// scalar side from ballots of SINGLE compares (a ballot of an AND of lane masks makes hipcc materialise the
+			// mask in a VGPR and compare it again, two VALU slots per visit).  With a NaN hi (opacity <= 0 or NaN, whose
+			// NaN power_cut also lets every lane through `cand`) or a NaN power the vote fires, so those pairs get the
+			// alpha < 1/255 test below, which skipped them in the forward (alpha < 0) -- the fast path would blend them.
+			// Inside the rare branch each lane picks its exp with the FORWARD's expression (render_fwd.hip): per lane the
+			// same exp the forward's default mode used on this pair, so alpha is the forward's alpha bit for bit.
 #ifdef BSR_BWD_EXACT_EXP
-			const bool lane_in_band = true, in_band = true;   // attribution build: the pinned exp on every visit
+			const bool in_band = true;   // attribution build: the pinned exp on every visit
 #else
-			const bool lane_in_band = cand && !(power >= q2.w);
-			const bool in_band = wave_ballot(lane_in_band) != 0ull;   // rare: ~1 % of the visits
+			const bool in_band = (wave_ballot(!(power >= q2.w)) & cand_mask) != 0ull;   // rare: ~1 % of the visits
 #endif
-			// per lane the same exp the forward's default mode used on this pair (a lane inside the band: the pinned one,
-			// any other: v_exp_f32 of the same power), so alpha is the forward's alpha bit for bit
 			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
 			if (in_band) {
+#ifdef BSR_BWD_EXACT_EXP
+				const bool lane_in_band = true;
+#else
+				const bool lane_in_band = !(fabsf(power - (q1.y + 1.0e-3f)) >= 1.1e-3f);
+#endif
 				const float Ge = bsr_expf_walk(power);
 				Gx = lane_in_band ? Ge : Gx;
 			}

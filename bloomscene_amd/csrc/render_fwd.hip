@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
-			r2.w = r1.y + 2.1e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): upper end of the decision band, -ln(255 o) + 1.1e-3
+			r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
 		}
 		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 		FSTAT_ADD(6, 1);      // batches (per wave)
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				const char* rec = rec0 + joff;
 				e.q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
 				e.q1 = srec_q1<FB>(rec);      // -c/2, power cut, opacity, depth
-				e.q2 = srec_q2<FB>(rec);      // r, g, b, upper end of the decision band
+				e.q2 = srec_q2<FB>(rec);      // r, g, b, centre of the decision band
 				const float dx = e.q0.x - pixfx;
 				const float dy = e.q0.y - pixfy;
 				e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
@@ -176,16 +176,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 					// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
 					// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
 					// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
-					// Only a candidate below that bound (`hi` = power_cut + 2.1e-3, staged in q2.w) needs E to decide, and only
-					// a trip holding such a lane evaluates E at all (a few % of the trips); every other one takes the VALUE
-					// from v_exp_f32.  Which exp a lane uses depends on ITS power alone -- never on the lanes or entries it
-					// shares a trip with -- so the image is the same whichever instantiation (NS, view batching, scratch
-					// capacity) renders it.  The test is `cand && !(power >= hi)` so that a NaN (hi: opacity <= 0 or NaN,
-					// whose NaN cut also lets every lane through `cand`; power: NaN conic) counts as inside -- those lanes
-					// get the exact path's arithmetic, e.g. alpha < 0 is skipped as in the reference.  The backward takes
-					// the same decision the same way (render_bwd.hip) and so sees the same alpha.
-					const bool b0 = e0.cand && !(e0.power >= e0.q2.w), b1 = e1.cand && !(e1.power >= e1.q2.w);
-					const bool b2 = e2.cand && !(e2.power >= e2.q2.w), b3 = e3.cand && !(e3.power >= e3.q2.w);
+					// Only a lane inside that 2.1e-3 wide band (centre = power_cut + 1e-3, staged in q2.w) needs E to decide, and
+					// only a trip holding such a lane evaluates E at all (a few % of the trips); every other one takes the
+					// VALUE from v_exp_f32.  Which exp a lane uses depends on ITS power alone -- never on the lanes or
+					// entries it shares a trip with -- so the image is the same whichever instantiation (NS, view batching,
+					// scratch capacity) renders it.  The test is `!(|power - centre| >= 1.1e-3)` so that a NaN (centre:
+					// opacity <= 0 or NaN; power: NaN conic) counts as inside -- those lanes get the exact path's arithmetic,
+					// e.g. alpha < 0 is skipped as in the reference.  (One subtraction and ONE compare per entry, voted
+					// directly: a vote on `cand && power < hi` makes hipcc materialise the AND-ed mask in a VGPR and compare
+					// it again -- two more half-rate VALU slots per entry, 8 % of the trip.)  The backward selects the exp
+					// per lane with the same expression (render_bwd.hip) and so sees the same alpha.
+					const bool b0 = !(fabsf(e0.power - e0.q2.w) >= 1.1e-3f), b1 = !(fabsf(e1.power - e1.q2.w) >= 1.1e-3f);
+					const bool b2 = !(fabsf(e2.power - e2.q2.w) >= 1.1e-3f), b3 = !(fabsf(e3.power - e3.q2.w) >= 1.1e-3f);
 					g0 = __builtin_amdgcn_exp2f(e0.power * 1.44269504088896341f);
 					g1 = __builtin_amdgcn_exp2f(e1.power * 1.44269504088896341f);
 					g2 = __builtin_amdgcn_exp2f(e2.power * 1.44269504088896341f);

@@ -28,8 +28,11 @@ FAST_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "shell_v
 def _compare_default_with_exact(c, st, label):
     """Runs the forward in both modes.  Asserted: radii, num_rendered, the per-tile lists are IDENTICAL; n_contrib
     differs on at most a 1e-5 share of the pixels (+2) -- the `T (1 - alpha) < 1e-4` stop sees a T that differs by ulps;
-    colour / depth / final_T of the default mode within 2e-5 of the image's scale of the oracle (1e-4 on pixels whose
-    stop decision moved: one more or one fewer entry of weight < 1e-4)."""
+    colour / depth / final_T of the default mode within 2e-5 of the image's scale of the oracle everywhere else.
+    On a pixel whose stop decision moved, the entry that triggers the stop is blended in one mode and not in the other
+    (forward.cu:433-437: the stopping Gaussian is NOT blended): its weight alpha T is below 1e-4 / (1 - alpha) * alpha,
+    i.e. up to 1e-2 at the 0.99 clamp -- the reference's own 2-ulp expf moves the same pixels against any other exp,
+    and SURVEY.md 8(d) sets aside a 1e-5 share of elements for such predicate flips."""
     from bloomscene_amd import _capi
     assert _capi.get_option("exact_exp") == 0
     rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
@@ -62,7 +65,7 @@ def _compare_default_with_exact(c, st, label):
         worst[name] = float(err[~m].max()) if (~m).any() else 0.0
         assert worst[name] <= 2e-5, (label, name, worst[name])
         if m.any():
-            assert float(err[m].max()) <= (5e-2 if name == "depth" else 2e-4), (label, name, float(err[m].max()))
+            assert float(err[m].max()) <= (5e-2 if name == "depth" else 1.1e-2), (label, name, float(err[m].max()))
     print(f"[fast-exp] {label:24s} stop decisions moved on {n_flip} of {flips.size} pixels; max err / scale: "
           + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     return n_flip
@@ -74,6 +77,30 @@ def test_default_forward_against_oracle_and_exact_mode(name):
     c = Hh.make_case(**CASES[name])
     st, _ = Hh.run_oracle(c, backward=False)
     _compare_default_with_exact(c, st, name)
+
+
+# the two cases of round 3's soak (4.6 k default-mode cases) whose colour left the 2e-5 band: a pixel whose
+# `T (1 - alpha) < 1e-4` stop lands on the other side with a T that differs by ulps
+STOP_MOVED = {
+    "soak_big_250k_cov_precomp": dict(P=250000, W=1850, H=645, deg=1, seed=201190006, scale_mul=2.186471765599889,
+                                      cov_mode="precomp"),
+    "soak_hint_6k_near_plane": dict(P=6000, W=233, H=141, deg=3, seed=96867431, scale_mul=19.390615306525284,
+                                    near_fraction=0.6, scale_modifier=1.9, cov_mode="precomp"),
+}
+
+
+@pytest.mark.fast_exp
+@pytest.mark.parametrize("name", list(STOP_MOVED))
+def test_default_forward_where_a_stop_decision_moves(name):
+    """The default mode's T differs from the exact mode's by ulps, so the reference's early stop (forward.cu:433-437)
+    can fall one entry earlier or later on a pixel whose T (1 - alpha) sits within those ulps of 1e-4: the stopping
+    entry is blended or not.  Here it does (found by the soak: 2 of 4.6 k default-mode cases, one pixel each); the
+    pixel count and the size of the change are bounded (_compare_default_with_exact), everything else stays inside
+    2e-5 of scale."""
+    c = Hh.make_case(**STOP_MOVED[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    n_flip = _compare_default_with_exact(c, st, name)
+    assert n_flip >= 1
 
 
 @pytest.mark.fast_exp
@@ -382,3 +409,55 @@ def test_group_visibility_equals_any_over_the_per_view_filter():
     assert 0 < int(got[0].sum()) < P and not got[2].any()
     rows = views.visible_rows_per_rank(dict(means3D=means, scales=scales, rotations=rots), cams, worlds=(1, 2))
     assert rows[1] == [int(per_view.any(dim=0).sum())] and len(rows[2]) == 2
+
+
+# ------------------------------------------------------------------ the soak's worst seeds, as named cases
+SOAK_SEEDS = {
+    # rounds 1-2 of tools/stress_gpu.py: the cases whose gradients missed 1e-5 of scale and were judged by conditioning
+    "one_gaussian_depth_gradient": dict(P=1, W=218, H=9, deg=0, seed=807008285, scale_mul=7.509433833011944, scene="a",
+                                        free_camera=True, scale_modifier=0.7, color_mode="precomp", M_extra=1,
+                                        depth_gradient=True),
+    "seven_gaussians_near_plane": dict(P=7, W=289, H=272, deg=3, seed=118639763, scale_mul=18.74694816713805,
+                                       near_fraction=0.6, scene="b", free_camera=True, scale_modifier=1.9, view=0,
+                                       cov_mode="precomp", M_extra=4),
+    "narrow_image_40k": dict(P=40000, W=72, H=205, deg=2, seed=842006941, scale_mul=6.492932378324813, near_fraction=0.1,
+                             scene="a", scale_modifier=1.9, color_mode="precomp"),
+    "one_small_gaussian": dict(P=1, W=226, H=175, deg=1, seed=347919734, scale_mul=0.33112824823942305, scene="a",
+                               free_camera=True, scale_modifier=1.9),
+    "big_100k_depth_gradient": dict(P=100000, W=1134, H=786, deg=0, seed=974144424, scale_mul=3.5622006417370153,
+                                    scene="a", scale_modifier=1.9, depth_gradient=True),
+    "shell_squeezed_depth_gradient": dict(P=6000, W=233, H=141, deg=1, seed=792644185, scale_mul=6.936273668730756,
+                                          scene="b", scale_modifier=0.7, view=57, squeeze_xy=0.1, depth_gradient=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SOAK_SEEDS))
+def test_ill_conditioned_soak_seeds(name):
+    """The random soak (tools/stress_gpu.py) lets a gradient tensor that misses 1e-5 of its scale pass when the miss is
+    explained by CONDITIONING: within 8x the change that a 64 eps sum|terms| perturbation of the nine pixel sums
+    produces in the oracle's own per-Gaussian chain (single splats whose opacity gradient is a 1 % residue of
+    cancelling terms, splats at the near plane).  Those seeds, pinned: forward bit-exact, every gradient either within
+    1e-5 of scale or within that bound -- and the bound must not be vacuous (< 1e-2 of scale)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from stress_gpu import chain_sensitivity
+    kw = dict(SOAK_SEEDS[name])
+    dg = kw.pop("depth_gradient", False)
+    c = Hh.make_case(**kw)
+    st, g = Hh.run_oracle(c, depth_gradient=dg)
+    out = Hh.run_hip(c, depth_gradient=dg)
+    np.testing.assert_array_equal(out.radii, st.radii)
+    np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
+    og = Hh.oracle_grads(c, g)
+    sens = None
+    for k in Hh.GRAD_KEYS:
+        ref, got = getattr(og, k), getattr(out.grads, k)
+        if ref is None:
+            continue
+        assert np.isfinite(got).all(), k
+        e = Hh.max_err_over_scale(got, ref)
+        if e >= 1e-5:
+            sens = sens or chain_sensitivity(st, c, dg)
+            assert sens[k] < 1e-2, (k, sens[k])
+            assert e <= 1e-5 + 8.0 * sens[k], (k, e, sens[k])
+            print(f"[soak-seed] {name}: dL_d{k} {e:.2e} of scale, conditioning bound {8 * sens[k]:.2e}")

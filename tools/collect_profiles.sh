@@ -9,14 +9,20 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 python -m pytest tests -m gpu -q -s > "$OUT/pytest_gpu.log" 2>&1; tail -1 "$OUT/pytest_gpu.log"
-python bench.py 2> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3.json"
+python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3_driver_form.json"   # what the driver runs
+python bench.py 2>> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3.json"
+python bench.py --exact-exp --steps 40 --warmup 10 --no-cpu-baseline --no-c4 --no-secondary 2>/dev/null | tail -1 > "$OUT/bench_c3_exact_exp.json"
 python bench.py --config c2 --steps 100 --warmup 10 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c2.json"
 python bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c5.json"
 python bench.py --colors precomp --steps 50 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_precomp_colors.json"
 python bench.py --depth-gradient --steps 50 --warmup 5 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$OUT/bench_c3_depth_gradient.json"
 python tools/bench_anchors.py 2>/dev/null | tail -1 > "$OUT/bench_anchors.json"
 python tools/sweep_c5.py 2>/dev/null > "$OUT/sweep_c5.jsonl"
-python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp > "$OUT/parity_report.jsonl" 2>/dev/null
+python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp lists > "$OUT/parity_report.jsonl" 2>/dev/null
+# the BloomScene-shaped step: kernel trace -> idle intervals (tools/trace_gaps.py)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_bloomscene_shape" -- python3 "$ROOT/tools/profile_bloomscene_shape.py" --steps 200 > "$OUT/bloomscene_shape_under_rocprof.log" 2>&1 )
+python tools/trace_gaps.py "$OUT/kt_bloomscene_shape" > "$OUT/bloomscene_shape_gaps.txt" 2>&1
+python tools/profile_bloomscene_shape.py --steps 200 2>/dev/null | tail -1 > "$OUT/bench_bloomscene_shape.json"
 if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so 2>/dev/null | tail -1 > "$OUT/walk_stats_c3.json"
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"

@@ -9,7 +9,7 @@ mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-c4 --no-secondary "${BENCH_ARGS[@]}" > "$ROOT/$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-c4 --no-secondary "${BENCH_ARGS[@]}" > "$ROOT/$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
 BENCH_ARGS=("$@")
