@@ -1,13 +1,17 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  bash tools/collect_profiles.sh <tag>
+# Run on the GPU box from the repo root:  bash tools/collect_profiles.sh <tag> [a|b|all]
+#   part a: test log, bench lines, parity report, BloomScene-shaped trace;  part b: kernel stats, PMC passes, walk statistics
+#   (two gpurun calls: together they exceed one call's 20-minute limit)
 # Produces gpurun_out/<tag>/: bench JSON lines, rocprofv3 kernel stats, PMC passes (C3 and C5), walk statistics,
 # parity report, test log.  Copy what is to be judged into profiles/<tag>/.
 set -u
 TAG=${1:-prof}
+PART=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+if [ "$PART" != "b" ]; then
 python -m pytest tests -m gpu -q -s > "$OUT/pytest_gpu.log" 2>&1; tail -1 "$OUT/pytest_gpu.log"
 python bench.py --gpus 1 --steps 20 --warmup 5 2> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3_driver_form.json"   # what the driver runs
 python bench.py 2>> "$OUT/bench_c3.err" | tail -1 > "$OUT/bench_c3.json"
@@ -23,6 +27,8 @@ python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp lists > "$OU
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_bloomscene_shape" -- python3 "$ROOT/tools/profile_bloomscene_shape.py" --steps 200 > "$OUT/bloomscene_shape_under_rocprof.log" 2>&1 )
 python tools/trace_gaps.py "$OUT/kt_bloomscene_shape" > "$OUT/bloomscene_shape_gaps.txt" 2>&1
 python tools/profile_bloomscene_shape.py --steps 200 2>/dev/null | tail -1 > "$OUT/bench_bloomscene_shape.json"
+fi
+if [ "$PART" != "a" ]; then
 if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so 2>/dev/null | tail -1 > "$OUT/walk_stats_c3.json"
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"
@@ -38,4 +44,5 @@ python tools/pmc_summary.py "$OUT/pmc_c5" > "$OUT/pmc_summary_c5.json"
 for d in kernel_trace kernel_trace_c5; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${d/kernel_trace/kernel_stats}.csv"; done
 # keep the merged-back payload small: the raw per-dispatch CSVs stay on the box
 find "$OUT" -name "*counter_collection.csv" -delete; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*agent_info.csv" -delete
-cut -c1-300 "$OUT/bench_c3.json"
+fi
+cut -c1-300 "$OUT/bench_c3_driver_form.json" 2>/dev/null
