@@ -230,7 +230,8 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
     gc.enable()
     device_allocs = torch.cuda.memory_stats(D.dev).get("num_device_alloc", 0) - allocs0
     host_step_ms = [1e3 * (b - a) for a, b in zip([t0] + host_marks[:-1], host_marks)]
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    per_step = sorted(in_order)
     prof_timed = _capi.profile_read()
     _capi.profile_enable(False)
     _capi.profile_only(None)
@@ -248,6 +249,7 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
         if dominant in prof_timed:
             prof[dominant] = prof_timed[dominant]   # the dominant stage: as measured inside the timed region
     return {"seconds": D.max_over_ranks(dt), "median_ms": per_step[len(per_step) // 2], "prof": prof,
+            "step_ms": [round(x, 4) for x in in_order] if steps <= 64 else None,
             "device_allocs": int(device_allocs), "max_host_ms": max(host_step_ms), "prewarm_steps": prewarm_steps,
             "timed_region_events": {"stage": dominant, "every_nth_step": sample_every,
                                     "launches": prof_timed.get(dominant, (0.0, 0))[1] if dominant else None}}
@@ -335,6 +337,7 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
            "prof": tm["prof"], "R": R, "visible": visible, "step_bytes": sb, "bcast_ms": bcast_ms, "M": M, "deg": deg,
            "device_allocs": tm["device_allocs"], "max_host_ms": tm["max_host_ms"],
            "timed_region_events": tm["timed_region_events"], "prewarm_steps": tm["prewarm_steps"],
+           "step_ms": tm["step_ms"],
            "allreduce_ms_per_step": state.get("allreduce_ms", 0.0) / max(steps + warmup, 1),
            "workload": f"{label}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
                        f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
@@ -613,6 +616,8 @@ def main():
                        "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256(),
                        "exact_exp": int(_capi.get_option("exact_exp"))},
             "ms_per_step_median": round(r["ms_per_step_median"], 4),
+            # every timed step on the GPU's clock (event to event), in order, when there are few enough to list
+            "step_ms": r["step_ms"],
             "roofline": roofline,
             "roofline_step": {"algorithmic_bytes": r["step_bytes"], "achieved": round(whole, 2),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},

@@ -437,7 +437,7 @@ def test_ill_conditioned_soak_seeds(name):
     explained by CONDITIONING: within 8x the change that a 64 eps sum|terms| perturbation of the nine pixel sums
     produces in the oracle's own per-Gaussian chain (single splats whose opacity gradient is a 1 % residue of
     cancelling terms, splats at the near plane).  Those seeds, pinned: forward bit-exact, every gradient either within
-    1e-5 of scale or within that bound -- and the bound must not be vacuous (< 1e-2 of scale)."""
+    1e-5 of scale or within that bound and, whatever the bound says, within 1e-3 of scale (observed: <= 2.4e-4)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from stress_gpu import chain_sensitivity
@@ -458,6 +458,6 @@ def test_ill_conditioned_soak_seeds(name):
         e = Hh.max_err_over_scale(got, ref)
         if e >= 1e-5:
             sens = sens or chain_sensitivity(st, c, dg)
-            assert sens[k] < 1e-2, (k, sens[k])
             assert e <= 1e-5 + 8.0 * sens[k], (k, e, sens[k])
+            assert e < 1e-3, (k, e)   # (the conditioning bound alone can be vacuous: these chains amplify by 1e3 and more)
             print(f"[soak-seed] {name}: dL_d{k} {e:.2e} of scale, conditioning bound {8 * sens[k]:.2e}")
