@@ -183,6 +183,10 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
     step made the sampled steps 0.26 ms (20 %) longer -- 5 % off the very throughput being measured.  The stage table
     comes from a short untimed pass after the timed region, every stage of every step bracketed."""
     from bloomscene_amd import _capi
+    # the collector runs BEFORE the clock ramp, not between it and the timed region: a full collection is tens of
+    # milliseconds of idle GPU, after which the first ten timed steps ran up to 30 % slow (1.68 -> 1.25 ms at C3)
+    gc.collect()
+    gc.disable()   # no collector pauses inside the timed region (the steps create no reference cycles)
     prewarm_steps = 0
     if prewarm_ms > 0:
         # clock ramp: the same number of untimed steps on every rank (a step may hold a collective), sized from four
@@ -211,14 +215,12 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
         _capi.profile_enable(1)
     for _ in range(warmup):
         step()
-    D.fence()
-    gc.collect()
-    gc.disable()   # no collector pauses inside the timed region (the steps create no reference cycles)
     _capi.profile_enable(sample_every if events_on else 0)
-    _capi.profile_reset()
-    allocs0 = torch.cuda.memory_stats(D.dev).get("num_device_alloc", 0)
+    _capi.profile_reset()   # (waits for the warm-up steps' events)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     host_marks = []
+    allocs0 = torch.cuda.memory_stats(D.dev).get("num_device_alloc", 0)
+    D.fence()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
