@@ -29,8 +29,8 @@ def main():
             pass
         rec = {"point": name, "bwd_batch": batch, "ms_per_step": b["ms_per_step"], "Msplats_per_s": b["value"],
                "stage_ms": {k: b["stage_ms"][k] for k in ("render_fwd", "render_bwd")}}
-        for key, kern in (("render_fwd", "bsr::k_render_fwd"), ("render_bwd", "bsr::k_render_bwd<false>")):
-            r = pmc.get(kern)
+        for key, kern in (("render_fwd", "bsr::k_render_fwd<"), ("render_bwd", "bsr::k_render_bwd<false>")):
+            r = next((v for k, v in pmc.items() if k.startswith(kern)), None)   # (template arguments follow the name)
             if not r:
                 continue
             us = r.get("dur_us(profiled)", 0.0)
