@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, cons
 		cov3d_from_scale_rot(sc, scale_modifier, q, cov3D);
 	}
 	for (int v = 0; v < V; v++) {
+		// (group mode without per-view radii: a group some earlier view already marked needs no further test)
+		if (radii == nullptr && group_mask != nullptr && ((seen >> group_of_view[v]) & 1ull)) continue;
 		const float* vm = viewmatrices + 16 * v;
 		const float* pm = projmatrices + 16 * v;
 		int radius_out = 0;

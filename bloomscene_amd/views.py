@@ -171,8 +171,9 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
             masks = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
                                      [assign_views(len(cams), r, world, assignment) for r in range(world)], scaling_modifier)
         masks = masks.to(dev)
-        pairs = masks.nonzero()                     # (rank, id), rank-major, ids ascending: ONE host synchronisation
-        counts = torch.bincount(pairs[:, 0], minlength=world).tolist()
+        counts = masks.sum(dim=1).tolist()          # the ONE host synchronisation of the distribution
+        # (rank, id) pairs, rank-major, ids ascending; the size is known, so no second read-back inside nonzero
+        pairs = torch.nonzero_static(masks, size=int(sum(counts)))
         sync(dev)
         t1 = time.perf_counter()
         idx_all = pairs[:, 1].contiguous()
