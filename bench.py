@@ -107,6 +107,11 @@ def self_launch(gpus):
     JSON line on the inherited stdout."""
     import socket
     import subprocess
+    # (counting devices does not initialise the GPU on this image; everything that does happens in the children)
+    have = torch.cuda.device_count()
+    if have < gpus and os.environ.get("BSR_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {gpus}: this box shows {have} GPU(s) -- one rank per GPU is needed "
+                         f"(the multi-rank control flow on ONE GPU: BSR_BENCH_SINGLE_DEVICE=1 BSR_BENCH_BACKEND=gloo)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

@@ -282,3 +282,45 @@ def test_render_views_batched_argument_checks_need_no_gpu():
         render_views_batched([a], both, bg, 0)
     with pytest.raises(RuntimeError, match="GPU tensor"):   # CPU tensors: there is no CPU path
         render_views_batched([a], g, bg, 0)
+
+
+def test_camera_pack_and_multi_view_helpers_on_cpu():
+    """views.CameraPack stacks a path's matrices once; select() slices consecutive views and gathers others; the
+    fused-front-end and option entry points fail loudly without a GPU (no CPU path)."""
+    from bloomscene_amd import _capi, views
+    from bloomscene_amd.cameras import rotate360_cameras
+    cams = rotate360_cameras(12, 64, 48, 1.0)
+    pack = views.CameraPack(cams, "cpu")
+    assert len(pack) == 12 and pack.world_view.shape == (12, 4, 4) and pack.centers.shape == (12, 3)
+    vms, pms, cps = pack.select([3, 4, 5])
+    assert torch.equal(vms, torch.stack([cams[i].world_view_transform for i in (3, 4, 5)]))
+    vms, pms, cps = pack.select([7, 2])
+    assert torch.equal(pms, torch.stack([cams[i].full_proj_transform for i in (7, 2)]))
+    with pytest.raises(ValueError, match="one image size"):
+        views.CameraPack([cams[0], views.yawed_camera(80, 48, 1.0, 0.0)], "cpu")
+    with pytest.raises(RuntimeError, match="GPU"):
+        views.group_visibility(pack, torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4), [[0, 1], [2]])
+    from bloomscene_amd.neural_gaussians import render_anchors
+    with pytest.raises(RuntimeError, match="GPU"):
+        render_anchors(torch.zeros(2, 3), torch.ones(2, 6), torch.zeros(2, 5, 3), torch.ones(10, 1), torch.zeros(10, 3),
+                       torch.zeros(10, 7), _settings())
+    # process-wide options: known names round-trip, unknown ones are an error with a message
+    assert _capi.get_option("exact_exp") == 0
+    _capi.set_option("exact_exp", 1)
+    assert _capi.get_option("exact_exp") == 1
+    _capi.set_option("exact_exp", 0)
+    assert _capi.get_option("no_such_option") == -1
+    with pytest.raises(RuntimeError, match="unknown option"):
+        _capi.set_option("no_such_option", 1)
+
+
+def test_bench_refuses_more_ranks_than_gpus_with_a_message():
+    """`python bench.py --gpus N` starts its own ranks; where the box shows fewer GPUs than ranks it says so (rc != 0)
+    instead of failing inside a child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "BSR_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "GPU(s)" in (r.stderr + r.stdout)
