@@ -12,8 +12,9 @@
  * allocates no device memory and touches no allocator or memory-pool setting.  (The one exception is 4 bytes of
  * stream-ordered memory for the error flag of a prefiltered = 1 call to bsr_visible_filter.)  The backward's 48
  * bytes per instance of partial sums live in the binning buffer the forward sized, over sections that are dead by
- * then.  The library keeps no results between calls (per host thread: a pinned 16-byte HOST landing buffer, an
- * event and the previous call's shape / num_rendered as a size hint; plus the opt-in stage profiler); the three
+ * then.  The library keeps no results between calls (per host thread: a pinned 32-byte HOST landing buffer, an
+ * event and the previous call's shape / num_rendered -- and, for the fused anchor front end, its selection count -- as
+ * size hints; process-wide: the two switches of bsr_set_option and the opt-in stage profiler); the three
  * scratch buffers handed from forward to backward are opaque, as in the reference
  * (__init__.py:97,106).
  *
