@@ -79,13 +79,18 @@ def test_default_forward_against_oracle_and_exact_mode(name):
     _compare_default_with_exact(c, st, name)
 
 
-# the two cases of round 3's soak (4.6 k default-mode cases) whose colour left the 2e-5 band: a pixel whose
+# cases of round 3's soaks (7 of ~5 200 default-mode cases) whose colour or depth left the 2e-5 band: a pixel whose
 # `T (1 - alpha) < 1e-4` stop lands on the other side with a T that differs by ulps
 STOP_MOVED = {
     "soak_big_250k_cov_precomp": dict(P=250000, W=1850, H=645, deg=1, seed=201190006, scale_mul=2.186471765599889,
                                       cov_mode="precomp"),
     "soak_hint_6k_near_plane": dict(P=6000, W=233, H=141, deg=3, seed=96867431, scale_mul=19.390615306525284,
                                     near_fraction=0.6, scale_modifier=1.9, cov_mode="precomp"),
+    # second soak of the round (5 more in ~2 900 default-mode cases)
+    "soak_mixed_2k_large_splats": dict(P=2000, W=394, H=119, deg=3, seed=613639856, scale_mul=11.726571156016597,
+                                       scale_modifier=1.9),
+    "soak_mixed_40k": dict(P=40000, W=240, H=190, deg=2, seed=951567977, scale_mul=6.782460180023914, near_fraction=0.1,
+                           scale_modifier=1.9),
 }
 
 
@@ -94,7 +99,7 @@ STOP_MOVED = {
 def test_default_forward_where_a_stop_decision_moves(name):
     """The default mode's T differs from the exact mode's by ulps, so the reference's early stop (forward.cu:433-437)
     can fall one entry earlier or later on a pixel whose T (1 - alpha) sits within those ulps of 1e-4: the stopping
-    entry is blended or not.  Here it does (found by the soak: 2 of 4.6 k default-mode cases, one pixel each); the
+    entry is blended or not.  Here it does (found by the soaks: 7 of ~5 200 default-mode cases, one to four pixels each); the
     pixel count and the size of the change are bounded (_compare_default_with_exact), everything else stays inside
     2e-5 of scale."""
     c = Hh.make_case(**STOP_MOVED[name])
