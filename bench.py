@@ -516,9 +516,14 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
             tw = prep_ms + comm + math.ceil(n_views / w) * per_view_ms
             tb = (0.0 if w == 1 else P * row_bytes / (LINK_GBS * 1e6)) + math.ceil(n_views / w) * per_view_bcast_ms
             t1 = tw if t1 is None else t1
+            t_render = math.ceil(n_views / w) * per_view_ms
             pred[str(w)] = {"rows_max": max(rr), "transfer_ms": round(comm, 3), "sweep_ms_scatter": round(tw, 3),
                             "speedup_scatter": round(t1 / tw, 2), "sweep_ms_broadcast": round(tb, 3),
-                            "Msplats_per_s_scatter": round(n_views * P / (tw * 1e-3) / 1e6, 1)}
+                            "Msplats_per_s_scatter": round(n_views * P / (tw * 1e-3) / 1e6, 1),
+                            # the sweep alone, Gaussians already distributed (a second camera path over the same scene):
+                            # ceil(views / N) views per rank, no exchange at all
+                            "sweep_ms_resident": round(t_render, 3),
+                            "speedup_resident": round(n_views * per_view_ms / t_render, 2)}
         out["predicted"] = pred
     del bufs, local
     torch.cuda.empty_cache()
