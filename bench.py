@@ -450,10 +450,10 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     alg_bytes = n_views * ((187 + 12 * M) * P + 24 * W * H) + 48 * R_all
     out["num_rendered_all_views"] = int(R_all)
     out["algorithmic_bytes_all_views"] = int(alg_bytes)
-    for batch in (1, 16):
+    for batch, compact in ((1, False), (16, False), (16, True)):
         def sweep():
             return views.render_views_sharded(cams if batch == 1 else pack, bufs, bg, deg, rank=D.rank, world=D.world,
-                                              batch=batch)
+                                              batch=batch, compact=compact)
         sweep()   # warm-up (allocator, first touch, size hints)
         times = []
         for _ in range(repeats):
@@ -463,7 +463,9 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
             D.fence()
             times.append(D.max_over_ranks(time.perf_counter() - t0))
         t = sorted(times)[len(times) // 2]
-        out[f"views_per_call_{batch}"] = {
+        # "_compacted": every 16-view batch rendered from the rows its own visibility filter kept (the reference's
+        # prefilter_voxel step, for the whole path in one pass); the filter and the gather are INSIDE the timed sweep
+        out[f"views_per_call_{batch}" + ("_compacted" if compact else "")] = {
             "sweep_ms": round(t * 1e3, 3), "ms_per_view_per_rank": round(t / max(len(mine), 1) * 1e3, 4),
             "value": round(n_views * P / t / 1e6, 1),
             "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1),

@@ -46,7 +46,11 @@ SIGNATURES = {
     "bsr_visible_filter_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                            C.c_float, C.c_float, _F, C.c_int, C.c_void_p]),
     "bsr_visible_filter_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
-                                            C.c_float, C.c_float, _F, _F, C.c_int, C.c_void_p]),
+                                            C.c_float, C.c_float, _F, _F, _F, C.c_int, C.c_void_p]),
+    "bsr_pack_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _F, C.c_int, _F, C.c_int,
+                                C.c_void_p]),
+    "bsr_gather_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _F, C.c_int,
+                                  C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "bsr_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
                                _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
                                _F, _F, _F, _F, C.c_int, C.c_void_p]),

@@ -151,7 +151,10 @@ void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* 
 void launch_visible_filter_views(int P, int V, const float* means3D, const float* scales, float scale_modifier,
                                  const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
                                  const float* projmatrices, int W, int H, float tan_fovx, float tan_fovy, int* radii,
-                                 const int* group_of_view, int n_groups, uint8_t* group_mask, hipStream_t s);
+                                 const int* group_of_view, int n_groups, uint8_t* group_mask, uint32_t* wg_counts,
+                                 uint32_t* group_counts, hipStream_t s);
+void launch_pack_rows(int R, int P, int n_src, const float* const* src, const int* widths, const int64_t* idx,
+                      int idx_stride, float* dst_packed, float* const* dst_each, hipStream_t s);
 void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
@@ -631,7 +634,8 @@ int bsr_visible_filter_views(int P, int n_views, int width, int height, const fl
 	{
 		StageTimer t("visible_filter_views", s);
 		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
-		                            projmatrices, width, height, tan_fovx, tan_fovy, radii, nullptr, 0, nullptr, s);
+		                            projmatrices, width, height, tan_fovx, tan_fovy, radii, nullptr, 0, nullptr,
+		                            nullptr, nullptr, s);
 	}
 	STAGE_CHECK("visible_filter_views", debug, s);
 	return 0;
@@ -640,23 +644,68 @@ int bsr_visible_filter_views(int P, int n_views, int width, int height, const fl
 int bsr_visible_filter_groups(int P, int n_views, int n_groups, int width, int height, const float* means3D,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrices, const float* projmatrices,
-                              float tan_fovx, float tan_fovy, const int* group_of_view, uint8_t* group_mask, int debug,
-                              void* stream)
+                              float tan_fovx, float tan_fovy, const int* group_of_view, uint8_t* group_mask,
+                              uint32_t* group_counts, int debug, void* stream)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (n_views < 0 || n_groups < 0 || n_groups > 64) return fail("bsr_visible_filter_groups: need 0 <= n_groups <= 64");
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrices, projmatrices)) return 1;
-	if (P == 0 || n_groups == 0) return 0;
+	if (P == 0 || n_groups == 0) {
+		if (group_counts && n_groups > 0) HIP_TRY(hipMemsetAsync(group_counts, 0, sizeof(uint32_t) * (size_t)n_groups, s));
+		return 0;
+	}
 	if (!group_mask || (n_views > 0 && !group_of_view)) return fail("bsr_visible_filter_groups: NULL buffer");
 	{
 		StageTimer t("visible_filter_groups", s);
+		uint32_t* wg_counts = nullptr;   // per-workgroup partial counts, stream-ordered scratch
+		if (group_counts) HIP_TRY(hipMallocAsync((void**)&wg_counts, sizeof(uint32_t) * (size_t)n_groups * ((P + 255) / 256), s));
 		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
 		                            projmatrices, width, height, tan_fovx, tan_fovy, nullptr, group_of_view, n_groups,
-		                            group_mask, s);
+		                            group_mask, wg_counts, group_counts, s);
+		if (wg_counts) HIP_TRY(hipFreeAsync(wg_counts, s));
 	}
 	STAGE_CHECK("visible_filter_groups", debug, s);
 	return 0;
+}
+
+static int gather_impl(const char* who, int R, int P, int n_src, const float* const* src, const int* widths,
+                       const int64_t* idx, int idx_stride, float* dst_packed, float* const* dst_each, int debug,
+                       void* stream)
+{
+	g_err[0] = 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (R < 0 || P < 0 || n_src < 1 || n_src > BSR_PACK_MAX_SRC) return fail("%s: need R >= 0, P >= 0 and 1 <= n_src <= 8", who);
+	if (!src || !widths) return fail("%s: NULL table", who);
+	int row = 0;
+	for (int k = 0; k < n_src; k++) {
+		if (widths[k] < 1 || !src[k]) return fail("%s: every source needs a pointer and a width >= 1", who);
+		row += widths[k];
+	}
+	if (row > 4096) return fail("%s: more than 4096 floats per row", who);
+	if (R == 0) return 0;
+	if (!idx || idx_stride < 1 || (!dst_packed && !dst_each)) return fail("%s: NULL buffer", who);
+	if (!dst_packed)
+		for (int k = 0; k < n_src; k++)
+			if (!dst_each[k]) return fail("%s: NULL destination", who);
+	{
+		StageTimer t(who, s);
+		launch_pack_rows(R, P, n_src, src, widths, idx, idx_stride, dst_packed, dst_each, s);
+	}
+	STAGE_CHECK(who, debug, s);
+	return 0;
+}
+
+int bsr_pack_rows(int R, int P, int n_src, const float* const* src, const int* widths, const int64_t* idx, int idx_stride,
+                  float* dst, int debug, void* stream)
+{
+	return gather_impl("pack_rows", R, P, n_src, src, widths, idx, idx_stride, dst, nullptr, debug, stream);
+}
+
+int bsr_gather_rows(int R, int P, int n_src, const float* const* src, const int* widths, const int64_t* idx,
+                    int idx_stride, float* const* dst, int debug, void* stream)
+{
+	return gather_impl("gather_rows", R, P, n_src, src, widths, idx, idx_stride, nullptr, dst, debug, stream);
 }
 
 int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer, void* binning_user,

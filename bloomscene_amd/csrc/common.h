@@ -8,6 +8,7 @@
 #define BSR_TILE 16          // reference cuda_rasterizer/config.h:15-16
 #define BSR_BLOCK 256        // one 16x16 tile per workgroup = 4 wave64
 #define BSR_NEAR 0.2f        // reference cuda_rasterizer/auxiliary.h:154
+#define BSR_PACK_MAX_SRC 8    // tensors bsr_pack_rows lays side by side
 
 namespace bsr {
 

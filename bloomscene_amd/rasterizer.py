@@ -307,9 +307,10 @@ def _rasterize_gaussians_filter_views_native(means3D, scales, rotations, scale_m
 
 def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
                                               projmatrices, tan_fovx, tan_fovy, image_height, image_width,
-                                              group_of_view, n_groups, debug):
+                                              group_of_view, n_groups, debug, return_counts=False):
     """Per-group visibility (bsr_visible_filter_groups): -> bool [n_groups, P], row g = "some view of group g has
-    radii > 0"; ``group_of_view`` int32 [V] on the device."""
+    radii > 0"; ``group_of_view`` int32 [V] on the device.  ``return_counts``: also the ones per row, int32 [n_groups]
+    on the device (accumulated by the kernel)."""
     _check_means3D(means3D)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
@@ -321,6 +322,7 @@ def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_
     if group_of_view.numel() != V:
         raise RuntimeError("group_of_view must hold one group id per view")
     mask = torch.empty((int(n_groups), P), dtype=torch.bool, device=dev)
+    counts = torch.zeros((int(n_groups),), dtype=torch.int32, device=dev) if return_counts else None
     if P != 0 and n_groups != 0:
         m = _dev_f32(means3D, "means3D", dev)
         s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)
@@ -331,9 +333,56 @@ def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_
             rc = _capi.lib().bsr_visible_filter_groups(
                 P, V, int(n_groups), int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier),
                 _ptr(r), _ptr(c), _ptr(v), _ptr(p), float(tan_fovx), float(tan_fovy), gv.data_ptr() if V else None,
-                mask.data_ptr(), int(bool(debug)), _stream_handle(dev))
+                mask.data_ptr(), counts.data_ptr() if return_counts else None, int(bool(debug)), _stream_handle(dev))
         _capi.check(rc, "rasterize_gaussians_filter_groups")
-    return mask
+    return (mask, counts) if return_counts else mask
+
+
+def _gather_rows_native(tensors, idx, idx_stride=1, rows=None, packed=True, debug=False):
+    """Rows ``idx`` (int64 on the device, every ``idx_stride``-th element) of up to eight fp32 tensors [P, ...] in one
+    pass.  ``packed``: one [R, sum of row widths] matrix, the tensors' rows side by side (bsr_pack_rows); otherwise a
+    list of tensors [R, ...] with the sources' trailing shapes (bsr_gather_rows)."""
+    import ctypes as C
+    if not 1 <= len(tensors) <= 8:
+        raise RuntimeError("gather_rows takes 1..8 tensors")
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("gather_rows needs GPU tensors; bloomscene_amd has no CPU path")
+    if idx.dtype != torch.int64 or idx.device != dev or not idx.is_contiguous():
+        raise RuntimeError("idx must be a contiguous int64 tensor on the tensors' device")
+    idx_stride = int(idx_stride)
+    R = int(rows) if rows is not None else (idx.numel() + idx_stride - 1) // idx_stride
+    if R < 0 or idx_stride < 1 or (R > 0 and (R - 1) * idx_stride + 1 > idx.numel()):
+        raise RuntimeError("idx holds fewer than rows elements at this stride")
+    widths = [int(torch.Size(t.shape[1:]).numel()) for t in tensors]
+    if any(t.shape[0] != tensors[0].shape[0] for t in tensors):
+        raise RuntimeError("gather_rows: the tensors must have the same number of rows")
+    srcs = [_dev_f32(t.detach(), "gather_rows source", dev) for t in tensors] if R else []
+    if R and any(t is None for t in srcs):
+        raise RuntimeError("gather_rows: rows requested from an empty tensor")
+    if packed:
+        out = torch.empty((R, sum(widths)), dtype=torch.float32, device=dev)
+    else:
+        out = [torch.empty((R,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev) for t in tensors]
+    if R:
+        n = len(srcs)
+        table = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        wtab = (C.c_int * n)(*widths)
+        with torch.cuda.device(dev):
+            if packed:
+                rc = _capi.lib().bsr_pack_rows(R, int(tensors[0].shape[0]), n, table, wtab, idx.data_ptr(), idx_stride,
+                                               out.data_ptr(), int(bool(debug)), _stream_handle(dev))
+            else:
+                rc = _capi.lib().bsr_gather_rows(R, int(tensors[0].shape[0]), n, table, wtab, idx.data_ptr(), idx_stride,
+                                                 (C.c_void_p * n)(*[t.data_ptr() for t in out]), int(bool(debug)),
+                                                 _stream_handle(dev))
+        _capi.check(rc, "gather_rows")
+    return out
+
+
+def _pack_rows_native(tensors, idx, idx_stride=1, rows=None, debug=False):
+    """bsr_pack_rows: [R, sum of row widths] fp32 (see _gather_rows_native)."""
+    return _gather_rows_native(tensors, idx, idx_stride, rows, True, debug)
 
 
 # ------------------------------------------------------------------ autograd (PYW:21-156)

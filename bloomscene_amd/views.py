@@ -168,18 +168,28 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         sync(dev)
         t0 = time.perf_counter()
         if masks is None:
-            masks = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
-                                     [assign_views(len(cams), r, world, assignment) for r in range(world)], scaling_modifier)
-        masks = masks.to(dev)
-        counts = masks.sum(dim=1).tolist()          # the ONE host synchronisation of the distribution
+            # the kernel counts each rank's rows while it writes the masks: 4 bytes per rank to read back
+            masks, counts = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
+                                             [assign_views(len(cams), r, world, assignment) for r in range(world)],
+                                             scaling_modifier, return_counts=True)
+        else:
+            masks = masks.to(dev)
+            counts = masks.sum(dim=1)
+        counts = counts.tolist()                    # the ONE host synchronisation of the distribution
         # (rank, id) pairs, rank-major, ids ascending; the size is known, so no second read-back inside nonzero
         pairs = torch.nonzero_static(masks, size=int(sum(counts)))
         sync(dev)
         t1 = time.perf_counter()
-        idx_all = pairs[:, 1].contiguous()
         trail = {k: tuple(bufs[k].shape[1:]) for k in keys}
-        flat_all = torch.cat([bufs[k].detach().index_select(0, idx_all).reshape(idx_all.numel(), -1).float()
-                              for k in keys], dim=1).contiguous()          # [sum counts, floats per Gaussian]
+        if dev.type == "cuda" and len(keys) <= 8 and all(bufs[k].dtype == torch.float32 for k in keys):
+            # one pass: every packed row gathered straight from the tensors (bsr_pack_rows)
+            from .rasterizer import _pack_rows_native
+            flat_all = _pack_rows_native([bufs[k] for k in keys], pairs.reshape(-1)[1:], idx_stride=2,
+                                         rows=pairs.shape[0])
+        else:                                       # CPU plumbing tests (gloo)
+            idx_all = pairs[:, 1].contiguous()
+            flat_all = torch.cat([bufs[k].detach().index_select(0, idx_all).reshape(idx_all.numel(), -1).float()
+                                  for k in keys], dim=1).contiguous()      # [sum counts, floats per Gaussian]
         sync(dev)
         t2 = time.perf_counter()
         info["filter_ms"], info["pack_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
@@ -228,22 +238,25 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     return local, my_views, info
 
 
-def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier: float = 1.0, debug=False):
+def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier: float = 1.0, debug=False,
+                     return_counts=False):
     """bool [len(groups), P]: row g = "some camera of groups[g] (a list of indices into ``cams``) sees the Gaussian",
     with prefilter_voxel's test (GR:342-349), in ONE pass over the Gaussians (bsr_visible_filter_groups) -- P bytes per
-    group written, instead of 4 P per view and the radii > 0 / any() passes behind them.  At most 64 groups."""
+    group written, instead of 4 P per view and the radii > 0 / any() passes behind them.  At most 64 groups.
+    ``return_counts``: (masks, int32 [len(groups)] ones per row, on the device -- accumulated by the kernel)."""
     from .rasterizer import _rasterize_gaussians_filter_groups_native
     dev = means3D.device
     order = [i for g in groups for i in g]
     if not order:
-        return torch.zeros((len(groups), means3D.shape[0]), dtype=torch.bool, device=dev)
+        z = torch.zeros((len(groups), means3D.shape[0]), dtype=torch.bool, device=dev)
+        return (z, torch.zeros((len(groups),), dtype=torch.int32, device=dev)) if return_counts else z
     vms, pms, _, c0 = _camera_stack(cams, order, dev)
     gid = torch.tensor([g for g, members in enumerate(groups) for _ in members], dtype=torch.int32)
     with torch.no_grad():
         return _rasterize_gaussians_filter_groups_native(
             means3D, scales[:, :3], rotations, scaling_modifier, torch.Tensor([]), vms, pms,
             math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5), int(c0.image_height), int(c0.image_width), gid,
-            len(groups), debug)
+            len(groups), debug, return_counts)
 
 
 def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0):
@@ -252,8 +265,9 @@ def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "co
     out = {}
     for w in worlds:
         groups = [assign_views(len(cams), r, w, assignment) for r in range(w)]
-        m = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], groups, scaling_modifier)
-        out[int(w)] = [int(x) for x in m.sum(dim=1).tolist()]
+        _, c = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], groups, scaling_modifier,
+                                return_counts=True)
+        out[int(w)] = [int(x) for x in c.tolist()]
     return out
 
 
@@ -465,14 +479,46 @@ def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_m
     return color, depth, radii
 
 
+def compact_for_view_groups(cams, gaussians: dict, groups, scaling_modifier: float = 1.0):
+    """One dict of per-Gaussian tensors per group of views, holding only the rows some view of the group can see
+    (ascending ids, so every frame rendered from it is bit-identical to the frame rendered from all rows): ONE pass of
+    the group filter over the Gaussians, a 4-byte-per-group read-back, one gather over all tensors.  This is the
+    reference's prefilter_voxel step (GR:342-349: render only what the visibility filter kept) for a whole camera
+    path at once.  A group that sees nothing gets row 0 alone (a culled Gaussian contributes nothing; P = 0 would take
+    the reference's zero-image path, RP:68-82, instead of the background).  At most 64 groups per filter pass."""
+    from .rasterizer import _gather_rows_native
+    keys = [k for k, v in gaussians.items() if torch.is_tensor(v) and v.numel() > 0]
+    P = gaussians["means3D"].shape[0]
+    subsets = []
+    for g0 in range(0, len(groups), 64):
+        chunk = groups[g0:g0 + 64]
+        masks, counts = group_visibility(cams, gaussians["means3D"], gaussians["scales"], gaussians["rotations"], chunk,
+                                         scaling_modifier, return_counts=True)
+        counts = counts.tolist()
+        pairs = torch.nonzero_static(masks, size=int(sum(counts)))
+        rows = _gather_rows_native([gaussians[k] for k in keys], pairs.reshape(-1)[1:], idx_stride=2,
+                                   rows=pairs.shape[0], packed=False) if pairs.shape[0] else None
+        off = 0
+        for n in counts:
+            if n == 0:
+                subsets.append({k: gaussians[k][:min(P, 1)] for k in keys})
+            else:
+                subsets.append({k: t[off:off + n] for k, t in zip(keys, rows)})
+            off += n
+    return subsets
+
+
 def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, world=None, keep_outputs=False,
-                         batch=1, views=None):
+                         batch=1, views=None, compact=False):
     """The rotate360 loop of BloomScene.render_video (reference bloomscene.py:191-211), sharded:
     this rank renders its round-robin share of ``cams`` with torch.no_grad() and returns
     {view index: (frame [3,H,W], depth [1,H,W])} (or only the indices when not keeping outputs).
     ``batch`` > 1 renders that many of the rank's views per native call (``render_views_batched``).
     ``views``: this rank's view indices when they are not the round-robin share (``scatter_visible_gaussians``).
-    ``cams`` may be a ``CameraPack`` when ``batch`` > 1 (no per-call stacking and upload of the matrices)."""
+    ``cams`` may be a ``CameraPack`` when ``batch`` > 1 (no per-call stacking and upload of the matrices).
+    ``compact`` (with ``batch`` > 1, scales + rotations given): every batch is rendered from the rows its views can see
+    (``compact_for_view_groups``) -- pays on sweeps whose views each see a small part of the scene (rotate360: 15 %),
+    costs a filter pass and a gather where every view sees everything.  Frames are bit-identical either way."""
     if rank is None:
         rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     if world is None:
@@ -482,9 +528,13 @@ def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, 
     mine = list(shard_views(len(cams), rank, world)) if views is None else list(views)
     with torch.no_grad():
         if batch > 1:
-            for b0 in range(0, len(mine), batch):
-                idx = mine[b0:b0 + batch]
-                color, depth, _ = render_views_batched(cams, gaussians, bg_color, sh_degree, idx=idx)
+            batches = [mine[b0:b0 + batch] for b0 in range(0, len(mine), batch)]
+            compact = (compact and bool(batches) and dev.type == "cuda" and gaussians["means3D"].shape[0] > 0
+                       and gaussians.get("scales") is not None and gaussians.get("rotations") is not None)
+            subsets = compact_for_view_groups(cams, gaussians, batches) if compact else None
+            for b, idx in enumerate(batches):
+                color, depth, _ = render_views_batched(cams, subsets[b] if compact else gaussians, bg_color, sh_degree,
+                                                       idx=idx)
                 for k, i in enumerate(idx):
                     out[i] = (color[k], depth[k]) if keep_outputs else None
             return out

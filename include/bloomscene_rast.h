@@ -203,15 +203,37 @@ int bsr_visible_filter_views(int P, int n_views,
  * one mask per GROUP of views: group_mask[g][i] (uint8 [n_groups, P], fully written) = 1 iff some view v with
  * group_of_view[v] == g has radii > 0 for Gaussian i.  group_of_view: DEVICE int[n_views], values in [0, n_groups),
  * n_groups <= 64.  With groups = the ranks of a view-parallel sweep this is "which Gaussians does rank g need": P
- * bytes per rank written instead of 4 P per view, and no radii > 0 / any() passes afterwards. */
+ * bytes per rank written instead of 4 P per view, and no radii > 0 / any() passes afterwards.
+ * group_counts (DEVICE uint32[n_groups], may be NULL): the number of ones in each row of group_mask, written by this
+ * call (what the caller needs to size its compaction: a 4*n_groups-byte read-back instead of a
+ * reduction over the masks). */
 int bsr_visible_filter_groups(int P, int n_views, int n_groups,
                               int width, int height,
                               const float* means3D, const float* scales, float scale_modifier,
                               const float* rotations, const float* cov3D_precomp,
                               const float* viewmatrices, const float* projmatrices,
                               float tan_fovx, float tan_fovy,
-                              const int* group_of_view, uint8_t* group_mask,
+                              const int* group_of_view, uint8_t* group_mask, uint32_t* group_counts,
                               int debug, void* stream);
+
+/* EXTENSION (views.scatter_visible_gaussians): dst[r] = the rows idx[r * idx_stride] of n_src (<= 8) per-Gaussian fp32
+ * tensors laid side by side, dst row = sum(widths) floats (<= 4096): one pass instead of an index_select per tensor
+ * plus a concatenation.  src / widths: HOST arrays (device pointers / floats per row of each tensor); idx: DEVICE int64
+ * (idx_stride in elements: 2 reads the second column of a [R, 2] index-pair matrix in place); dst: DEVICE [R, sum(widths)].
+ * P = rows of every source tensor: a row number outside [0, P) packs as zeros. */
+int bsr_pack_rows(int R, int P, int n_src,
+                  const float* const* src, const int* widths,
+                  const int64_t* idx, int idx_stride,
+                  float* dst,
+                  int debug, void* stream);
+
+/* EXTENSION (views.render_views_sharded(compact=True)): the same gather with one destination per tensor:
+ * dst[k] (HOST array of DEVICE pointers) = [R, widths[k]] = rows idx[] of src[k]. */
+int bsr_gather_rows(int R, int P, int n_src,
+                    const float* const* src, const int* widths,
+                    const int64_t* idx, int idx_stride,
+                    float* const* dst,
+                    int debug, void* stream);
 
 /* Backward pass for the forward call that produced (radii, geom/binning/image buffers, R).
  * dL_dpix is [3,H,W]; dL_depths [1,H,W] is accepted and ignored exactly like the reference

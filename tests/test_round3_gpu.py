@@ -7,6 +7,7 @@
 * data-parallel training over views: two ranks, two different views, the packed all-reduce must
   leave oracle-gradient(view 0) + oracle-gradient(view 1) on every rank.
 """
+import math
 import os
 import socket
 
@@ -384,6 +385,37 @@ def test_frames_from_scattered_visible_subsets_equal_frames_from_all_gaussians()
     assert all(0 < c < 60000 for c in results[0][2])      # each rank got a strict subset
 
 
+def test_sweep_with_per_batch_compaction_renders_the_same_frames():
+    """views.render_views_sharded(batch > 1, compact=True): each batch of views is rendered from the rows its own
+    visibility filter kept (one filter pass + one gather for the whole path) -- frames and depths bit-identical to the
+    sweep over all Gaussians, with a non-black background, a ragged last batch, and a batch that sees nothing at all."""
+    from bloomscene_amd import views
+    dev = _dev()
+    P, W, H, deg, V = 50000, 320, 180, 2, 11
+    sc = Hh.scene_b(P, W, H, deg, n_views=V, seed=4)
+    sc.scales = sc.scales * 3.0
+    cams = [c.to(dev) for c in sc.cameras]
+    g = {k: getattr(sc, k).to(dev) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    g["colors_precomp"] = None
+    bg = torch.tensor([0.3, 0.1, 0.6], device=dev)
+    pack = views.CameraPack(cams, dev)
+    want = views.render_views_sharded(pack, g, bg, deg, rank=0, world=1, keep_outputs=True, batch=4)
+    got = views.render_views_sharded(pack, g, bg, deg, rank=0, world=1, keep_outputs=True, batch=4, compact=True)
+    assert sorted(got) == sorted(want) == list(range(V))
+    for i in range(V):
+        assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i
+    subsets = views.compact_for_view_groups(pack, {k: v for k, v in g.items() if v is not None}, [[0, 1, 2, 3], [4], []])
+    assert 0 < subsets[1]["means3D"].shape[0] < subsets[0]["means3D"].shape[0] < P
+    assert subsets[2]["means3D"].shape[0] == 1 and subsets[0]["shs"].shape[1:] == g["shs"].shape[1:]
+    # everything far above the yawing cameras: every batch sees nothing and must still come out as the background
+    far = dict(g, means3D=g["means3D"] + torch.tensor([0.0, 1.0e4, 0.0], device=dev))
+    blank = views.render_views_sharded(pack, far, bg, deg, rank=0, world=1, keep_outputs=True, batch=4, compact=True)
+    ref = views.render_views_sharded(pack, far, bg, deg, rank=0, world=1, keep_outputs=True, batch=4)
+    for i in range(V):
+        assert torch.equal(blank[i][0], ref[i][0]) and torch.equal(blank[i][1], ref[i][1])
+    assert torch.equal(blank[0][0], bg.view(3, 1, 1).expand(3, H, W))
+
+
 @pytest.mark.fast_exp
 def test_default_mode_is_reproducible_and_independent_of_the_instantiation():
     """Which exp a pixel uses on a pair depends on that pair alone (render_fwd.hip), never on the lanes it shares a wave
@@ -414,6 +446,77 @@ def test_group_visibility_equals_any_over_the_per_view_filter():
     assert 0 < int(got[0].sum()) < P and not got[2].any()
     rows = views.visible_rows_per_rank(dict(means3D=means, scales=scales, rotations=rots), cams, worlds=(1, 2))
     assert rows[1] == [int(per_view.any(dim=0).sum())] and len(rows[2]) == 2
+    # the counts the kernel accumulates beside the masks
+    got2, counts = views.group_visibility(cams, means, scales, rots, groups, return_counts=True)
+    assert torch.equal(got2, got) and counts.dtype == torch.int32
+    assert counts.tolist() == got.sum(dim=1).tolist()
+
+
+def test_multi_view_filter_bounding_square_cull_never_changes_a_radius():
+    """k_visible_filter_views drops (view, Gaussian) pairs with a conservative bounding-square test before the exact
+    one: every row must stay bit-equal to the single-view filter (k_preprocess<true>, no such test) on inputs built to
+    sit on the cull's edges -- splats of every size from sub-pixel to larger than the scene, centres far outside, on
+    the frustum's borders and around the near plane, un-normalised quaternions, indefinite precomputed covariances,
+    NaN / Inf entries, a scaled view matrix, 70 views (more than one queue's worth per lane)."""
+    from bloomscene_amd import rasterizer as RZ
+    from bloomscene_amd.synthetic import scene_b
+    dev = _dev()
+    gen = torch.Generator().manual_seed(77)
+    P, W, H, V = 30011, 200, 120, 70
+    sc = scene_b(P, W, H, 1, n_views=V, seed=12)
+    means = sc.means3D.clone()
+    spread = torch.exp(torch.rand(P, 1, generator=gen) * 6.0 - 3.0)             # 0.05 .. 20 x the scene's extent
+    means = means * spread
+    scales = torch.exp(torch.rand(P, 3, generator=gen) * 16.0 - 10.0)            # 4.5e-5 .. 400
+    rots = torch.randn(P, 4, generator=gen) * torch.exp(torch.randn(P, 1, generator=gen))
+    means[5] = float("nan"); scales[6, 1] = float("inf"); rots[7] = 0.0; means[8, 2] = float("inf")
+    cams = sc.cameras
+    vms = torch.stack([c.world_view_transform for c in cams]).clone()
+    pms = torch.stack([c.full_proj_transform for c in cams]).clone()
+    vms[3, :, :3] *= 1.7                                                         # a view matrix that also scales
+    tanx, tany = math.tan(cams[0].FoVx * 0.5), math.tan(cams[0].FoVy * 0.5)
+    sym = torch.randn(P, 6, generator=gen) * torch.exp(torch.rand(P, 1, generator=gen) * 12.0 - 8.0)   # not PSD
+    for mode in ("scale_rot", "cov"):
+        kw_s = (scales.to(dev), rots.to(dev), torch.Tensor([])) if mode == "scale_rot" else \
+               (torch.Tensor([]), torch.Tensor([]), sym.to(dev))
+        for mod in (1.0, 2.5):
+            radii = RZ._rasterize_gaussians_filter_views_native(means.to(dev), kw_s[0], kw_s[1], mod, kw_s[2],
+                                                                vms.to(dev), pms.to(dev), tanx, tany, H, W, False)
+            seen = 0
+            for v in range(V):
+                single = RZ._rasterize_gaussians_filter_native(means.to(dev), kw_s[0], kw_s[1], mod, kw_s[2],
+                                                               vms[v].to(dev), pms[v].to(dev), tanx, tany, H, W, False,
+                                                               False)
+                assert torch.equal(radii[v], single), (mode, mod, v, int((radii[v] != single).sum()))
+                seen += int((single > 0).sum())
+            assert 0.01 * P * V < seen < 0.9 * P * V, seen       # neither nothing nor everything visible
+
+
+def test_pack_rows_equals_index_select_and_cat():
+    """bsr_pack_rows: one pass == index_select per tensor + cat, for a strided index column, odd widths, an empty
+    selection; a row number outside the tensors packs as zeros."""
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    gen = torch.Generator().manual_seed(5)
+    P = 7001
+    ts = [torch.randn(P, 3, generator=gen), torch.randn(P, 16, 3, generator=gen), torch.randn(P, generator=gen),
+          torch.randn(P, 4, generator=gen), torch.randn(P, 1, generator=gen), torch.randn(P, 7, generator=gen)]
+    ts = [t.to(dev) for t in ts]
+    idx = torch.randperm(P, generator=gen)[:3333].sort().values.to(dev)
+    want = torch.cat([t.index_select(0, idx).reshape(idx.numel(), -1) for t in ts], dim=1)
+    assert torch.equal(RZ._pack_rows_native(ts, idx), want)
+    pairs = torch.stack([torch.zeros_like(idx), idx], dim=1).contiguous()
+    assert torch.equal(RZ._pack_rows_native(ts, pairs.reshape(-1)[1:], idx_stride=2, rows=idx.numel()), want)
+    assert RZ._pack_rows_native(ts, idx[:0]).shape == (0, want.shape[1])
+    bad = torch.tensor([0, P, -1, P - 1], device=dev)
+    got = RZ._pack_rows_native(ts[:2], bad)
+    assert torch.equal(got[0], want.new_tensor(torch.cat([ts[0][0].reshape(-1), ts[1][0].reshape(-1)]).tolist()))
+    assert not got[1].any() and not got[2].any() and torch.equal(got[3, :3], ts[0][P - 1])
+    wide = [torch.randn(50, 300, generator=gen).to(dev)]
+    sel = torch.tensor([49, 0, 7], device=dev)
+    assert torch.equal(RZ._pack_rows_native(wide, sel), wide[0][sel])
+    with pytest.raises(RuntimeError, match="1..8"):
+        RZ._pack_rows_native(ts + ts, idx)
 
 
 # ------------------------------------------------------------------ the soak's worst seeds, as named cases
