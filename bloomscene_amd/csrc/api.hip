@@ -428,7 +428,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		{
 			StageTimer t("render_fwd", s);
 			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
-			                  background, img.final_T, img.n_contrib, out_color, out_depth, s);
+			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth, s);
 		}
 		return 0;
 	};

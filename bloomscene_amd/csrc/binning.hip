@@ -914,7 +914,35 @@ __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint3
 		merge_loaded_runs<NT, M, true, false>(keys, n2, start, n, tid, point_list);
 }
 
-// Small class (n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
+// Tiny class (n <= 64: every tile of a sparse camera-sweep view): one wave per tile, one key per lane, no LDS and no
+// synchronisation at all -- a key's place is the number of smaller keys ((depth bits, id) pairs are unique within a
+// tile), counted against the wave's keys broadcast one by one from SGPRs.  27 keys: ~110 instructions, against a
+// merge network that keeps 4 of 64 lanes busy and a 32-KB LDS footprint that caps the small class at 20 waves per CU.
+__global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __restrict__ n_ptr, int capacity,
+                                                         const uint32_t* __restrict__ tile_start,
+                                                         const BinElem* __restrict__ elems,
+                                                         uint32_t* __restrict__ point_list)
+{
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (tile >= T) return;
+	const int n_instances = *n_ptr;
+	const uint32_t start = tile_start[tile];
+	const int n = (int)(tile_start[tile + 1] - start);
+	if (n_instances > capacity || n > 64 || n <= 0) return;   // (scratch too small: stage is re-run) / another class / empty
+	uint64_t key = ~0ull;
+	if (lane < n) key = elem_key(load_elem(elems + start + lane));
+	const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+	uint32_t rank = 0;
+	for (int j = 0; j < n; j++) {
+		const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+		                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+		rank += kj < key ? 1u : 0u;
+	}
+	if (lane < n) point_list[start + rank] = lo;
+}
+
+// Small class (64 < n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
 // lane and round (16 in two trips beyond 512 keys).
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
@@ -927,7 +955,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
-	if (n > BSR_SORT_SMALL || n <= 0) return;   // on the big-tile list / empty
+	if (n > BSR_SORT_SMALL || n <= 64) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (or empty)
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
 	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0);   // (> 512 keys: two runs per lane)
@@ -1091,6 +1119,7 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
 	// which real inputs reach only with NaN / non-positive depth bits
 	const int force_int = opt_sort_force_int();
+	hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
 	                   force_int);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the

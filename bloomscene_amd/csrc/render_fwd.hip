@@ -52,14 +52,20 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
-	if (*n_ptr > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
+	// the three scalar loads leave together (a sparse view's tile lives for little more than its chain of dependent loads)
+	const int n_instances = *n_ptr;
+	const uint32_t start = tile_start[tile];
+	const uint32_t end = tile_start[tile + 1];
+	if (n_instances > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
-	const int wave = tid >> 6, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave-uniform: kept on the scalar side)
 #ifdef BSR_WALK_STATS
 	unsigned long long wstat[BSR_NSTAT_F] = {};
 	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-	stage_init(st, tid);   // (fenced by the first loop-top barrier)
+	// the sentinel record, written by EVERY wave (the same three values): a wave that stages a small tile for itself
+	// (below) reads it behind its own wave-level fence, the workgroup-staged path behind the staging's barriers
+	stage_init(st, lane);
 	const unsigned int* const my_list = &st.list[my_list_index<NS>(wave, lane)][0];
 	const int tx = tile % gx, tyv = tile / gx;
 	const int view = tyv / gy, ty = tyv - view * gy;
@@ -73,8 +79,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	const float pixfy = (float)py;
 	const float tile_x0 = (float)(tx * BSR_TILE), tile_y0 = (float)(ty * BSR_TILE);
 
-	const uint32_t start = tile_start[tile];
-	const uint32_t end = tile_start[tile + 1];
 	const int n = (int)(end - start);
 
 	bool done = !inside;
@@ -84,147 +88,196 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 	float D = 0.f;
 	float acc = 0.000001f;
 
-	for (int base = 0; base < n; base += FB) {
-		// whole tile finished?  (the barrier is also the WAR fence for the staging buffers)
-		const bool wave_done = (wave_ballot(!done) == 0ull);
-		if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
-		__syncthreads();
-		if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
-
-		const int cnt = min(FB, n - base);
-		const bool valid = tid < cnt;
-		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-		if (valid) {
-			const uint32_t id = point_list[start + base + tid];
-			const float4* r = rec + (size_t)id * BSR_REC;
-			r0 = r[0];
-			r1 = r[1];
-			r2 = r[2];
-			r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
-		}
-		const int n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
-		FSTAT_ADD(6, 1);      // batches (per wave)
-		FSTAT_ADD(7, cnt);    // staged entries (every wave sees the batch)
-
-		if (!wave_done) {
-			// Walk over this wave's compacted list(s), FOUR entries per trip as one straight-line block: no vote and
-			// no branch per entry.  (The predecessor voted "any candidate lane?" per entry and returned early: 2 % of the
-			// visits took that exit, and every visit paid two dependent LDS round trips and three branches in a chain
-			// the seven waves of a SIMD could not cover -- once v_exp_f32 had cut the arithmetic, a quarter fewer
-			// instructions bought 4 %.)  Here the four entries' LDS reads and their power / exp / alpha chains are
-			// independent and the scheduler interleaves them; only the blend itself is serial in T.  The rows are
-			// sentinel-padded to a multiple of four, and a sentinel is never a candidate.
-			// Fully predicated by value: a lane that must not blend carries alpha 0.
-			//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
-			//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
-			// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
-			int n_lim = __builtin_amdgcn_readfirstlane(n_mine);   // set to 0 to leave (single loop exit)
-			uint32_t lastj = 0xffffffffu;
-			const char* const rec0 = reinterpret_cast<const char*>(&st.q0[0]);
-			struct Ent { float4 q0, q1, q2; float power; bool cand; };
-			auto load = [&](const unsigned int joff) {
-				Ent e;
-				const char* rec = rec0 + joff;
-				e.q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
-				e.q1 = srec_q1<FB>(rec);      // -c/2, power cut, opacity, depth
-				e.q2 = srec_q2<FB>(rec);      // r, g, b, centre of the decision band
-				const float dx = e.q0.x - pixfx;
-				const float dy = e.q0.y - pixfy;
-				e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
-				// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
-				e.cand = !(e.power > 0.0f) && !(e.power < e.q1.y);
-				return e;
-			};
-			// c2: this lane blends the entry unless the stop test below fires
-			auto blend = [&](const Ent& e, const float alpha_raw, const bool c2, const unsigned int joff) {
-				const float a_eff = c2 ? alpha_raw : 0.0f;
-				const float test_T = T * (1 - a_eff);
-				const bool stop = test_T < 0.0001f;
-				const float a = stop ? 0.0f : a_eff;
-				// reference :439-446 as its nvcc build evaluates them (and the oracle restates them): c * alpha rounded, then
-				// ONE fused multiply-add with T.  fma(c * 0, T, x) == x exactly for every finite c.
-				C0 = __builtin_fmaf(e.q2.x * a, T, C0);
-				C1 = __builtin_fmaf(e.q2.y * a, T, C1);
-				C2 = __builtin_fmaf(e.q2.z * a, T, C2);
-				D = __builtin_fmaf(e.q1.w * a, T, D);
-				acc = __builtin_fmaf(a, T, acc);
-				T = stop ? T : test_T;
-				lastj = (c2 && !stop) ? joff : lastj;   // byte offset of the last entry of THIS batch the lane blended
-				done = done || stop;
+	// the walk over the calling wave's list (n_mine entries staged; pos_bias: 16 * (list position + 1) - byte offset of
+	// the staged slot), shared by the two staging schemes below
+	auto walk = [&](const int n_mine, const uint32_t pos_bias) {
+		// Walk over this wave's compacted list(s), FOUR entries per trip as one straight-line block: no vote and
+		// no branch per entry.  (The predecessor voted "any candidate lane?" per entry and returned early: 2 % of the
+		// visits took that exit, and every visit paid two dependent LDS round trips and three branches in a chain
+		// the seven waves of a SIMD could not cover -- once v_exp_f32 had cut the arithmetic, a quarter fewer
+		// instructions bought 4 %.)  Here the four entries' LDS reads and their power / exp / alpha chains are
+		// independent and the scheduler interleaves them; only the blend itself is serial in T.  The rows are
+		// sentinel-padded to a multiple of four, and a sentinel is never a candidate.
+		// Fully predicated by value: a lane that must not blend carries alpha 0.
+		//   not a candidate, alpha < 1/255, or done -> a_eff = 0   (reference: continue)
+		//   T (1 - alpha) < 1e-4      -> a       = 0   and the lane is done (reference :433-437)
+		// T >= 1e-4 is an invariant of every lane, so test_T < 1e-4 can only fire where a_eff > 0.
+		int n_lim = __builtin_amdgcn_readfirstlane(n_mine);   // set to 0 to leave (single loop exit)
+		uint32_t lastj = 0xffffffffu;
+		const char* const rec0 = reinterpret_cast<const char*>(&st.q0[0]);
+		struct Ent { float4 q0, q1, q2; float power; bool cand; };
+		auto load = [&](const unsigned int joff) {
+			Ent e;
+			const char* rec = rec0 + joff;
+			e.q0 = srec_q0<FB>(rec);      // x, y, -a/2, -b
+			e.q1 = srec_q1<FB>(rec);      // -c/2, power cut, opacity, depth
+			e.q2 = srec_q2<FB>(rec);      // r, g, b, centre of the decision band
+			const float dx = e.q0.x - pixfx;
+			const float dy = e.q0.y - pixfy;
+			e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic: == -0.5f * (a dx dx + c dy dy) - b dx dy
+			// reference: if (power > 0) continue;  then alpha < 1/255 -> continue (here proven by the cut)
+			e.cand = !(e.power > 0.0f) && !(e.power < e.q1.y);
+			return e;
+		};
+		// c2: this lane blends the entry unless the stop test below fires
+		auto blend = [&](const Ent& e, const float alpha_raw, const bool c2, const unsigned int joff) {
+			const float a_eff = c2 ? alpha_raw : 0.0f;
+			const float test_T = T * (1 - a_eff);
+			const bool stop = test_T < 0.0001f;
+			const float a = stop ? 0.0f : a_eff;
+			// reference :439-446 as its nvcc build evaluates them (and the oracle restates them): c * alpha rounded, then
+			// ONE fused multiply-add with T.  fma(c * 0, T, x) == x exactly for every finite c.
+			C0 = __builtin_fmaf(e.q2.x * a, T, C0);
+			C1 = __builtin_fmaf(e.q2.y * a, T, C1);
+			C2 = __builtin_fmaf(e.q2.z * a, T, C2);
+			D = __builtin_fmaf(e.q1.w * a, T, D);
+			acc = __builtin_fmaf(a, T, acc);
+			T = stop ? T : test_T;
+			lastj = (c2 && !stop) ? joff : lastj;   // byte offset of the last entry of THIS batch the lane blended
+			done = done || stop;
 #ifdef BSR_WALK_STATS
-				{
-					const int live = __popcll(wave_ballot(c2 && !stop));
-					FSTAT_ADD(0, 1);                                        // visits (incl. sentinel padding)
-					FSTAT_ADD(1, wave_ballot(e.cand) != 0ull ? 1 : 0);      // ... with a candidate lane
-					FSTAT_ADD(5, live);                                     // lanes that blend
-					if (live) { FSTAT_ADD(3, 1); FSTAT_ADD(8 + ((live - 1) >> 3), 1); }   // blending visits + histogram
-				}
-#endif
-			};
-			for (int i = 0; i < n_lim; i += 4) {
-				const uint4 l = *reinterpret_cast<const uint4*>(my_list + i);   // (the row is sentinel-padded to a multiple of 4)
-				const Ent e0 = load(l.x), e1 = load(l.y), e2 = load(l.z), e3 = load(l.w);
-				float g0, g1, g2, g3;
-				bool decide = true;   // false: alpha >= 1/255 is already proven for every candidate lane of the trip
-				if (EXACT) {
-					g0 = bsr_expf_walk(e0.power);
-					g1 = bsr_expf_walk(e1.power);
-					g2 = bsr_expf_walk(e2.power);
-					g3 = bsr_expf_walk(e3.power);
-				} else {
-					// `alpha >= 1/255` is decided on alpha = min(0.99, o E(power)) with the pinned exp E.  A candidate has
-					// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
-					// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
-					// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
-					// Only a lane inside that 2.1e-3 wide band (centre = power_cut + 1e-3, staged in q2.w) needs E to decide, and
-					// only a trip holding such a lane evaluates E at all (a few % of the trips); every other one takes the
-					// VALUE from v_exp_f32.  Which exp a lane uses depends on ITS power alone -- never on the lanes or
-					// entries it shares a trip with -- so the image is the same whichever instantiation (NS, view batching,
-					// scratch capacity) renders it.  The test is `!(|power - centre| >= 1.1e-3)` so that a NaN (centre:
-					// opacity <= 0 or NaN; power: NaN conic) counts as inside -- those lanes get the exact path's arithmetic,
-					// e.g. alpha < 0 is skipped as in the reference.  (One subtraction and ONE compare per entry, voted
-					// directly: a vote on `cand && power < hi` makes hipcc materialise the AND-ed mask in a VGPR and compare
-					// it again -- two more half-rate VALU slots per entry, 8 % of the trip.)  The backward selects the exp
-					// per lane with the same expression (render_bwd.hip) and so sees the same alpha.
-					const bool b0 = !(fabsf(e0.power - e0.q2.w) >= 1.1e-3f), b1 = !(fabsf(e1.power - e1.q2.w) >= 1.1e-3f);
-					const bool b2 = !(fabsf(e2.power - e2.q2.w) >= 1.1e-3f), b3 = !(fabsf(e3.power - e3.q2.w) >= 1.1e-3f);
-					g0 = __builtin_amdgcn_exp2f(e0.power * 1.44269504088896341f);
-					g1 = __builtin_amdgcn_exp2f(e1.power * 1.44269504088896341f);
-					g2 = __builtin_amdgcn_exp2f(e2.power * 1.44269504088896341f);
-					g3 = __builtin_amdgcn_exp2f(e3.power * 1.44269504088896341f);
-					decide = (wave_ballot(b0) | wave_ballot(b1) | wave_ballot(b2) | wave_ballot(b3)) != 0ull;   // rare
-					if (decide) {
-						FSTAT_ADD(2, 1);   // trips decided by the pinned exp
-						g0 = b0 ? bsr_expf_walk(e0.power) : g0;
-						g1 = b1 ? bsr_expf_walk(e1.power) : g1;
-						g2 = b2 ? bsr_expf_walk(e2.power) : g2;
-						g3 = b3 ? bsr_expf_walk(e3.power) : g3;
-					}
-				}
-				const float a0 = fminf(0.99f, e0.q1.z * g0), a1 = fminf(0.99f, e1.q1.z * g1);
-				const float a2 = fminf(0.99f, e2.q1.z * g2), a3 = fminf(0.99f, e3.q1.z * g3);
-				if (decide) {
-					blend(e0, a0, e0.cand && !(a0 < 1.0f / 255.0f) && !done, l.x);
-					blend(e1, a1, e1.cand && !(a1 < 1.0f / 255.0f) && !done, l.y);
-					blend(e2, a2, e2.cand && !(a2 < 1.0f / 255.0f) && !done, l.z);
-					blend(e3, a3, e3.cand && !(a3 < 1.0f / 255.0f) && !done, l.w);
-				} else {
-					blend(e0, a0, e0.cand && !done, l.x);
-					blend(e1, a1, e1.cand && !done, l.y);
-					blend(e2, a2, e2.cand && !done, l.z);
-					blend(e3, a3, e3.cand && !done, l.w);
-				}
-				if (wave_ballot(!done) == 0ull) n_lim = 0;   // every pixel of the quadrant is done: leave
+			{
+				const int live = __popcll(wave_ballot(c2 && !stop));
+				FSTAT_ADD(0, 1);                                        // visits (incl. sentinel padding)
+				FSTAT_ADD(1, wave_ballot(e.cand) != 0ull ? 1 : 0);      // ... with a candidate lane
+				FSTAT_ADD(5, live);                                     // lanes that blend
+				if (live) { FSTAT_ADD(3, 1); FSTAT_ADD(8 + ((live - 1) >> 3), 1); }   // blending visits + histogram
 			}
-			last16 = lastj != 0xffffffffu ? lastj + ((uint32_t)(base + 1) << 4) : last16;   // 16 * (list position + 1)
+#endif
+		};
+		for (int i = 0; i < n_lim; i += 4) {
+			const uint4 l = *reinterpret_cast<const uint4*>(my_list + i);   // (the row is sentinel-padded to a multiple of 4)
+			const Ent e0 = load(l.x), e1 = load(l.y), e2 = load(l.z), e3 = load(l.w);
+			float g0, g1, g2, g3;
+			bool decide = true;   // false: alpha >= 1/255 is already proven for every candidate lane of the trip
+			if (EXACT) {
+				g0 = bsr_expf_walk(e0.power);
+				g1 = bsr_expf_walk(e1.power);
+				g2 = bsr_expf_walk(e2.power);
+				g3 = bsr_expf_walk(e3.power);
+			} else {
+				// `alpha >= 1/255` is decided on alpha = min(0.99, o E(power)) with the pinned exp E.  A candidate has
+				// power >= power_cut = -ln(255 o) - 1e-3; at power >= -ln(255 o) + 1.1e-3 ANY exp within a few ulp gives
+				// alpha >= (1 + 1e-3) / 255: the decision is "blend" whatever the last bits are (margin 1e-3 in the
+				// exponent = 0.1 % of alpha, against 1e-6 for the rounding of logf, of E and of v_exp_f32 together).
+				// Only a lane inside that 2.1e-3 wide band (centre = power_cut + 1e-3, staged in q2.w) needs E to decide, and
+				// only a trip holding such a lane evaluates E at all (a few % of the trips); every other one takes the
+				// VALUE from v_exp_f32.  Which exp a lane uses depends on ITS power alone -- never on the lanes or
+				// entries it shares a trip with -- so the image is the same whichever instantiation (NS, view batching,
+				// scratch capacity) renders it.  The test is `!(|power - centre| >= 1.1e-3)` so that a NaN (centre:
+				// opacity <= 0 or NaN; power: NaN conic) counts as inside -- those lanes get the exact path's arithmetic,
+				// e.g. alpha < 0 is skipped as in the reference.  (One subtraction and ONE compare per entry, voted
+				// directly: a vote on `cand && power < hi` makes hipcc materialise the AND-ed mask in a VGPR and compare
+				// it again -- two more half-rate VALU slots per entry, 8 % of the trip.)  The backward selects the exp
+				// per lane with the same expression (render_bwd.hip) and so sees the same alpha.
+				const bool b0 = !(fabsf(e0.power - e0.q2.w) >= 1.1e-3f), b1 = !(fabsf(e1.power - e1.q2.w) >= 1.1e-3f);
+				const bool b2 = !(fabsf(e2.power - e2.q2.w) >= 1.1e-3f), b3 = !(fabsf(e3.power - e3.q2.w) >= 1.1e-3f);
+				g0 = __builtin_amdgcn_exp2f(e0.power * 1.44269504088896341f);
+				g1 = __builtin_amdgcn_exp2f(e1.power * 1.44269504088896341f);
+				g2 = __builtin_amdgcn_exp2f(e2.power * 1.44269504088896341f);
+				g3 = __builtin_amdgcn_exp2f(e3.power * 1.44269504088896341f);
+				decide = (wave_ballot(b0) | wave_ballot(b1) | wave_ballot(b2) | wave_ballot(b3)) != 0ull;   // rare
+				if (decide) {
+					FSTAT_ADD(2, 1);   // trips decided by the pinned exp
+					g0 = b0 ? bsr_expf_walk(e0.power) : g0;
+					g1 = b1 ? bsr_expf_walk(e1.power) : g1;
+					g2 = b2 ? bsr_expf_walk(e2.power) : g2;
+					g3 = b3 ? bsr_expf_walk(e3.power) : g3;
+				}
+			}
+			const float a0 = fminf(0.99f, e0.q1.z * g0), a1 = fminf(0.99f, e1.q1.z * g1);
+			const float a2 = fminf(0.99f, e2.q1.z * g2), a3 = fminf(0.99f, e3.q1.z * g3);
+			if (decide) {
+				blend(e0, a0, e0.cand && !(a0 < 1.0f / 255.0f) && !done, l.x);
+				blend(e1, a1, e1.cand && !(a1 < 1.0f / 255.0f) && !done, l.y);
+				blend(e2, a2, e2.cand && !(a2 < 1.0f / 255.0f) && !done, l.z);
+				blend(e3, a3, e3.cand && !(a3 < 1.0f / 255.0f) && !done, l.w);
+			} else {
+				blend(e0, a0, e0.cand && !done, l.x);
+				blend(e1, a1, e1.cand && !done, l.y);
+				blend(e2, a2, e2.cand && !done, l.z);
+				blend(e3, a3, e3.cand && !done, l.w);
+			}
+			if (wave_ballot(!done) == 0ull) n_lim = 0;   // every pixel of the quadrant is done: leave
+		}
+		last16 = lastj != 0xffffffffu ? lastj + pos_bias : last16;   // 16 * (list position + 1)
+	};
+
+	// A tile of at most 64 entries (the views of a camera sweep: a few dozen entries in every tile) is staged by each
+	// wave FOR ITSELF: the wave loads the entries, tests them against its own quadrant, and keeps records, list and a
+	// copy of the sentinel in its own quarter of the staging arrays -- no workgroup barrier anywhere, the four waves
+	// run their chains of dependent loads independently (such a tile's life is those chains, not arithmetic).  Same
+	// box test, same list order, same walk: identical bits.
+	if ((NS == 1) && n <= 64) {
+		// (outside the batch loop: its address arithmetic must not live across the other path's walk)
+		if (n > 0 && wave_ballot(!done) != 0ull) {
+			int n_mine;
+			uint32_t pos_bias;
+			const bool valid = lane < n;
+			bool hit = false;
+			if (valid) {
+				const uint32_t id = point_list[start + lane];
+				const float4* r = rec + (size_t)id * BSR_REC;
+				const float4 r0 = r[0], r1 = r[1];
+				float4 r2 = r[2];
+				r2.w = r1.y + 1.0e-3f;
+				const int slot = (wave << 6) + lane;
+				st.q0[slot] = r0;
+				st.q1[slot] = r1;
+				st.q2[slot] = r2;
+				const float a = -2.0f * r0.z, b = -r0.w, c = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
+				const bool pd = (a > 0.0f) && (c > 0.0f) && (a * c - b * b > 0.0f);
+				hit = box_may_hit<7, 7>(r0.x, r0.y, a, b, c, r1.y, -b / c, -b / a, pd, tile_x0 + (float)((wave & 1) << 3),
+				                        tile_y0 + (float)((wave >> 1) << 3));
+			}
+			const unsigned long long m = wave_ballot(hit);
+			n_mine = (int)__popcll(m);
+			if (hit) st.list[wave][__popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)(((wave << 6) + lane) << 4);
+			if (lane < 3) st.list[wave][n_mine + lane] = (unsigned int)(FB << 4);   // pad to the four entries of a trip
+			pos_bias = 16u - ((uint32_t)wave << 10);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			walk(n_mine, pos_bias);
+		}
+	} else {
+		for (int base = 0; base < n; base += FB) {
+			const bool wave_done = (wave_ballot(!done) == 0ull);
+			int n_mine;
+			uint32_t pos_bias;
+			if (base > 0) {
+				// whole tile finished?  (the barrier is also the WAR fence for the staging buffers; the first batch has
+				// nothing to wait for: the sentinel stage_init wrote is read behind the two barriers of the staging)
+				if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+				__syncthreads();
+				if (s_done[0] & s_done[1] & s_done[2] & s_done[3]) break;
+			}
+			const int cnt = min(FB, n - base);
+			const bool valid = tid < cnt;
+			float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+			if (valid) {
+				const uint32_t id = point_list[start + base + tid];
+				const float4* r = rec + (size_t)id * BSR_REC;
+				r0 = r[0];
+				r1 = r[1];
+				r2 = r[2];
+				r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
+			}
+			n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
+			pos_bias = (uint32_t)(base + 1) << 4;
+			FSTAT_ADD(6, 1);      // batches (per wave)
+			FSTAT_ADD(7, cnt);    // staged entries (every wave sees the batch)
+			if (!wave_done) walk(n_mine, pos_bias);
 		}
 	}
 
 	if (inside) {
 		const size_t plane = (size_t)H * W;
 		const size_t pix_id = (size_t)W * py + px, img = (size_t)view * plane;
-		final_T[img + pix_id] = T;
-		n_contrib[img + pix_id] = last16 >> 4;
+		if (final_T != nullptr) {   // (view-batched calls have no backward and pass no per-pixel state)
+			final_T[img + pix_id] = T;
+			n_contrib[img + pix_id] = last16 >> 4;
+		}
 		float* oc = out_color + 3 * img;
 		oc[pix_id] = __builtin_fmaf(T, bg_color[0], C0);
 		oc[plane + pix_id] = __builtin_fmaf(T, bg_color[1], C1);

@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--shift-y", type=float, default=0.0, help="move every Gaussian up by this much (1e4: no view sees "
                                                                  "anything -- the empty-tile floor of the sweep)")
+    ap.add_argument("--lib", default="", help="another build of the same C ABI (A/B and knock-out runs)")
     a = ap.parse_args()
-    from bloomscene_amd import views
+    from bloomscene_amd import _capi, views
+    if a.lib:
+        _capi.use_library(a.lib)
     from bloomscene_amd.synthetic import scene_b
     dev = torch.device("cuda:0")
     sc = scene_b(a.gaussians, 1920, 1080, 3, n_views=a.views, seed=0)
