@@ -404,23 +404,40 @@ __global__ void __launch_bounds__(256) k_tile_count(int T, int n_slices, const i
 	if (c != 0u && t < (uint32_t)T) atomicAdd(&tile_count[t], c);
 }
 
+// Inclusive sum over the 64 lanes on the vector ALU alone (the sequence LLVM's atomic optimiser emits for wave64 on
+// GFX9): four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3 and lane 31
+// into rows 2 - 3.  (__shfl_up is a ds_bpermute round trip per step.)
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+	return x;
+}
+
 // ONE workgroup of 1024: tile_count -> tile_start (exclusive scan in tile order, tile_start[T] = total) and the work
-// lists of the wide sort classes (as k_tile_ranges builds them).  Thread i owns the ceil(T / 1024) consecutive tiles
-// from i * per on.  (Folding this into k_tile_count's last-finishing workgroup was measured: the per-workgroup
-// ordering it needs -- returning atomics + one contended counter -- cost 4x the launch it saves.)
+// lists of the wide sort classes (as k_tile_ranges builds them).  (Folding this into k_tile_count's last-finishing
+// workgroup was measured: the per-workgroup ordering it needs -- returning atomics + one contended counter -- cost 4x
+// the launch it saves.)  The tiles are taken in chunks of 1024 consecutive ones, thread i <-> tile 1024 j + i: every
+// access is coalesced (a thread owning `per` CONSECUTIVE tiles made each wave load touch 64 cache lines: 105 us on
+// this one CU at 65 536 tiles -- 8 stacked 1080p views, one 8K view).  All counts are requested up front and stay in
+// registers; a wave scans its 64 tiles of every chunk, then the 16 x (chunks) wave totals are scanned once.
+template <int NC>   // chunks held in registers: 8 (up to 8192 tiles: one 1080p view) or 64 (16-bit tile ids)
 __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restrict__ n_ptr, int capacity,
                                                       const uint32_t* __restrict__ tile_count,
                                                       uint32_t* __restrict__ tile_start,
                                                       uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
 {
+	__shared__ uint32_t s_tot[1024];         // [chunk][wave] totals (NC x 16 used), then their exclusive prefix
 	__shared__ uint32_t s_w[16];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int per = (T + 1023) >> 10;   // <= 64 for 16-bit tile ids
-	const int t0 = tid * per;
-	// counts requested before anything else (the kernel is one workgroup's chain of round trips)
-	uint32_t c8[8];
+	const int chunks = (T + 1023) >> 10;     // <= NC
+	uint32_t c[NC];
 #pragma unroll
-	for (int j = 0; j < 8; j++) c8[j] = (j < per && t0 + j < T) ? tile_count[t0 + j] : 0u;
+	for (int j = 0; j < NC; j++) c[j] = (j < chunks && (j << 10) + tid < T) ? tile_count[(j << 10) + tid] : 0u;
 	{
 		const int n = *n_ptr;
 		if (n > capacity) return;   // overflow: the stage is re-run
@@ -429,46 +446,40 @@ __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restri
 			return;
 		}
 	}
-	uint32_t mine = 0;
+	// inclusive scan of every chunk's 64 tiles of this wave (c[j] becomes the inclusive sum, the count is re-derived)
 	bool any_big = false;
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		mine += c8[j];
-		any_big = any_big || c8[j] > (uint32_t)BSR_SORT_SMALL_N;
-	}
-	for (int k = 8; k < per; k++) {   // images beyond 8192 tiles
-		const uint32_t c = t0 + k < T ? tile_count[t0 + k] : 0u;
-		mine += c;
-		any_big = any_big || c > (uint32_t)BSR_SORT_SMALL_N;
-	}
-	uint32_t incl = mine;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += t;
-	}
-	if (lane == 63) s_w[wave] = incl;
+	s_tot[tid] = 0u;
 	__syncthreads();
-	uint32_t run = incl - mine;
-	for (int w = 0; w < wave; w++) run += s_w[w];
 #pragma unroll
-	for (int j = 0; j < 8; j++)
-		if (j < per && t0 + j < T) {
-			tile_start[t0 + j] = run;
-			run += c8[j];
+	for (int j = 0; j < NC; j++) {
+		if (j < chunks) {   // (uniform)
+			any_big = any_big || c[j] > (uint32_t)BSR_SORT_SMALL_N;
+			const uint32_t incl = wave_inclusive_sum_dpp(c[j]);
+			if (lane == 63) s_tot[j * 16 + wave] = incl;
+			c[j] = incl - c[j];   // exclusive within the wave
 		}
-	for (int k = 8; k < per; k++) {
-		const int t = t0 + k;
-		if (t >= T) break;
-		tile_start[t] = run;
-		run += tile_count[t];
 	}
-	if (tid == 1023) tile_start[T] = run;   // (thread 1023 owns the last tiles or none: run is the total either way)
-	if (wave_ballot(any_big) != 0ull) {   // rare: waves without a long tile skip the filing
-		for (int k = 0; k < per; k++) {
-			const int t = t0 + k;
-			const uint32_t c = t < T ? tile_count[t] : 0u;
-			const int cls = c > 8192u ? 2 : (c > 4096u ? 1 : (c > (uint32_t)BSR_SORT_SMALL_N ? 0 : -1));
+	__syncthreads();
+	// exclusive scan of the 1024 (chunk, wave) totals: thread t owns total t
+	{
+		const uint32_t mine = s_tot[tid];
+		const uint32_t incl = wave_inclusive_sum_dpp(mine);
+		if (lane == 63) s_w[wave] = incl;
+		__syncthreads();
+		uint32_t run = incl - mine;
+		for (int w = 0; w < wave; w++) run += s_w[w];
+		s_tot[tid] = run;
+		if (tid == 1023) tile_start[T] = run + mine;   // the total
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < NC; j++)
+		if (j < chunks && (j << 10) + tid < T) tile_start[(j << 10) + tid] = s_tot[j * 16 + wave] + c[j];
+	if (__syncthreads_or(any_big)) {   // rare: the filing re-reads the counts
+		for (int j = 0; j < chunks; j++) {
+			const int t = (j << 10) + tid;
+			const uint32_t cc = t < T ? tile_count[t] : 0u;
+			const int cls = cc > 8192u ? 2 : (cc > 4096u ? 1 : (cc > (uint32_t)BSR_SORT_SMALL_N ? 0 : -1));
 #pragma unroll
 			for (int c3 = 0; c3 < 3; c3++) {
 				const uint64_t b = wave_ballot(cls == c3);
@@ -942,12 +953,12 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 	if (lane < n) point_list[start + rank] = lo;
 }
 
-// Small class (64 < n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
+// Small class (min_n < n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
 // lane and round (16 in two trips beyond 512 keys).
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const BinElem* __restrict__ elems,
-                                                          uint32_t* __restrict__ point_list, int force_int)
+                                                          uint32_t* __restrict__ point_list, int force_int, int min_n)
 {
 	__shared__ uint64_t s_keys[4][BSR_SORT_SMALL];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -955,7 +966,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
-	if (n > BSR_SORT_SMALL || n <= 64) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (or empty)
+	if (n > BSR_SORT_SMALL || n <= min_n) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (min_n = 64) or empty
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
 	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0);   // (> 512 keys: two runs per lane)
@@ -1079,8 +1090,12 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 		n_slices = n_slices > 256 ? 256 : n_slices;
 		hipLaunchKernelGGL(k_tile_count, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
 		                   digit_total1, elems_a, tile_count);
-		hipLaunchKernelGGL(k_tile_starts, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start, big_tiles,
-		                   flags);
+		if (T <= 8192)
+			hipLaunchKernelGGL(k_tile_starts<8>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
+			                   big_tiles, flags);
+		else
+			hipLaunchKernelGGL(k_tile_starts<64>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
+			                   big_tiles, flags);
 		hipLaunchKernelGGL(k_tile_scatter, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
 		                   digit_total1, elems_a, elems_b, tile_start, tile_cursor);
 		*elems_sorted = elems_b;
@@ -1119,9 +1134,14 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
 	// which real inputs reach only with NaN / non-positive depth bits
 	const int force_int = opt_sort_force_int();
-	hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list);
+	// sparse frames (the views of a camera sweep: every tile a few dozen entries) get the tiny class its own kernel;
+	// where tiles average 128 entries or more the few short ones stay with the small class (one launch fewer)
+	const bool tiny = (long long)n_bound < 128ll * T;
+	if (tiny)
+		hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems,
+		                   point_list);
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
-	                   force_int);
+	                   force_int, tiny ? 64 : 0);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
 	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
 	const int g1 = min(T, n_bound / (BSR_SORT_SMALL + 1)), g4 = min(T, n_bound / 4097),

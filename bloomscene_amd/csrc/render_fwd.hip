@@ -235,6 +235,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 			if (hit) st.list[wave][__popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)(((wave << 6) + lane) << 4);
 			if (lane < 3) st.list[wave][n_mine + lane] = (unsigned int)(FB << 4);   // pad to the four entries of a trip
 			pos_bias = 16u - ((uint32_t)wave << 10);
+			FSTAT_ADD(6, 1);    // batches (per wave)
+			FSTAT_ADD(7, n);    // staged entries
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
