@@ -587,7 +587,7 @@ def main():
         # the reference's own rotate360 preset: 180 views, 2 degrees apart (utils/trajectory.py:102-126)
         c4_180 = c4_sweep(D, args, n_views=180, repeats=3)
         c4["preset_180_views"] = {k: c4_180[k] for k in ("workload", "views", "views_per_rank", "broadcast_ms",
-                                                        "views_per_call_16", "scatter_visible", "predicted") if k in c4_180}
+                                                        "views_per_call_16", "views_per_call_16_compacted", "scatter_visible", "predicted") if k in c4_180}
     secondary = None
     if D.world == 1 and headline and not args.no_secondary:
         sec_steps = max(20, args.steps // 2)
