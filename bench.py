@@ -144,10 +144,14 @@ class Dist:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = os.environ.get("BSR_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+            # a rank that waits for a peer which has failed gives up after five minutes, not after the default thirty
+            import datetime
+            patience = datetime.timedelta(seconds=300)
             if backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev,
+                                        timeout=patience)
             else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=patience)
 
     def fence(self):
         if self.multi:
@@ -582,12 +586,19 @@ def main():
     r = raster_workload(D, args, P, W, H, deg, do_bwd, precomp=precomp, scale_mul=args.scale_mul,
                         cycle_views=args.cycle_views, label=args.config, allreduce=args.allreduce_grads,
                         depth_gradient=args.depth_gradient)
-    c4 = None if args.no_c4 else c4_sweep(D, args)
-    if c4 is not None and headline:
+    def guarded(fn, *a, **kw):
+        # the secondary legs must not cost the headline its line: an exception there is reported in the leg's place
+        try:
+            return fn(*a, **kw)
+        except Exception as exc:   # noqa: BLE001
+            return {"error": f"{type(exc).__name__}: {exc}"}
+    c4 = None if args.no_c4 else guarded(c4_sweep, D, args)
+    if c4 is not None and headline and "error" not in c4:
         # the reference's own rotate360 preset: 180 views, 2 degrees apart (utils/trajectory.py:102-126)
-        c4_180 = c4_sweep(D, args, n_views=180, repeats=3)
-        c4["preset_180_views"] = {k: c4_180[k] for k in ("workload", "views", "views_per_rank", "broadcast_ms",
-                                                        "views_per_call_16", "views_per_call_16_compacted", "scatter_visible", "predicted") if k in c4_180}
+        c4_180 = guarded(c4_sweep, D, args, n_views=180, repeats=3)
+        keep = ("workload", "views", "views_per_rank", "broadcast_ms", "views_per_call_16", "views_per_call_16_compacted",
+                "scatter_visible", "predicted")
+        c4["preset_180_views"] = c4_180 if "error" in c4_180 else {k: c4_180[k] for k in keep if k in c4_180}
     secondary = None
     if D.world == 1 and headline and not args.no_secondary:
         sec_steps = max(20, args.steps // 2)

@@ -54,7 +54,8 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.depth = (float*)p;
 	return g;
 }
-// The backward's slab (48 B per instance) lives in the caller's binning buffer too, over the radix ping-pong
+// The backward's slab (SIZED at 48 B per instance; its rows are 36 B, 40 B with the depth gradient: the reader's last
+// 16-byte load of a run may reach 12 B past it) lives in the caller's binning buffer too, over the radix ping-pong
 // buffers, which are dead once the forward has returned: the library owns no device memory, as in the reference,
 // where every byte of scratch comes from the caller's resize callbacks (rasterize_points.cu:27-33).
 // with_slab = false (view-batched forward: inference only) sizes the section for the ping-pong buffers alone.

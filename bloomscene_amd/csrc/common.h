@@ -44,6 +44,13 @@ struct BinElem {
 	uint32_t y;   // Gaussian id
 	uint32_t z;   // bits of the view-space depth
 };
+// Slab rows (k_render_bwd -> k_preprocess_bwd) are TIGHT: 9 floats per kept instance (10 with the depth-gradient
+// extension), 4-byte aligned, moved with wide accesses that only assume that alignment.
+typedef float bsr_f32x4 __attribute__((ext_vector_type(4)));
+typedef float bsr_f32x2 __attribute__((ext_vector_type(2)));
+typedef bsr_f32x4 bsr_f32x4_a4 __attribute__((aligned(4)));
+typedef bsr_f32x2 bsr_f32x2_a4 __attribute__((aligned(4)));
+__host__ __device__ __forceinline__ constexpr int slab_row_floats(bool depth_grad) { return depth_grad ? 10 : 9; }
 typedef uint32_t bsr_u32x3 __attribute__((ext_vector_type(3)));
 typedef bsr_u32x3 bsr_u32x3_a4 __attribute__((aligned(4)));
 __device__ __forceinline__ BinElem load_elem(const BinElem* p)
@@ -60,7 +67,7 @@ struct BinState {
 	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
 	BinElem* elems_a;     // [R] (tile id, gaussian id, depth bits): ping-pong buffers of the radix passes
 	BinElem* elems_b;       // [R]
-	float4* slab;         // [R][3] the backward's per-instance partial sums (k_render_bwd -> k_preprocess_bwd): the SAME
+	float4* slab;         // [R][9 or 10 floats, tight] the backward's per-instance partial sums (k_render_bwd -> k_preprocess_bwd): the SAME
 	                      //        bytes as elems_a / elems_b, which are dead once the forward has returned
 	uint32_t* hist;       // [256 * BSR_HIST_BLOCKS_MAX] digit-major workgroup histograms, then [256] digit totals
 	static size_t bytes(size_t R, bool with_slab);
@@ -119,9 +126,9 @@ struct BwdArgs {
 	const float* campos;
 	float tan_fovx, tan_fovy, focal_x, focal_y;
 	GeomState geom;
-	const float4* slab;            // [R][3] per-instance partial sums written by k_render_bwd, Gaussian-major:
+	const float4* slab;            // [R][9 floats; 10 with depth_grad] per-instance partial sums written by k_render_bwd, Gaussian-major:
 	                               //        row wg_base[g/256] + inst_offset[g] + k = k-th kept tile of Gaussian g
-	int depth_grad;                // extension: slab row[2].y carries dL/d(view z), added to dL_dmean3D
+	int depth_grad;                // extension: slab rows carry a tenth float, dL/d(view z), added to dL_dmean3D
 	float* dL_dmean2D;         // [P,3]  (outputs; fully written)
 	float* dL_dconic;          // [P,4]
 	float* dL_dopacity;        // [P]

@@ -174,18 +174,21 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	//
 	// The blocks of the 64 Gaussians of a wave are adjacent too (k_preprocess numbers the kept instances of a workgroup
 	// in id order), so the wave's rows are ONE contiguous run of the slab.  A thread walking its own rows issues
-	// 48-B-strided loads, one dependent round trip per row, and the wave runs as many trips as its longest block;
+	// row-strided loads, one dependent round trip per row, and the wave runs as many trips as its longest block;
 	// instead the wave copies the run into LDS with coalesced 16-byte loads (all in flight at once) and every thread
 	// adds its rows from there, in the same order: same sums bit for bit.  The staging area is the SH tile, which is
 	// not in use yet (its own few KB in the instantiations without one).
 	constexpr int STAGE_F4 = ROW_F4 > 0 ? 64 * (ROW_F4 + 1) : 192;   // float4 per wave
-	constexpr uint32_t STAGE_ROWS = STAGE_F4 / 3;
 	__shared__ float4 s_stage[4][STAGE_F4];   // ROW_F4 > 0: reinterpreted as ShTile<ROW_F4> by the SH part below
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float g_z = 0.f;   // dL/d(view z): written only by the depth-gradient variant of k_render_bwd (else 0)
 	{
+		// rows are tight: 9 floats (10 with the depth gradient), so a run starts on a 4-byte boundary only
+		const uint32_t rowf = (uint32_t)slab_row_floats(a.depth_grad != 0);
+		const uint32_t stage_rows = (uint32_t)(STAGE_F4 * 4) / rowf;
 		const int lane = threadIdx.x & 63;
 		float4* const stage = s_stage[threadIdx.x >> 6];
+		const float* const stage_f = reinterpret_cast<const float*>(stage);
 		const uint32_t area = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
 		const uint32_t off = n_inst ? a.geom.wg_kept[idx >> 8] + a.geom.inst_offset[idx] : 0u;
@@ -201,34 +204,34 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		if (has != 0ull) {   // wave-uniform
 			// first row of the run: any lane with a block knows it (its block starts `excl` rows in)
 			const uint32_t run0 = (uint32_t)__builtin_amdgcn_readlane((int)(off - excl), (int)__builtin_ctzll(has));
-			const float4* const src = a.slab + (size_t)run0 * 3;
-			for (uint32_t c0 = 0; c0 < total; c0 += STAGE_ROWS) {
-				const uint32_t n_rows = min(STAGE_ROWS, total - c0);
-				const uint32_t n_f4 = n_rows * 3;
-				const float4* const s = src + (size_t)c0 * 3;
+			const float* const src = reinterpret_cast<const float*>(a.slab) + (size_t)run0 * rowf;
+			for (uint32_t c0 = 0; c0 < total; c0 += stage_rows) {
+				const uint32_t n_rows = min(stage_rows, total - c0);
+				const uint32_t n_f4 = (n_rows * rowf + 3u) >> 2;   // (the last one may read up to 12 B past the run: the slab
+				                                                   //  is sized at 48 B per row, api.hip)
+				const bsr_f32x4_a4* const s = reinterpret_cast<const bsr_f32x4_a4*>(src + (size_t)c0 * rowf);
 				for (uint32_t i0 = 0; i0 < n_f4; i0 += 256) {   // four 1-KiB loads in flight per trip
 					const uint32_t i = i0 + (uint32_t)lane;
-					float4 v0, v1, v2, v3;
+					bsr_f32x4 v0, v1, v2, v3;
 					if (i < n_f4) v0 = s[i];
 					if (i + 64 < n_f4) v1 = s[i + 64];
 					if (i + 128 < n_f4) v2 = s[i + 128];
 					if (i + 192 < n_f4) v3 = s[i + 192];
-					if (i < n_f4) stage[i] = v0;
-					if (i + 64 < n_f4) stage[i + 64] = v1;
-					if (i + 128 < n_f4) stage[i + 128] = v2;
-					if (i + 192 < n_f4) stage[i + 192] = v3;
+					if (i < n_f4) stage[i] = make_float4(v0.x, v0.y, v0.z, v0.w);
+					if (i + 64 < n_f4) stage[i + 64] = make_float4(v1.x, v1.y, v1.z, v1.w);
+					if (i + 128 < n_f4) stage[i + 128] = make_float4(v2.x, v2.y, v2.z, v2.w);
+					if (i + 192 < n_f4) stage[i + 192] = make_float4(v3.x, v3.y, v3.z, v3.w);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				const uint32_t k0 = max(excl, c0), k1 = min(incl, c0 + n_rows);
 				for (uint32_t k = k0; k < k1; k++) {
-					const float4* row = stage + (k - c0) * 3;
-					const float4 s0 = row[0], s1 = row[1], s2 = row[2];
-					g[0] += s0.x; g[1] += s0.y; g[2] += s0.z; g[3] += s0.w;
-					g[4] += s1.x; g[5] += s1.y; g[6] += s1.z; g[7] += s1.w;
-					g[8] += s2.x;
-					g_z += s2.y;
+					const float* row = stage_f + (k - c0) * rowf;
+					g[0] += row[0]; g[1] += row[1]; g[2] += row[2]; g[3] += row[3];
+					g[4] += row[4]; g[5] += row[5]; g[6] += row[6]; g[7] += row[7];
+					g[8] += row[8];
+					if (a.depth_grad) g_z += row[9];
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();   // the next chunk / the SH part overwrites the staging area

@@ -13,7 +13,7 @@
 //     writes (wave_sums_masked below),
 //   * each wave stores its sums in its own LDS slot (LDS float atomics cost ~16 cycles each on
 //     gfx950 whatever the exec mask); the 4 slots are added in a fixed order at the batch end,
-//   * each instance's 9 sums are written ONCE to its row [12 floats] of a GAUSSIAN-MAJOR slab: the
+//   * each instance's 9 sums are written ONCE to its row [9 floats; 10 with the depth gradient] of a GAUSSIAN-MAJOR slab: the
 //     rows of one Gaussian (one per kept tile of its rect, row-major) are adjacent, at the instance
 //     numbering fixed by the forward's preprocess,
 //   * k_preprocess_bwd later reads each Gaussian's rows as one contiguous run and adds them in that
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                                                           const float* __restrict__ dL_dpixels,
                                                           const float* __restrict__ out_depth,   // DEPTH only
                                                           const float* __restrict__ dL_depths,   // DEPTH only
-                                                          float4* __restrict__ slab)        // [R][3]
+                                                          float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
 	__shared__ BwdShared<NV> sh;
@@ -494,17 +494,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float ca = -2.0f * e0.z, cb = -e0.w, cc = -2.0f * e1.x;
 			const float no = -e1.z;
 			const float h = 0.5f * no;
-			float4* row = slab + (size_t)my_row * 3;
+			float* const row = reinterpret_cast<float*>(slab) + (size_t)my_row * slab_row_floats(DEPTH);
 #ifdef BSR_BWD_PAIR_PRODUCTS
 			(void)ca; (void)cb; (void)cc; (void)h;
-			row[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
-			row[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{a9[0], a9[1], a9[2], a9[3]};
+			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{a9[4], a9[5], a9[6], a9[7]};
 #else
-			row[0] = make_float4(no * ddelx_dx * (ca * a9[0] + cb * a9[1]), no * ddely_dy * (cc * a9[1] + cb * a9[0]),
-			                     h * a9[2], h * a9[3]);
-			row[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
+			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{no * ddelx_dx * (ca * a9[0] + cb * a9[1]),
+			                                                   no * ddely_dy * (cc * a9[1] + cb * a9[0]), h * a9[2], h * a9[3]};
+			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{h * a9[4], a9[5], a9[6], a9[7]};
 #endif
-			row[2] = make_float4(a9[8], a9[9], 0.f, 0.f);
+			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
+			else row[8] = a9[8];
 		}
 		__syncthreads();
 	}
@@ -513,12 +514,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
 		const uint32_t id = point_list[slot];
-		float4* row = slab + (size_t)instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2],
-		                                            rec[(size_t)id * BSR_REC + 3], tx, ty) * 3;
-		const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-		row[0] = z;
-		row[1] = z;
-		row[2] = z;
+		float* const row = reinterpret_cast<float*>(slab) +
+		                   (size_t)instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3],
+		                                          tx, ty) * slab_row_floats(DEPTH);
+		const bsr_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+		*reinterpret_cast<bsr_f32x4_a4*>(row) = z;
+		*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = z;
+		if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{0.f, 0.f};
+		else row[8] = 0.f;
 	}
 #ifdef BSR_WALK_STATS
 	if (lane == 0) {

@@ -300,6 +300,15 @@ def test_camera_pack_and_multi_view_helpers_on_cpu():
         views.CameraPack([cams[0], views.yawed_camera(80, 48, 1.0, 0.0)], "cpu")
     with pytest.raises(RuntimeError, match="GPU"):
         views.group_visibility(pack, torch.zeros(4, 3), torch.ones(4, 3), torch.ones(4, 4), [[0, 1], [2]])
+    # the row gathers of the sweep paths: argument checks before anything native, and no CPU path either
+    from bloomscene_amd import rasterizer as RZ
+    with pytest.raises(RuntimeError, match="GPU"):
+        RZ._gather_rows_native([torch.zeros(4, 3)], torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="1..8"):
+        RZ._gather_rows_native([], torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="GPU"):
+        views.compact_for_view_groups(pack, dict(means3D=torch.zeros(4, 3), scales=torch.ones(4, 3),
+                                                 rotations=torch.ones(4, 4)), [[0], [1]])
     from bloomscene_amd.neural_gaussians import render_anchors
     with pytest.raises(RuntimeError, match="GPU"):
         render_anchors(torch.zeros(2, 3), torch.ones(2, 6), torch.zeros(2, 5, 3), torch.ones(10, 1), torch.zeros(10, 3),

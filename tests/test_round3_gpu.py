@@ -33,7 +33,9 @@ def _compare_default_with_exact(c, st, label):
     On a pixel whose stop decision moved, the entry that triggers the stop is blended in one mode and not in the other
     (forward.cu:433-437: the stopping Gaussian is NOT blended): its weight alpha T is below 1e-4 / (1 - alpha) * alpha,
     i.e. up to 1e-2 at the 0.99 clamp -- the reference's own 2-ulp expf moves the same pixels against any other exp,
-    and SURVEY.md 8(d) sets aside a 1e-5 share of elements for such predicate flips."""
+    and SURVEY.md 8(d) sets aside a 1e-5 share of elements for such predicate flips.  Colour and final_T move by at most
+    that weight; depth = D / acc (acc > 0.5) by at most 2 x 1e-2 x the depth of the farthest visible Gaussian, which
+    may be many times the largest value of the depth image (splats crowding the near plane)."""
     from bloomscene_amd import _capi
     assert _capi.get_option("exact_exp") == 0
     rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
@@ -57,19 +59,29 @@ def _compare_default_with_exact(c, st, label):
     assert n_flip <= 2 + 1e-5 * flips.size, (label, n_flip, flips.size)
     fl = flips.reshape(c.H, c.W)
     col, dep = color.cpu().numpy(), depth.cpu().numpy()
+    # the other decision a pixel's ulps can move: the depth output is D / acc only where acc > 0.5 (else 0), and
+    # acc = 1 - final_T + 1e-6 -- a pixel whose final_T sits within ulps of 0.5 has a depth in one mode and 0 in the other
+    valid_moved = ((dep[0] == 0.0) != (st.depth[0] == 0.0)) & (np.abs(st.final_T.reshape(c.H, c.W) - 0.5) <= 1e-5)
+    assert int(valid_moved.sum()) <= 2 + 1e-5 * flips.size, (label, int(valid_moved.sum()))
     worst = {}
     for name, got, ref in (("color", col, st.color), ("depth", dep, st.depth),
                            ("final_T", b.final_T.reshape(1, c.H, c.W), st.final_T.reshape(1, c.H, c.W))):
         scale = max(float(np.abs(ref).max()), 1e-30)
         err = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / scale
-        m = np.broadcast_to(fl, err.shape)
+        m = np.broadcast_to(fl | valid_moved if name == "depth" else fl, err.shape)
         worst[name] = float(err[~m].max()) if (~m).any() else 0.0
         assert worst[name] <= 2e-5, (label, name, worst[name])
-        if m.any():
-            assert float(err[m].max()) <= (5e-2 if name == "depth" else 1.1e-2), (label, name, float(err[m].max()))
-    print(f"[fast-exp] {label:24s} stop decisions moved on {n_flip} of {flips.size} pixels; max err / scale: "
-          + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
-    return n_flip
+        if m.any() and name == "depth":
+            vis = st.radii > 0
+            z_far = max(float(st.depths[vis].max()) if vis.any() else 0.0, scale)
+            mm = np.broadcast_to(fl & ~valid_moved, err.shape)
+            if mm.any():
+                assert float(err[mm].max()) * scale <= 2.2e-2 * z_far, (label, name, float(err[mm].max()), z_far)
+        elif m.any():
+            assert float(err[m].max()) <= 1.1e-2, (label, name, float(err[m].max()))
+    print(f"[fast-exp] {label:24s} stop decisions moved on {n_flip}, depth validity on {int(valid_moved.sum())} of "
+          f"{flips.size} pixels; max err / scale: " + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    return n_flip + int(valid_moved.sum())
 
 
 @pytest.mark.fast_exp
@@ -80,7 +92,7 @@ def test_default_forward_against_oracle_and_exact_mode(name):
     _compare_default_with_exact(c, st, name)
 
 
-# cases of round 3's soaks (7 of ~5 200 default-mode cases) whose colour or depth left the 2e-5 band: a pixel whose
+# cases of round 3's soaks (8 of ~8 000 default-mode cases) whose colour or depth left the 2e-5 band: a pixel whose
 # `T (1 - alpha) < 1e-4` stop lands on the other side with a T that differs by ulps
 STOP_MOVED = {
     "soak_big_250k_cov_precomp": dict(P=250000, W=1850, H=645, deg=1, seed=201190006, scale_mul=2.186471765599889,
@@ -92,6 +104,10 @@ STOP_MOVED = {
                                        scale_modifier=1.9),
     "soak_mixed_40k": dict(P=40000, W=240, H=190, deg=2, seed=951567977, scale_mul=6.782460180023914, near_fraction=0.1,
                            scale_modifier=1.9),
+    # third soak: NOT a stop -- a pixel whose accumulated opacity sits within ulps of the 0.5 below which the depth output
+    # is 0 (forward: depth = acc > 0.5 ? D / acc : 0): it has a depth in one mode and none in the other
+    "soak3_40k_depth_validity_threshold": dict(P=40000, W=371, H=258, deg=1, seed=893405730, scale_mul=3.087722131808848,
+                                          near_fraction=0.6, scene="b", view=16),
 }
 
 
@@ -100,7 +116,7 @@ STOP_MOVED = {
 def test_default_forward_where_a_stop_decision_moves(name):
     """The default mode's T differs from the exact mode's by ulps, so the reference's early stop (forward.cu:433-437)
     can fall one entry earlier or later on a pixel whose T (1 - alpha) sits within those ulps of 1e-4: the stopping
-    entry is blended or not.  Here it does (found by the soaks: 7 of ~5 200 default-mode cases, one to four pixels each); the
+    entry is blended or not.  Here it does (found by the soaks: 8 of ~8 000 default-mode cases, one to four pixels each); the
     pixel count and the size of the change are bounded (_compare_default_with_exact), everything else stays inside
     2e-5 of scale."""
     c = Hh.make_case(**STOP_MOVED[name])

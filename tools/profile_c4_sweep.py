@@ -31,13 +31,15 @@ def main():
     bufs = {k: getattr(sc, k).to(dev) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
     if a.shift_y:
         bufs["means3D"][:, 1] += a.shift_y
-    pack = views.CameraPack([c.to(dev) for c in sc.cameras], dev)
+    cams = [c.to(dev) for c in sc.cameras]
+    pack = views.CameraPack(cams, dev)
     bg = torch.zeros(3, device=dev)
     ts = []
     for _ in range(a.reps + 2):
         torch.cuda.synchronize()
         t = time.perf_counter()
-        views.render_views_sharded(pack, bufs, bg, 3, rank=0, world=1, batch=a.batch, compact=a.compact)
+        views.render_views_sharded(cams if a.batch == 1 else pack, bufs, bg, 3, rank=0, world=1, batch=a.batch,
+                                   compact=a.compact)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t) * 1e3)
     print("sweep ms (median of %d): %.3f" % (a.reps, sorted(ts[2:])[a.reps // 2]))

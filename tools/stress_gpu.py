@@ -102,7 +102,9 @@ def stress_anchors(args, rng):
 
 
 def stress_views(args, rng):
-    """bsr_forward_views against per-view bsr_forward calls: bit-identical colour, depth, radii; summed count."""
+    """bsr_forward_views against per-view bsr_forward calls: bit-identical colour, depth, radii; summed count.  Also the
+    multi-view visibility filter against the per-view one (its conservative cull must never change a radius), and the
+    frames rendered from the rows the group filter kept (views.compact_for_view_groups) against the frames from all."""
     import math
     from bloomscene_amd import rasterizer as RZ
     from bloomscene_amd.views import yawed_camera
@@ -144,6 +146,26 @@ def stress_views(args, rng):
             assert torch.equal(colors[v].view(torch.int32), color.view(torch.int32)), (kw, V, v)
             assert torch.equal(depths[v].view(torch.int32), depth.view(torch.int32)), (kw, V, v)
         assert Rv == total, (kw, V)
+        vms = torch.stack([cm.world_view_transform for cm in cams])
+        pms = torch.stack([cm.full_proj_transform for cm in cams])
+        fr = RZ._rasterize_gaussians_filter_views_native(t["means3D"], t["scales"], t["rot"], c.scale_modifier, t["cov"],
+                                                         vms, pms, tfx, tfy, c.H, c.W, False)
+        for v, cm in enumerate(cams):
+            one = RZ._rasterize_gaussians_filter_native(t["means3D"], t["scales"], t["rot"], c.scale_modifier, t["cov"],
+                                                        cm.world_view_transform, cm.full_proj_transform, tfx, tfy, c.H,
+                                                        c.W, False, False)
+            assert torch.equal(fr[v], one), (kw, V, v, "multi-view filter")
+        if c.scales is not None and c.scale_modifier == 1.0:
+            from bloomscene_amd import views as VW
+            g = {"means3D": t["means3D"], "scales": t["scales"], "rotations": t["rot"], "opacities": t["opac"]}
+            g["shs" if c.shs is not None else "colors_precomp"] = t["shs"] if c.shs is not None else t["colors"]
+            groups = [list(range(0, (V + 1) // 2)), list(range((V + 1) // 2, V))]
+            subs = VW.compact_for_view_groups(cams, g, [gr for gr in groups if gr])
+            for gr, sub in zip([gr for gr in groups if gr], subs):
+                col, dep, _ = VW.render_views_batched(cams, sub, bg, c.deg, idx=gr)
+                for k, v in enumerate(gr):
+                    assert torch.equal(col[k].view(torch.int32), colors[v].view(torch.int32)), (kw, V, v, "compacted")
+                    assert torch.equal(dep[k].view(torch.int32), depths[v].view(torch.int32)), (kw, V, v, "compacted")
         n += 1
     print(f"view-batch stress ok: {n} random cases")
 
@@ -215,7 +237,7 @@ def main():
     n = 0
     worst = (0.0, None, None)
     n_cond = 0
-    worst_img, n_img_loose = 0.0, 0
+    worst_img, n_img_loose, n_valid_moved = 0.0, 0, 0
     while time.time() < t_end:
         if args.mode == "hint":
             P, W, H = 6000, 233, 141
@@ -262,13 +284,30 @@ def main():
             assert (out.depth.view(np.uint32) == st.depth.view(np.uint32)).all(), kw
         else:
             for name, a, b in (("color", out.color, st.color), ("depth", out.depth, st.depth)):
-                e = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))
+                diff = np.abs(a.astype(np.float64) - b.astype(np.float64))
+                if name == "depth":
+                    # depth = acc > 0.5 ? D / acc : 0 with acc = 1 - final_T + 1e-6: a pixel whose final_T sits within
+                    # ulps of 0.5 has a depth in one mode and 0 in the other -- counted, not compared
+                    moved = ((a[0] == 0.0) != (b[0] == 0.0)) & (np.abs(st.final_T.reshape(c.H, c.W) - 0.5) <= 1e-5)
+                    assert int(moved.sum()) <= 2 + 1e-5 * moved.size, (name, int(moved.sum()), kw)
+                    n_valid_moved += int(moved.sum())
+                    diff = np.where(moved[None], 0.0, diff)
+                d_abs = float(diff.max())
+                e = d_abs / max(float(np.abs(b).max()), 1e-30)
                 worst_img = max(worst_img, e)
                 # 2e-5 of scale unless a `T (1 - alpha) < 1e-4` stop moved: the stopping entry is then blended in one mode
-                # and not in the other (the reference does not blend it), a change of up to alpha T < 1e-2 at the 0.99
-                # clamp; a pixel's depth = D / acc moves with it.  tests/test_round3_gpu.py pins the cases found so
-                # far and checks there that it IS a moved stop, pixel by pixel.
-                assert e <= (1.1e-2 if name == "color" else 5e-2), (name, e, kw)
+                # and not in the other (the reference does not blend it), a change of weight alpha T < 1e-2 at the 0.99
+                # clamp.  A colour moves by at most that; a pixel's depth = D / acc (acc > 0.5) by at most 2 x 1e-2 x the
+                # depth of the FARTHEST visible Gaussian -- which on a scene with most splats at the near plane is many
+                # times the largest value of the depth image itself (soak 3: 5.6 % of the image's maximum).
+                # tests/test_round3_gpu.py pins the cases found so far and checks there that it IS a moved stop, pixel by
+                # pixel.
+                if name == "color":
+                    assert e <= 1.1e-2, (name, e, kw)
+                else:
+                    vis = st.radii > 0
+                    z_far = float(st.depths[vis].max()) if vis.any() else 0.0
+                    assert d_abs <= 2.2e-2 * max(z_far, float(np.abs(b).max())), (name, e, d_abs, z_far, kw)
                 if e > 2e-5:
                     n_img_loose += 1
                     print(f"  image outside 2e-5 of scale ({name} {e:.1e}): {kw}", flush=True)
@@ -290,7 +329,8 @@ def main():
         n += 1
     print(f"stress ok: {n} random cases ({n_cond} tensors judged by conditioning), "
           f"worst gradient error / scale = {worst[0]:.2e} ({worst[1]}, {worst[2]}); default-mode images: worst error / "
-          f"scale {worst_img:.1e}, {n_img_loose} images above 2e-5 (a stop decision moved)")
+          f"scale {worst_img:.1e}, {n_img_loose} images above 2e-5 (a stop decision moved), {n_valid_moved} pixels whose "
+          f"depth validity (acc > 0.5) moved")
 
 
 if __name__ == "__main__":
