@@ -54,15 +54,15 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.depth = (float*)p;
 	return g;
 }
-// The backward's slab (SIZED at 48 B per instance; its rows are 36 B, 40 B with the depth gradient: the reader's last
-// 16-byte load of a run may reach 12 B past it) lives in the caller's binning buffer too, over the radix ping-pong
+// The backward's slab (sized at 40 B per instance + 16: its rows are 36 B, 40 B with the depth gradient, and the
+// reader's last 16-byte load of a run may reach 12 B past it) lives in the caller's binning buffer too, over the radix ping-pong
 // buffers, which are dead once the forward has returned: the library owns no device memory, as in the reference,
 // where every byte of scratch comes from the caller's resize callbacks (rasterize_points.cu:27-33).
 // with_slab = false (view-batched forward: inference only) sizes the section for the ping-pong buffers alone.
 static size_t bin_work_bytes(size_t R, bool with_slab)
 {
 	const size_t pingpong = 2 * align_up(R * sizeof(BinElem), 256);
-	const size_t slab = with_slab ? align_up(R * 48, 256) : 0;
+	const size_t slab = with_slab ? align_up(R * BSR_SLAB_ROW_BYTES + BSR_SLAB_TAIL_BYTES, 256) : 0;
 	return pingpong > slab ? pingpong : slab;
 }
 size_t BinState::bytes(size_t R, bool with_slab)
@@ -456,10 +456,10 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		sc->last_R = h_R > decayed ? h_R : decayed;
 	}
 	// The backward is handed R, not the capacity this call carved with: it finds point_list at the buffer's start and
-	// puts its slab (48 B per KEPT instance) right behind point_list[R].  A guessed buffer serves it only if that
+	// puts its slab (up to 40 B per KEPT instance) right behind point_list[R].  A guessed buffer serves it only if that
 	// R-based carve ends inside it -- with kept <= cap < R the slab could otherwise run past the end (cap + 512 Ki < R
 	// is enough to get past the 2 MB of histogram space behind the work section).
-	const bool backward_fits = V != 1 || align_up((size_t)R * sizeof(uint32_t), 256) + align_up((size_t)h_kept * 48, 256) <=
+	const bool backward_fits = V != 1 || align_up((size_t)R * sizeof(uint32_t), 256) + align_up((size_t)h_kept * BSR_SLAB_ROW_BYTES + BSR_SLAB_TAIL_BYTES, 256) <=
 	                                         BinState::bytes(cap, true) - 256;
 	if (!guess || (size_t)h_kept > cap || !backward_fits) {
 		// first call of this shape, more kept instances than the guessed scratch holds (the kernels of the first
@@ -776,7 +776,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	ImgState img = ImgState::carve(image_buffer, N, (size_t)T);
 	BinState bin = BinState::carve(binning_buffer, (size_t)(R > 0 ? R : 0), true);
 
-	// slab[R][12] f32: per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows), in the
+	// slab[R][9 or 10] f32 (tight rows): per-instance partial sums, Gaussian-major (kept instances only use the first R_kept rows), in the
 	// caller's binning buffer over the forward's dead radix ping-pong buffers.  The forward sized the buffer for R or for
 	// a guessed capacity it checked against this very carve (forward_impl: backward_fits): point_list[R], then the rows
 	// of the kept instances, end inside it.

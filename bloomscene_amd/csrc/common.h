@@ -51,6 +51,8 @@ typedef float bsr_f32x2 __attribute__((ext_vector_type(2)));
 typedef bsr_f32x4 bsr_f32x4_a4 __attribute__((aligned(4)));
 typedef bsr_f32x2 bsr_f32x2_a4 __attribute__((aligned(4)));
 __host__ __device__ __forceinline__ constexpr int slab_row_floats(bool depth_grad) { return depth_grad ? 10 : 9; }
+#define BSR_SLAB_ROW_BYTES 40   // what the binning buffer reserves per instance (the wider row) ...
+#define BSR_SLAB_TAIL_BYTES 16  // ... plus the 12 B a reader's last 16-byte load may reach past a run
 typedef uint32_t bsr_u32x3 __attribute__((ext_vector_type(3)));
 typedef bsr_u32x3 bsr_u32x3_a4 __attribute__((aligned(4)));
 __device__ __forceinline__ BinElem load_elem(const BinElem* p)

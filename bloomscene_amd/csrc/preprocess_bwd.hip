@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 			for (uint32_t c0 = 0; c0 < total; c0 += stage_rows) {
 				const uint32_t n_rows = min(stage_rows, total - c0);
 				const uint32_t n_f4 = (n_rows * rowf + 3u) >> 2;   // (the last one may read up to 12 B past the run: the slab
-				                                                   //  is sized at 48 B per row, api.hip)
+				                                                   //  carries 16 spare bytes, api.hip)
 				const bsr_f32x4_a4* const s = reinterpret_cast<const bsr_f32x4_a4*>(src + (size_t)c0 * rowf);
 				for (uint32_t i0 = 0; i0 < n_f4; i0 += 256) {   // four 1-KiB loads in flight per trip
 					const uint32_t i = i0 + (uint32_t)lane;

@@ -322,7 +322,7 @@ int bsr_backward_depth(int P, int D, int M, int R,
 /* Scratch sizes, for callers that pre-allocate instead of growing inside the callback
  * (the reference's required<T>(n), cuda_rasterizer/rasterizer_impl.h:68-73). */
 size_t bsr_geometry_bytes(int P);
-size_t bsr_binning_bytes(int num_rendered);   /* 52 B / instance + 2 MB: point list, radix ping-pong buffers = backward slab */
+size_t bsr_binning_bytes(int num_rendered);   /* 44 B / instance + 2 MB: point list, radix ping-pong buffers = backward slab */
 size_t bsr_image_bytes(int width, int height);
 
 /* Byte offset, inside the image buffer a forward call filled, of its float final_T[height * width] (the

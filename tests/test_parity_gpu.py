@@ -685,7 +685,7 @@ def test_library_owns_no_device_memory():
     outside0 = total - free0 - torch.cuda.memory_reserved()
     alloc0 = torch.cuda.memory_allocated()
     rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
-    assert bb.numel() >= _capi.lib().bsr_binning_bytes(R) >= 52 * R
+    assert bb.numel() >= _capi.lib().bsr_binning_bytes(R) >= 44 * R
     out, M = _raw_backward(c, rs, t, R, radii, gb, bb, ib, c.gC, c.gD)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
@@ -693,7 +693,7 @@ def test_library_owns_no_device_memory():
     # (growth only: the HIP runtime may RELEASE memory of its own meanwhile -- kernel scratch of earlier tests in this
     # process was seen to shrink by 400 MB here -- which says nothing about the library)
     assert outside1 - outside0 < (8 << 20), (outside0, outside1)
-    assert torch.cuda.max_memory_allocated() - alloc0 >= 52 * R          # the scratch is on torch's books
+    assert torch.cuda.max_memory_allocated() - alloc0 >= 44 * R          # the scratch is on torch's books
     assert np.isfinite(out["mean3D"]).all()
 
 

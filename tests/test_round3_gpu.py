@@ -178,7 +178,7 @@ class _CanaryScratch:
 
 def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
     """the forward may size the binning buffer from a guess `cap` and keep it when the KEPT instances
-    fit; the backward carves it for R = num_rendered (it is not told cap) and writes 48 B per kept instance behind
+    fit; the backward carves it for R = num_rendered (it is not told cap) and writes up to 40 B per kept instance behind
     point_list[R].  With kept <= cap and cap + 512 Ki < R that ran past the buffer.  Here: a 1 M-Gaussian view with R1
     instances, then the same shape with all scales multiplied so that kept2 <= 1.25 R1 + 4096 while point_list[R2] plus
     the slab rows end behind the guessed buffer; every scratch buffer carries a canary behind the bytes the library asked for, which forward + backward must
@@ -206,8 +206,8 @@ def test_backward_slab_stays_inside_a_guessed_binning_buffer(monkeypatch):
     cap = R1 + R1 // 4 + 4096
     guess_bytes = int(_capi.lib().bsr_binning_bytes(cap))
 
-    def carve_end(R, kept):   # where the backward's R-based carve ends: point_list[R], then 48 B per kept instance
-        return (4 * R + 255) // 256 * 256 + 48 * kept
+    def carve_end(R, kept):   # where the backward's R-based carve ends: point_list[R], then 40 B per kept instance + 16
+        return (4 * R + 255) // 256 * 256 + 40 * kept + 16
 
     # the dangerous window: the kept instances still fit the guess (no re-run for THAT reason) but the R-based carve of
     # the backward ends behind the guessed buffer; with kept / R ~ 0.62 that is R2 ~ 1.54 .. 1.61 x the guess
