@@ -92,7 +92,7 @@ def test_default_forward_against_oracle_and_exact_mode(name):
     _compare_default_with_exact(c, st, name)
 
 
-# cases of round 3's soaks (8 of ~8 000 default-mode cases) whose colour or depth left the 2e-5 band: a pixel whose
+# cases of round 3's soaks (22 of ~9 800 default-mode cases) whose colour or depth left the 2e-5 band: a pixel whose
 # `T (1 - alpha) < 1e-4` stop lands on the other side with a T that differs by ulps
 STOP_MOVED = {
     "soak_big_250k_cov_precomp": dict(P=250000, W=1850, H=645, deg=1, seed=201190006, scale_mul=2.186471765599889,
@@ -116,7 +116,7 @@ STOP_MOVED = {
 def test_default_forward_where_a_stop_decision_moves(name):
     """The default mode's T differs from the exact mode's by ulps, so the reference's early stop (forward.cu:433-437)
     can fall one entry earlier or later on a pixel whose T (1 - alpha) sits within those ulps of 1e-4: the stopping
-    entry is blended or not.  Here it does (found by the soaks: 8 of ~8 000 default-mode cases, one to four pixels each); the
+    entry is blended or not.  Here it does (found by the soaks: 22 of ~9 800 default-mode cases, one to four pixels each); the
     pixel count and the size of the change are bounded (_compare_default_with_exact), everything else stays inside
     2e-5 of scale."""
     c = Hh.make_case(**STOP_MOVED[name])
