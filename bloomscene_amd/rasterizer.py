@@ -322,7 +322,8 @@ def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_
     if group_of_view.numel() != V:
         raise RuntimeError("group_of_view must hold one group id per view")
     mask = torch.empty((int(n_groups), P), dtype=torch.bool, device=dev)
-    counts = torch.zeros((int(n_groups),), dtype=torch.int32, device=dev) if return_counts else None
+    # (every count is written by the call; only the P = 0 shortcut below leaves the library out)
+    counts = (torch.empty if P != 0 else torch.zeros)((int(n_groups),), dtype=torch.int32, device=dev) if return_counts else None
     if P != 0 and n_groups != 0:
         m = _dev_f32(means3D, "means3D", dev)
         s, r = _dev_f32(scales, "scales", dev), _dev_f32(rotations, "rotations", dev)

@@ -13,6 +13,7 @@ decoded Gaussians; ``render_neural`` starts one step earlier, at the outputs of 
 """
 from __future__ import annotations
 
+import functools
 import math
 import time
 
@@ -238,6 +239,12 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     return local, my_views, info
 
 
+@functools.lru_cache(maxsize=32)
+def _group_ids(sizes, dev_str):
+    """int32 device tensor [sum(sizes)]: group g repeated sizes[g] times (uploaded once per grouping, not per call)."""
+    return torch.tensor([g for g, n in enumerate(sizes) for _ in range(n)], dtype=torch.int32).to(dev_str)
+
+
 def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier: float = 1.0, debug=False,
                      return_counts=False):
     """bool [len(groups), P]: row g = "some camera of groups[g] (a list of indices into ``cams``) sees the Gaussian",
@@ -251,7 +258,7 @@ def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier:
         z = torch.zeros((len(groups), means3D.shape[0]), dtype=torch.bool, device=dev)
         return (z, torch.zeros((len(groups),), dtype=torch.int32, device=dev)) if return_counts else z
     vms, pms, _, c0 = _camera_stack(cams, order, dev)
-    gid = torch.tensor([g for g, members in enumerate(groups) for _ in members], dtype=torch.int32)
+    gid = _group_ids(tuple(len(members) for members in groups), str(dev))
     with torch.no_grad():
         return _rasterize_gaussians_filter_groups_native(
             means3D, scales[:, :3], rotations, scaling_modifier, torch.Tensor([]), vms, pms,
