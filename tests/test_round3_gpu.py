@@ -401,6 +401,44 @@ def test_frames_from_scattered_visible_subsets_equal_frames_from_all_gaussians()
     assert all(0 < c < 60000 for c in results[0][2])      # each rank got a strict subset
 
 
+@pytest.mark.parametrize("shape", ["dense_tiles", "sparse_tiles"])
+def test_results_do_not_depend_on_the_order_of_the_gaussians(shape):
+    """A size-independent property of the whole pipeline: a pixel blends its Gaussians in depth order and every
+    per-Gaussian gradient is summed in tile order, so PERMUTING the input rows changes nothing -- image and depth bit
+    for bit, radii and gradients the same rows permuted (exact mode; a pair of equal depths would be ordered by id and
+    could move a last bit, so the depths are checked to be distinct).  Numbering, workgroup composition, histogram
+    columns, slab runs, the wave-private staging and the counting sort of small tiles all see different data."""
+    from bloomscene_amd import _capi
+    kw = dict(P=200_000, W=801, H=601, deg=2, seed=9, scale_mul=2.5) if shape == "dense_tiles" else \
+        dict(P=30_000, W=1280, H=720, deg=1, seed=10, scale_mul=1.0, scene="b", view=5)
+    c = Hh.make_case(**kw)
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(8):   # separate Gaussians of equal view depth (200 k float32 depths in [1, 10) collide by birthday)
+        st, _ = Hh.run_oracle(c, backward=False)
+        d = np.where(st.radii > 0, st.depths, -np.arange(c.P, dtype=np.float32) - 1.0)   # culled ones: distinct dummies
+        _, first, counts = np.unique(d, return_index=True, return_counts=True)
+        if (counts == 1).all():
+            break
+        tied = np.setdiff1d(np.arange(c.P), first[counts == 1])
+        c.means3D[tied] += (torch.rand(len(tied), 3, generator=gen) - 0.5) * 2.0e-3
+    perm = torch.randperm(c.P, generator=gen)
+    c2 = Hh.make_case(**kw)
+    c2.means3D = c.means3D.clone()
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        setattr(c2, k, getattr(c, k)[perm].contiguous())
+    assert _capi.get_option("exact_exp") == 1
+    a, b = Hh.run_hip(c), Hh.run_hip(c2)
+    vis_depths = st.depths[st.radii > 0]
+    assert np.unique(vis_depths).size == vis_depths.size
+    np.testing.assert_array_equal(a.color.view(np.uint32), b.color.view(np.uint32))
+    np.testing.assert_array_equal(a.depth.view(np.uint32), b.depth.view(np.uint32))
+    p = perm.numpy()
+    np.testing.assert_array_equal(a.radii[p], b.radii)
+    assert 0 < int((a.radii > 0).sum()) < c.P or shape == "dense_tiles"
+    for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+        np.testing.assert_array_equal(getattr(a.grads, k)[p].view(np.uint32), getattr(b.grads, k).view(np.uint32), err_msg=k)
+
+
 def test_sweep_with_per_batch_compaction_renders_the_same_frames():
     """views.render_views_sharded(batch > 1, compact=True): each batch of views is rendered from the rows its own
     visibility filter kept (one filter pass + one gather for the whole path) -- frames and depths bit-identical to the
