@@ -1,5 +1,5 @@
 // A consumer of the C ABI that knows nothing about torch or python: plain hipMalloc'd buffers, C callbacks for
-// the three scratch buffers, bsr_forward + bsr_backward through include/bloomscene_rast.h.  This is the shape
+// the three scratch buffers, bsr_forward + bsr_backward (+ the camera-sweep helpers: group filter, row gathers) through include/bloomscene_rast.h.  This is the shape
 // of the binding a maintainer of the reference would write in rasterize_points.cu (option B).
 // tests/test_abi_native_gpu.py feeds it a seeded scene and compares what it writes with the CPU oracle.
 //
@@ -139,6 +139,66 @@ int main(int argc, char** argv)
 	                  use_sh ? g_sh : nullptr, g_scale, g_rot, 0, stream);
 	if (rc != 0) { fprintf(stderr, "bsr_backward: %s\n", bsr_last_error()); return 1; }
 	HIP_OK(hipStreamSynchronize(stream));
+
+	// ---- the camera-sweep helpers through the same header: group filter (this one camera as a path of one view in one
+	// group) + its row count, then the rows it kept gathered both ways; checked here against the forward's radii and a
+	// gather on the host
+	{
+		std::vector<int> h_radii((size_t)P);
+		HIP_OK(hipMemcpy(h_radii.data(), radii, (size_t)P * sizeof(int), hipMemcpyDeviceToHost));
+		int group0 = 0;
+		int* d_group = nullptr;
+		uint8_t* d_mask = nullptr;
+		uint32_t* d_count = nullptr;
+		HIP_OK(hipMalloc((void**)&d_group, sizeof(int)));
+		HIP_OK(hipMemcpy(d_group, &group0, sizeof(int), hipMemcpyHostToDevice));
+		HIP_OK(hipMalloc((void**)&d_mask, (size_t)P + 16));
+		HIP_OK(hipMalloc((void**)&d_count, sizeof(uint32_t)));
+		rc = bsr_visible_filter_groups(P, 1, 1, W, H, d_means, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, fl[0], fl[1],
+		                               d_group, d_mask, d_count, 0, stream);
+		if (rc != 0) { fprintf(stderr, "bsr_visible_filter_groups: %s\n", bsr_last_error()); return 1; }
+		HIP_OK(hipStreamSynchronize(stream));
+		std::vector<uint8_t> h_mask((size_t)P);
+		uint32_t h_count = 0;
+		HIP_OK(hipMemcpy(h_mask.data(), d_mask, (size_t)P, hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(&h_count, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+		std::vector<int64_t> idx;
+		for (int i = 0; i < P; i++) {
+			if ((h_mask[(size_t)i] != 0) != (h_radii[(size_t)i] > 0)) { fprintf(stderr, "group mask != radii > 0 at %d\n", i); return 1; }
+			if (h_mask[(size_t)i]) idx.push_back(i);
+		}
+		if (h_count != idx.size()) { fprintf(stderr, "group count %u != %zu\n", h_count, idx.size()); return 1; }
+		const int R = (int)idx.size();
+		if (R > 0) {
+			int64_t* d_idx = to_device(idx);
+			const float* srcs[3] = {d_means, d_op, d_rot};
+			const int widths[3] = {3, 1, 4};
+			float* packed = device_out<float>((size_t)R * 8);
+			float* each[3] = {device_out<float>((size_t)R * 3), device_out<float>((size_t)R), device_out<float>((size_t)R * 4)};
+			if (!d_idx || !packed || !each[0] || !each[1] || !each[2]) { fprintf(stderr, "device allocation failed\n"); return 2; }
+			rc = bsr_pack_rows(R, P, 3, srcs, widths, d_idx, 1, packed, 0, stream);
+			if (rc != 0) { fprintf(stderr, "bsr_pack_rows: %s\n", bsr_last_error()); return 1; }
+			rc = bsr_gather_rows(R, P, 3, srcs, widths, d_idx, 1, each, 0, stream);
+			if (rc != 0) { fprintf(stderr, "bsr_gather_rows: %s\n", bsr_last_error()); return 1; }
+			HIP_OK(hipStreamSynchronize(stream));
+			std::vector<float> h_packed((size_t)R * 8), h0((size_t)R * 3), h1((size_t)R), h2((size_t)R * 4);
+			HIP_OK(hipMemcpy(h_packed.data(), packed, h_packed.size() * 4, hipMemcpyDeviceToHost));
+			HIP_OK(hipMemcpy(h0.data(), each[0], h0.size() * 4, hipMemcpyDeviceToHost));
+			HIP_OK(hipMemcpy(h1.data(), each[1], h1.size() * 4, hipMemcpyDeviceToHost));
+			HIP_OK(hipMemcpy(h2.data(), each[2], h2.size() * 4, hipMemcpyDeviceToHost));
+			for (int r = 0; r < R; r++) {
+				const size_t i = (size_t)idx[(size_t)r];
+				float want[8] = {means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i],
+				                 rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+				if (memcmp(want, &h_packed[(size_t)r * 8], sizeof(want)) != 0 || memcmp(want, &h0[(size_t)r * 3], 12) != 0 ||
+				    memcmp(want + 3, &h1[(size_t)r], 4) != 0 || memcmp(want + 4, &h2[(size_t)r * 4], 16) != 0) {
+					fprintf(stderr, "gathered row %d differs\n", r);
+					return 1;
+				}
+			}
+		}
+		printf("sweep helpers ok: %u of %d rows kept by the group filter, packed and gathered\n", h_count, P);
+	}
 
 	FILE* fo = fopen(argv[2], "wb");
 	if (!fo) { perror(argv[2]); return 2; }

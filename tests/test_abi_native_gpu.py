@@ -42,7 +42,7 @@ def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
             _f32(a).tofile(f)
     r = subprocess.run([EXE, str(inp), str(outp), "exact"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi_roundtrip ok" in r.stdout
+    assert "abi_roundtrip ok" in r.stdout and "sweep helpers ok" in r.stdout
     N = W * H
     with open(outp, "rb") as f:
         nr = int(np.fromfile(f, np.int32, 1)[0])
