@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, cons
 			}
 			if (radii != nullptr) radii[(size_t)v * P + wave_base + src] = radius_out;
 			if (group_mask != nullptr && radius_out > 0) {
-				const int g = group_of_view[v];
+				const int g = group_of_view[v] & 63;   // (an id outside [0, 64) must not index past the wave's LDS words)
 				atomicOr(&L.seen[g >> 5][src], 1u << (g & 31));
 			}
 		}
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(256) k_visible_filter_views(int P, int V, cons
 		bool cand = valid;
 		if (groups_only) {
 			// a group some earlier view already marked needs no further test (bits land with a queue's delay: harmless)
-			const int g = group_of_view[v];
+			const int g = group_of_view[v] & 63;
 			cand = cand && !((L.seen[g >> 5][lane] >> (g & 31)) & 1u);
 		}
 		const float pvz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];

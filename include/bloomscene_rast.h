@@ -201,7 +201,8 @@ int bsr_visible_filter_views(int P, int n_views,
 
 /* EXTENSION (views.scatter_visible_gaussians): the same per-view test as bsr_visible_filter_views, reduced on the fly to
  * one mask per GROUP of views: group_mask[g][i] (uint8 [n_groups, P], fully written) = 1 iff some view v with
- * group_of_view[v] == g has radii > 0 for Gaussian i.  group_of_view: DEVICE int[n_views], values in [0, n_groups),
+ * group_of_view[v] == g has radii > 0 for Gaussian i.  group_of_view: DEVICE int[n_views], values in [0, n_groups)
+ * (only their low 6 bits are used),
  * n_groups <= 64.  With groups = the ranks of a view-parallel sweep this is "which Gaussians does rank g need": P
  * bytes per rank written instead of 4 P per view, and no radii > 0 / any() passes afterwards.
  * group_counts (DEVICE uint32[n_groups], may be NULL): the number of ones in each row of group_mask, written by this
