@@ -91,7 +91,9 @@ def measured_traffic(config, stage):
     try:
         with open(path) as fh:
             d = json.load(fh)
-        src = {"profile": d.get("profile"), "csrc_sha256": d.get("csrc_sha256")}
+        # kind "committed": the figure is a constant read from a profile the builder committed, taken on ANOTHER run of the
+        # same kernel sources -- NOT a measurement of the run this line reports (rocprofv3 --pmc cannot run inside it)
+        src = {"kind": "committed", "profile": d.get("profile"), "csrc_sha256": d.get("csrc_sha256")}
         if d.get("csrc_sha256") != csrc_sha256():
             return None, None, dict(src, matches_timed_build=False)
         e = d[config][stage]
@@ -562,8 +564,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (N = 1) workloads")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--exact-exp", action="store_true",
-                    help="bsr_set_option('exact_exp', 1): the pinned exp on every evaluation of the forward blend (bit-equal "
-                         "to the CPU oracle); the metric is quoted on the library's default")
+                    help="BSR_FLAG_EXACT_EXP on every call: the pinned exp on every evaluation of the forward blend "
+                         "(bit-equal to the CPU oracle); the metric is quoted on the library's default")
+    ap.add_argument("--strict-gradients", action="store_true",
+                    help="BSR_FLAG_EXACT_GRAD on every call: the reference's per-pair operations in the backward tile "
+                         "walk (meets SURVEY 8(d)'s elementwise gradient bar); the metric is quoted on the default")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run for this long BEFORE the W warm-up steps of the headline workload, so that the "
                          "GPU clocks have ramped when the K timed steps start (reported as prewarm_steps)")
@@ -574,8 +579,10 @@ def main():
     from bloomscene_amd import _capi
     if args.lib:
         _capi.use_library(args.lib)
-    if args.exact_exp:
-        _capi.set_option("exact_exp", 1)
+    if args.exact_exp or args.strict_gradients:
+        # per-call flags, taken by every rasterizer call of this (main) thread from its numerics context
+        from bloomscene_amd import numerics
+        numerics(exact_exp=args.exact_exp, strict_gradients=args.strict_gradients).__enter__()
     D = Dist(args.gpus)
     P, W, H, deg, do_bwd = CONFIGS[args.config]
     if args.gaussians:
@@ -586,12 +593,31 @@ def main():
     r = raster_workload(D, args, P, W, H, deg, do_bwd, precomp=precomp, scale_mul=args.scale_mul,
                         cycle_views=args.cycle_views, label=args.config, allreduce=args.allreduce_grads,
                         depth_gradient=args.depth_gradient)
+    leg_failed = [False]
+
     def guarded(fn, *a, **kw):
-        # the secondary legs must not cost the headline its line: an exception there is reported in the leg's place
+        # The secondary legs must not cost the headline its line: an exception there is reported in the leg's place.
+        # With several ranks the legs hold collectives, so the ranks must leave a failed leg TOGETHER: after every leg
+        # each rank contributes its error flag to one MAX all-reduce, and once any rank has failed no rank starts another
+        # leg.  That covers the failures that happen on every rank at the same point (an exception in code all
+        # ranks run on same-sized data); a rank that fails alone INSIDE a leg still leaves its peers in that leg's
+        # collective until the process group's 300 s patience runs out.
+        if leg_failed[0]:
+            return {"error": "skipped: an earlier secondary leg failed on some rank"}
         try:
-            return fn(*a, **kw)
+            res = fn(*a, **kw)
+            err = None
         except Exception as exc:   # noqa: BLE001
-            return {"error": f"{type(exc).__name__}: {exc}"}
+            res, err = None, {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            failed_somewhere = D.max_over_ranks(0.0 if err is None else 1.0) > 0.0
+        except Exception as exc:   # noqa: BLE001  (the ranks are out of step: no further collective from this rank)
+            failed_somewhere = True
+            err = err or {"error": f"{type(exc).__name__}: {exc}"}
+        if failed_somewhere:
+            leg_failed[0] = True
+            return err or {"error": "abandoned: this leg failed on another rank"}
+        return res
     c4 = None if args.no_c4 else guarded(c4_sweep, D, args)
     if c4 is not None and headline and "error" not in c4:
         # the reference's own rotate360 preset: 180 views, 2 degrees apart (utils/trajectory.py:102-126)
@@ -639,7 +665,7 @@ def main():
                        "parallelism": f"view-parallel x{D.world}" + (" + gradient all-reduce" if args.allreduce_grads
                                                                       and D.multi and do_bwd else ""),
                        "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256(),
-                       "exact_exp": int(_capi.get_option("exact_exp"))},
+                       "exact_exp": int(args.exact_exp), "strict_gradients": int(args.strict_gradients)},
             "ms_per_step_median": round(r["ms_per_step_median"], 4),
             # every timed step on the GPU's clock (event to event), in order, when there are few enough to list
             "step_ms": r["step_ms"],

@@ -10,5 +10,6 @@ from .rasterizer import (  # noqa: F401
     GaussianRasterizer,
     rasterize_gaussians,
 )
+from .numerics import numerics  # noqa: F401  (thread-local default of the per-call numerics flags)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "numerics"]

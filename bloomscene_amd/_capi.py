@@ -33,10 +33,14 @@ SIGNATURES = {
                               C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, C.c_float, _F, _F,
                               _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int, C.c_void_p,
                               C.POINTER(C.c_int)]),
+    "bsr_forward_ex": (C.c_int, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
+                                 C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, C.c_float, _F, _F,
+                                 _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_int)] + [C.c_uint]),
     "bsr_forward_views": (C.c_int, [ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F,
                                     C.c_float, _F, _F, _F, _F, _F, C.c_float, C.c_float, C.c_int, _F, _F, _F, C.c_int,
-                                    C.c_void_p, C.POINTER(C.c_int)]),
+                                    C.c_void_p, C.POINTER(C.c_int), C.c_uint]),
     "bsr_visible_filter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                      C.c_float, C.c_float, C.c_int, _F, C.c_int, C.c_void_p]),
     "bsr_visible_scratch_bytes": (C.c_size_t, [C.c_int]),
@@ -45,8 +49,9 @@ SIGNATURES = {
                                              C.c_void_p]),
     "bsr_visible_filter_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
                                            C.c_float, C.c_float, _F, C.c_int, C.c_void_p]),
+    "bsr_visible_groups_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "bsr_visible_filter_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_float, _F, _F, _F, _F,
-                                            C.c_float, C.c_float, _F, _F, _F, C.c_int, C.c_void_p]),
+                                            C.c_float, C.c_float, _F, _F, _F, _F, C.c_int, C.c_void_p]),
     "bsr_pack_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _F, C.c_int, _F, C.c_int,
                                 C.c_void_p]),
     "bsr_gather_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _F, C.c_int,
@@ -57,6 +62,9 @@ SIGNATURES = {
     "bsr_backward_depth": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
                                      _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
                                      _F, _F, _F, _F, _F, _F, C.c_int, C.c_void_p]),
+    "bsr_backward_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
+                                  _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
+                                  _F, _F, _F, _F, _F, _F, C.c_int, C.c_void_p, C.c_uint]),
     "bsr_geometry_bytes": (C.c_size_t, [C.c_int]),
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -76,10 +84,10 @@ SIGNATURES = {
     "bsr_anchor_gradient_bytes": (C.c_size_t, [C.c_int]),
     "bsr_anchor_render_forward": (C.c_int, [C.c_int, C.c_int] + [_F] * 8 + [ALLOC_FN, C.c_void_p] * 4
                                   + [_F, C.c_int, C.c_int, C.c_float, _F, _F, _F, C.c_float, C.c_float, _F, _F, C.c_int,
-                                     C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+                                     C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_uint]),
     "bsr_anchor_render_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_F] * 6 + [_F, _F, _F]
                                    + [_F, C.c_int, C.c_int, C.c_float, _F, _F, _F, C.c_float, C.c_float]
-                                   + [_F] * 3 + [_F] * 5 + [_F] + [_F] * 6 + [C.c_int, C.c_void_p]),
+                                   + [_F] * 3 + [_F] * 5 + [_F] + [_F] * 6 + [C.c_int, C.c_void_p, C.c_uint]),
 }
 
 _lib = None
@@ -120,7 +128,8 @@ def use_library(path: str):
 
 
 def set_option(name: str, value) -> None:
-    """bsr_set_option (include/bloomscene_rast.h): "exact_exp", "sort_force_int"."""
+    """bsr_set_option (include/bloomscene_rast.h): the test hook "sort_force_int".  Numerics are per call:
+    bloomscene_amd.numerics / GaussianRasterizer(exact_exp=, strict_gradients=)."""
     check(lib().bsr_set_option(name.encode(), int(bool(value))), "bsr_set_option")
 
 

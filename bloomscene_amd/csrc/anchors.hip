@@ -397,7 +397,7 @@ int bsr_anchor_render_forward(int n_anchors, int n_offsets, const float* anchor,
                               const float* background, int width, int height, float scale_modifier,
                               const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                               float tan_fovy, float* out_color, float* out_depth, int debug, void* stream,
-                              int* num_selected, int* num_rendered)
+                              int* num_selected, int* num_rendered, unsigned flags)
 {
 	if (!num_selected || !num_rendered) return fail("bsr_anchor_render_forward: num_selected / num_rendered is NULL");
 	*num_rendered = 0;
@@ -432,10 +432,11 @@ int bsr_anchor_render_forward(int n_anchors, int n_offsets, const float* anchor,
 	                      anchor_scratch, xyz, rgb, opacity, scaling, rot, stream))
 		return 1;
 	// gaussian_renderer.render's call (GR:235-262): colors_precomp, sh_degree 1 (unused without SHs), prefiltered False
-	return bsr_forward(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, S, 1, 0,
-	                   background, width, height, S ? xyz : nullptr, nullptr, S ? rgb : nullptr, S ? opacity : nullptr,
-	                   S ? scaling : nullptr, scale_modifier, S ? rot : nullptr, nullptr, viewmatrix, projmatrix, cam_pos,
-	                   tan_fovx, tan_fovy, 0, out_color, out_depth, S ? radii : nullptr, debug, stream, num_rendered);
+	return bsr_forward_ex(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, S, 1, 0,
+	                      background, width, height, S ? xyz : nullptr, nullptr, S ? rgb : nullptr, S ? opacity : nullptr,
+	                      S ? scaling : nullptr, scale_modifier, S ? rot : nullptr, nullptr, viewmatrix, projmatrix,
+	                      cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, S ? radii : nullptr, debug, stream,
+	                      num_rendered, flags);
 }
 
 int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, int num_rendered,
@@ -448,7 +449,7 @@ int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, i
                                const float* g_xyz, const float* g_color, const float* g_opacity, const float* g_scaling,
                                const float* g_rot, float* gradient_scratch, float* dL_danchor, float* dL_dgrid_scaling,
                                float* dL_dgrid_offsets, float* dL_dneural_opacity, float* dL_dcolor,
-                               float* dL_dscale_rot, int debug, void* stream)
+                               float* dL_dscale_rot, int debug, void* stream, unsigned flags)
 {
 	const int S = num_selected;
 	const size_t s = (size_t)(S > 0 ? S : 0);
@@ -460,17 +461,12 @@ int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, i
 		const int* radii = (const int*)(gaussians + 14 * s);
 		float* d_rot = gs, *d_xyz = gs + 4 * s, *d_rgb = gs + 7 * s, *d_scaling = gs + 10 * s, *d_opacity = gs + 13 * s,
 		     *d_mean2D = gs + 14 * s;
-		int rc;
-		if (out_depth)
-			rc = bsr_backward_depth(S, 1, 0, num_rendered, background, width, height, xyz, nullptr, rgb, scaling,
-			                        scale_modifier, rot, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
-			                        geom_buffer, binning_buffer, image_buffer, out_depth, dL_dpix, dL_depths, d_mean2D, nullptr,
-			                        d_opacity, d_rgb, d_xyz, nullptr, nullptr, d_scaling, d_rot, debug, stream);
-		else
-			rc = bsr_backward(S, 1, 0, num_rendered, background, width, height, xyz, nullptr, rgb, scaling, scale_modifier,
-			                  rot, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer,
-			                  binning_buffer, image_buffer, dL_dpix, dL_depths, d_mean2D, nullptr, d_opacity, d_rgb, d_xyz,
-			                  nullptr, nullptr, d_scaling, d_rot, debug, stream);
+		// (out_depth == NULL: the reference's backward; else the depth-gradient extension)
+		const int rc = bsr_backward_ex(S, 1, 0, num_rendered, background, width, height, xyz, nullptr, rgb, scaling,
+		                               scale_modifier, rot, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy,
+		                               radii, geom_buffer, binning_buffer, image_buffer, out_depth, dL_dpix, dL_depths,
+		                               d_mean2D, nullptr, d_opacity, d_rgb, d_xyz, nullptr, nullptr, d_scaling, d_rot, debug,
+		                               stream, flags);
 		if (rc) return rc;
 		// gradients that reached the expanded tensors from outside the rasterizer (BloomScene's scaling regulariser
 		// reads `scaling`, bloomscene.py:296-297): added before they are pulled back through the expansion

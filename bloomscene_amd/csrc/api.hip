@@ -102,7 +102,9 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 // of the previous forward call on this thread (the size guess of the next one).  Nothing here carries
 // results between calls.
 struct SyncCache {
-	int* pinned = nullptr;       // [4] = flags[0..3] of the forward; [4] = landing word of read_u32_blocking
+	int* pinned = nullptr;       // [4] = flags[0..3] of the forward; [4] = landing word of read_u32_blocking;
+	                             // [5] = error flag a prefiltered bsr_visible_filter kernel writes straight into host memory
+	int* pinned_dev = nullptr;   // the same buffer as the device addresses it
 	hipEvent_t copied = nullptr;
 	int device = -1;
 	int last_P = -1, last_W = -1, last_H = -1, last_V = -1;
@@ -116,9 +118,14 @@ static SyncCache* sync_cache()
 	if (c.device != dev) {   // first use on this thread, or the thread moved to another GPU
 		if (c.copied) (void)hipEventDestroy(c.copied);
 		c.copied = nullptr;
-		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) {
 			c.pinned = nullptr;
 			fail("hipHostMalloc failed");
+			return nullptr;
+		}
+		if (hipHostGetDevicePointer((void**)&c.pinned_dev, c.pinned, 0) != hipSuccess) {
+			c.pinned_dev = nullptr;
+			fail("hipHostGetDevicePointer failed");
 			return nullptr;
 		}
 		if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess) {
@@ -166,22 +173,21 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, hipStream_t s);
+                       float* out_depth, bool exact_exp, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, hipStream_t s);
+                       float4* slab, bool strict, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- options (bsr_set_option)
-static std::atomic<int> g_opt_exact_exp{0};
+// Numerics are per call (the `flags` of bsr_forward_ex / bsr_backward_ex); the one process-wide switch left is a test
+// hook that changes no result.
 static std::atomic<int> g_opt_sort_force_int{0};
-int opt_exact_exp() { return g_opt_exact_exp.load(std::memory_order_relaxed); }
 int opt_sort_force_int() { return g_opt_sort_force_int.load(std::memory_order_relaxed); }
 static std::atomic<int>* find_option(const char* name)
 {
 	if (!name) return nullptr;
-	if (!strcmp(name, "exact_exp")) return &g_opt_exact_exp;
 	if (!strcmp(name, "sort_force_int")) return &g_opt_sort_force_int;
 	return nullptr;
 }
@@ -321,11 +327,14 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
-                int debug, void* stream, int* num_rendered)
+                int debug, void* stream, int* num_rendered, unsigned flags)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (num_rendered) *num_rendered = 0;
+	// (BSR_FLAG_EXACT_GRAD concerns the backward alone: accepted here so that a caller can hand one word to both)
+	if (flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD))
+		return fail("forward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD));
 	if (P == 0) {   // reference rasterize_points.cu:68-82: zero images, no scratch, num_rendered = 0
 		if (width <= 0 || height <= 0 || !out_color || !out_depth) return fail("invalid image outputs");
 		HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)V * 3 * width * height * sizeof(float), s));
@@ -408,11 +417,19 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	BinElem* elems_free = nullptr;
 	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
 	// from device memory and returns at once if it exceeds the capacity
-	auto run_tail = [&](size_t capacity) -> int {
+	auto run_tail = [&](size_t capacity, bool rerun) -> int {
 		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity, V == 1));
 		if (!bin_p) return fail("scratch allocation callback returned null");
 		bin = BinState::carve(bin_p, capacity, V == 1);
 		cap = capacity;
+		if (rerun) {
+			// A first tail that was NOT skipped (kept <= its capacity, but the backward's carve would not fit) has already
+			// filed its long tiles: flags[1], [4], [5] count the work lists of the wide sort classes and are zeroed only by
+			// k_scans.  Counting again on top of them would list every long tile twice (two workgroups sorting one tile
+			// through the same global scratch) and could spill one class's list into the next.
+			HIP_TRY(hipMemsetAsync(img.flags + 1, 0, sizeof(int), s));
+			HIP_TRY(hipMemsetAsync(img.flags + 4, 0, 2 * sizeof(int), s));
+		}
 		const int* n_ptr = img.flags + 2;
 		{
 			StageTimer t("binning", s);
@@ -429,7 +446,8 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		{
 			StageTimer t("render_fwd", s);
 			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
-			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth, s);
+			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
+			                  (flags & BSR_FLAG_EXACT_EXP) != 0, s);
 		}
 		return 0;
 	};
@@ -438,7 +456,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	if (guess) {
 		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
 		if (c > 0x7fffffffu) c = 0x7fffffffu;
-		if (run_tail(c)) return 1;   // the whole rest of the forward is in flight before the host waits
+		if (run_tail(c, false)) return 1;   // the whole rest of the forward is in flight before the host waits
 	}
 	HIP_TRY(hipEventSynchronize(sc->copied));
 	const int h_flag = prefiltered ? sc->pinned[0] : 0;
@@ -464,7 +482,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	if (!guess || (size_t)h_kept > cap || !backward_fits) {
 		// first call of this shape, more kept instances than the guessed scratch holds (the kernels of the first
 		// attempt then returned without touching anything), or a buffer the backward's carve would overrun
-		if (run_tail((size_t)R)) return 1;
+		if (run_tail((size_t)R, guess)) return 1;
 	}
 	STAGE_CHECK("render_fwd", debug, s);
 	return 0;
@@ -591,10 +609,15 @@ int bsr_visible_filter(int P, int M, int width, int height, const float* means3D
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
 	if (P == 0) return 0;
 	if (!radii) return fail("radii is null");
+	// prefiltered: the kernel reports a culled point through ONE word of the calling thread's pinned HOST buffer (mapped
+	// into the device's address space): no device allocation, nothing to free on an error path
 	int* d_flag = nullptr;
+	SyncCache* sc = nullptr;
 	if (prefiltered) {
-		HIP_TRY(hipMallocAsync((void**)&d_flag, sizeof(int), s));
-		HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+		sc = sync_cache();
+		if (!sc) return 1;
+		sc->pinned[5] = 0;
+		d_flag = sc->pinned_dev + 5;
 	}
 	PreArgs a;
 	memset(&a, 0, sizeof(a));
@@ -612,11 +635,8 @@ int bsr_visible_filter(int P, int M, int width, int height, const float* means3D
 	}
 	STAGE_CHECK("visible_filter", debug, s);
 	if (prefiltered) {
-		int h = 0;
-		HIP_TRY(hipMemcpyAsync(&h, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
 		HIP_TRY(hipStreamSynchronize(s));
-		HIP_TRY(hipFreeAsync(d_flag, s));
-		if (h) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+		if (sc->pinned[5]) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
 	}
 	return 0;
 }
@@ -642,29 +662,36 @@ int bsr_visible_filter_views(int P, int n_views, int width, int height, const fl
 	return 0;
 }
 
+size_t bsr_visible_groups_scratch_bytes(int P, int n_groups)
+{
+	if (P <= 0 || n_groups <= 0) return 0;
+	return sizeof(uint32_t) * (size_t)n_groups * (((size_t)P + 255) / 256);
+}
+
 int bsr_visible_filter_groups(int P, int n_views, int n_groups, int width, int height, const float* means3D,
                               const float* scales, float scale_modifier, const float* rotations,
                               const float* cov3D_precomp, const float* viewmatrices, const float* projmatrices,
                               float tan_fovx, float tan_fovy, const int* group_of_view, uint8_t* group_mask,
-                              uint32_t* group_counts, int debug, void* stream)
+                              uint32_t* group_counts, void* count_scratch, int debug, void* stream)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	if (n_views < 0 || n_groups < 0 || n_groups > 64) return fail("bsr_visible_filter_groups: need 0 <= n_groups <= 64");
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrices, projmatrices)) return 1;
-	if (P == 0 || n_groups == 0) {
+	if (P == 0 || n_groups == 0) {   // (P == 0: group_mask has no elements; n_groups == 0: no rows)
 		if (group_counts && n_groups > 0) HIP_TRY(hipMemsetAsync(group_counts, 0, sizeof(uint32_t) * (size_t)n_groups, s));
 		return 0;
 	}
 	if (!group_mask || (n_views > 0 && !group_of_view)) return fail("bsr_visible_filter_groups: NULL buffer");
+	if (group_counts && !count_scratch)
+		return fail("bsr_visible_filter_groups: group_counts needs count_scratch (bsr_visible_groups_scratch_bytes)");
 	{
 		StageTimer t("visible_filter_groups", s);
-		uint32_t* wg_counts = nullptr;   // per-workgroup partial counts, stream-ordered scratch
-		if (group_counts) HIP_TRY(hipMallocAsync((void**)&wg_counts, sizeof(uint32_t) * (size_t)n_groups * ((P + 255) / 256), s));
+		// per-workgroup partial counts: the caller's scratch, like every other byte of device memory this library uses
+		uint32_t* wg_counts = group_counts ? (uint32_t*)count_scratch : nullptr;
 		launch_visible_filter_views(P, n_views, means3D, scales, scale_modifier, rotations, cov3D_precomp, viewmatrices,
 		                            projmatrices, width, height, tan_fovx, tan_fovy, nullptr, group_of_view, n_groups,
 		                            group_mask, wg_counts, group_counts, s);
-		if (wg_counts) HIP_TRY(hipFreeAsync(wg_counts, s));
 	}
 	STAGE_CHECK("visible_filter_groups", debug, s);
 	return 0;
@@ -720,7 +747,21 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn b
 	return forward_impl(1, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D, M,
 	                    background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
 	                    rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
-	                    out_color, out_depth, radii, debug, stream, num_rendered);
+	                    out_color, out_depth, radii, debug, stream, num_rendered, 0u);
+}
+
+int bsr_forward_ex(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer, void* binning_user,
+                   bsr_alloc_fn imageBuffer, void* image_user, int P, int D, int M, const float* background, int width,
+                   int height, const float* means3D, const float* shs, const float* colors_precomp,
+                   const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                   const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                   float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
+                   int debug, void* stream, int* num_rendered, unsigned flags)
+{
+	return forward_impl(1, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D, M,
+	                    background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+	                    rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+	                    out_color, out_depth, radii, debug, stream, num_rendered, flags);
 }
 
 int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_alloc_fn binningBuffer, void* binning_user,
@@ -730,7 +771,7 @@ int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_allo
                       const float* rotations, const float* cov3D_precomp, const float* viewmatrices,
                       const float* projmatrices, const float* cam_positions, float tan_fovx, float tan_fovy,
                       int prefiltered, float* out_color, float* out_depth, int* radii, int debug, void* stream,
-                      int* num_rendered)
+                      int* num_rendered, unsigned flags)
 {
 	g_err[0] = 0;
 	if (num_rendered) *num_rendered = 0;
@@ -739,7 +780,7 @@ int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user, bsr_allo
 	return forward_impl(n_views, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, D,
 	                    M, background, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
 	                    rotations, cov3D_precomp, viewmatrices, projmatrices, cam_positions, tan_fovx, tan_fovy,
-	                    prefiltered, out_color, out_depth, radii, debug, stream, num_rendered);
+	                    prefiltered, out_color, out_depth, radii, debug, stream, num_rendered, flags);
 }
 
 }  // extern "C"
@@ -752,10 +793,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
                          const float* out_depth, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
                          float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                         float* dL_dscale, float* dL_drot, int debug, void* stream)
+                         float* dL_dscale, float* dL_drot, int debug, void* stream, unsigned flags)
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
+	if (flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP))
+		return fail("backward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP));
 	if (P == 0) return 0;
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
 	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("scratch buffer is null");
@@ -786,7 +829,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		{
 			StageTimer t("render_bwd", s);
 			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
-			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slab, s);
+			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slab,
+			                  (flags & BSR_FLAG_EXACT_GRAD) != 0, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}
@@ -825,7 +869,7 @@ int bsr_backward(int P, int D, int M, int R, const float* background, int width,
 	return backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
 	                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, nullptr, nullptr, dL_dmean2D, dL_dconic, dL_dopacity,
-	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
+	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, 0u);
 }
 
 int bsr_backward_depth(int P, int D, int M, int R, const float* background, int width, int height,
@@ -845,7 +889,28 @@ int bsr_backward_depth(int P, int D, int M, int R, const float* background, int 
 	return backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
 	                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
 	                     binning_buffer, image_buffer, dL_dpix, out_depth, dL_depths, dL_dmean2D, dL_dconic, dL_dopacity,
-	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
+	                     dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, 0u);
+}
+
+int bsr_backward_ex(int P, int D, int M, int R, const float* background, int width, int height,
+                    const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                    float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                    const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                    const float* out_depth, const float* dL_dpix, const float* dL_depths, float* dL_dmean2D,
+                    float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                    float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream, unsigned flags)
+{
+	(void)colors_precomp;
+	if (P > 0 && out_depth && !dL_depths) {
+		g_err[0] = 0;
+		return fail("bsr_backward_ex: out_depth selects the depth-gradient extension, which needs dL_depths");
+	}
+	return backward_impl(P, D, M, R, background, width, height, means3D, shs, scales, scale_modifier, rotations,
+	                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+	                     binning_buffer, image_buffer, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, dL_dmean2D,
+	                     dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream,
+	                     flags);
 }
 
 }  // extern "C"

@@ -390,8 +390,11 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
 //      With W the view rotation, J the projection Jacobian, S the 3-D covariance:
 //        cov2D = (J W) S (J W)^t + 0.3 I,   |J|_F^2 <= K / tz^2  (K = fx^2 (1 + limx^2) + fy^2 (1 + limy^2), the clamp of
 //        tx/tz, ty/tz bounds J02, J12),  B := K |W|_F^2 |S|_F / tz^2 >= |(J W) S (J W)^t|_2 for ANY symmetric S,
-//        lambda_max = mid + sqrt(max(0.1, ((a-c)/2)^2 + b^2)) <= 1.5 B + 0.62, radius = ceil(3 sqrt(lambda)) <= rb :=
-//        3.01 sqrt(1.5015 B + 1) + 2.
+//        lambda_max = mid + sqrt(max(0.1, ((a-c)/2)^2 + b^2)) = max(largest eigenvalue of cov2D, mid + sqrt(0.1))
+//        <= B + 0.3 + 0.317 for any symmetric S, definite or not (the eigenvalues of the 2x2 block lie in [-B, B]: no
+//        positive semi-definiteness is assumed; tests/test_filter_cull_bound_cpu.py sweeps rank-2 covariances with
+//        eigenvalues +s, -s).  The test uses 1.5 B + 0.62 (the extra half B covers the fp32 evaluation of mid^2 - det
+//        on large entries): radius = ceil(3 sqrt(lambda)) <= rb := 3.01 sqrt(1.5015 B + 1) + 2.
 //      get_rect() is empty when px + r < 0 or px - r >= 16 gx (same in y): tested with rb and a slack of 2 px + 1e-5 |px|
 //      for the float evaluation of ndc2pix; every compare is false for NaN, so doubtful lanes stay candidates.
 //   B  the surviving (lane, view) pairs are queued in LDS and evaluated 64 at a time with the exact code: lane i takes

@@ -152,6 +152,37 @@ __device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ 
 	return off + kept_rank(w * h, mask, k);
 }
 
+// Arithmetic shortcuts of the walk, each with a switch.  STRICT (BSR_FLAG_EXACT_GRAD of bsr_backward_ex) turns all five
+// off: the reference's per-pair operations on the reference's operands (backward.cu:521,527-536,557,561-583), IEEE
+// divisions, no fp contraction, the pinned exp on every pair, accum_rec per channel -- only the ORDER of the sums then
+// differs from the oracle's.  The attribution builds (make attrib, tools/attribute_gradient_error.py) switch one off at a
+// time through the macros.
+#ifdef BSR_BWD_EXACT_EXP
+#define BSR_A_EXP true
+#else
+#define BSR_A_EXP false
+#endif
+#ifdef BSR_BWD_IEEE_DIV
+#define BSR_A_DIV true
+#else
+#define BSR_A_DIV false
+#endif
+#ifdef BSR_BWD_NO_CONTRACT
+#define BSR_A_NOCONTRACT true
+#else
+#define BSR_A_NOCONTRACT false
+#endif
+#ifdef BSR_BWD_PAIR_PRODUCTS
+#define BSR_A_PAIRS true
+#else
+#define BSR_A_PAIRS false
+#endif
+#ifdef BSR_BWD_CHANNEL_ACCUM
+#define BSR_A_CHAN true
+#else
+#define BSR_A_CHAN false
+#endif
+
 #ifndef BSR_BWD_BATCH
 #define BSR_BWD_BATCH 128   // entries staged per batch (occupancy sweep: make batch BATCH=64|256, tools/sweep_occupancy.sh)
 #endif
@@ -170,11 +201,136 @@ struct BwdShared {
 	uint32_t max_contrib[4];
 };
 
+// ---- per-pair arithmetic of the walk -------------------------------------------------------------------------------
+// State a pixel carries along the list (back to front) and the constants of the pixel.
+template <bool DEPTH, bool CHAN>
+struct PairState {
+	float T;
+	float Srec;                 // fast form: sum_ch accum_rec[ch] * dL_dpixel[ch] (+ the depth channel in the extension)
+	float acc_rec[CHAN ? 4 : 1], last_color[CHAN ? 4 : 1], last_alpha;   // CHAN: reference :527-536 channel by channel ([3] = depth)
+};
+struct PixelConst {
+	float dpx0, dpx1, dpx2, neg_Tfinal_bg, gz, g1, ddelx_dx, ddely_dy;
+};
+// Gradients are compared with a tolerance, not bitwise (the reference's own sums are unordered), so the default form
+// fuses multiply-adds (BSR_PAIR_TERMS is instantiated once under `#pragma clang fp contract(fast)` and once without) and
+// uses a refined reciprocal instead of the reference's two IEEE divisions (:521,:557).
+//   DIV    the reference's IEEE divisions                       PAIRS  the reference's per-pair terms (:561-580) instead of moments
+//   CHAN   accum_rec channel by channel (:527-536)
+// Per pair the reference adds (:574-583), with gd = G * dL_dalpha and w = o * gd:
+//   dL_dmean2D.x += -w * ddelx_dx * (a dx + b dy)      dL_dconic.x += -0.5 w dx dx
+//   dL_dmean2D.y += -w * ddely_dy * (c dy + b dx)      dL_dconic.y += -0.5 w dx dy
+//   dL_dopacity  += gd                                  dL_dconic.w += -0.5 w dy dy
+// o, a, b, c and the two scale factors are constants of the ENTRY, so the default form sums only the six moments of gd
+// over the pixels (1, dx, dy, dx dx, dx dy, dy dy); the entry's row is assembled from the four quadrants' moments once,
+// when it is written (5 multiplies per pair instead of 13).
+#define BSR_PAIR_TERMS                                                                                                      \
+	const float om = 1.f - alpha;                                                                                           \
+	float inv;                                                                                                              \
+	if constexpr (DIV) {                                                                                                    \
+		inv = 1.0f / om;                                                                                                    \
+		st.T = st.T / om; /* reference :521 */                                                                              \
+	} else {                                                                                                                \
+		inv = __builtin_amdgcn_rcpf(om); /* 1 ulp */                                                                        \
+		/* T/(1-alpha): quotient estimate + one residual correction (the residual T - om * qT is exact in the fma, so the  \
+		   1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare cases: the T chain          \
+		   (hundreds of steps in dense tiles) does not drift.  (plain T * inv: -2 % time, +20 % elements off by > 1e-4) */  \
+		const float qT = st.T * inv;                                                                                        \
+		st.T = __builtin_fmaf(__builtin_fmaf(-om, qT, st.T), inv, qT);                                                      \
+	}                                                                                                                       \
+	const float T = st.T;                                                                                                   \
+	float S, Sd = 0.f;                                                                                                      \
+	if constexpr (CHAN) {                                                                                                   \
+		/* accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, then (c - accum_rec) * dL_dpixel.            \
+		   A pair the reference skips must leave (accum_rec, last_color, last_alpha) standing.  The depth extension is     \
+		   the oracle's separate pass (bsro_render_backward_depth): its own recurrence on d_i = gz z_i + g1. */             \
+		const bool live = G != 0.f;                                                                                         \
+		const float c4[4] = {q2.x, q2.y, q2.z, DEPTH ? px.gz * q1.w + px.g1 : 0.f};                                         \
+		const float dp[3] = {px.dpx0, px.dpx1, px.dpx2};                                                                    \
+		S = 0.f;                                                                                                            \
+		_Pragma("unroll") for (int ch = 0; ch < (DEPTH ? 4 : 3); ch++) {                                                    \
+			const float ar = st.last_alpha * st.last_color[ch] + (1.f - st.last_alpha) * st.acc_rec[ch];                    \
+			st.acc_rec[ch] = live ? ar : st.acc_rec[ch];                                                                    \
+			st.last_color[ch] = live ? c4[ch] : st.last_color[ch];                                                          \
+			if (ch < 3) S += (c4[ch] - st.acc_rec[ch]) * dp[ch];                                                            \
+			else Sd = c4[ch] - st.acc_rec[ch];                                                                              \
+		}                                                                                                                   \
+		st.last_alpha = live ? alpha : st.last_alpha;                                                                       \
+	} else {                                                                                                                \
+		/* The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it only through     \
+		   sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so the projection                \
+		   Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence Srec' = alpha * u + (1 - alpha) * Srec    \
+		   with u = sum_ch c[ch] * dL_dpixel[ch]: one scalar instead of three channels (the depth extension adds its       \
+		   term d_i to u). */                                                                                               \
+		float u = q2.x * px.dpx0 + q2.y * px.dpx1 + q2.z * px.dpx2;                                                         \
+		if (DEPTH) u += __builtin_fmaf(px.gz, q1.w, px.g1);                                                                 \
+		S = u - st.Srec;                                                                                                    \
+		st.Srec = st.Srec + alpha * S;                                                                                      \
+	}                                                                                                                       \
+	float dL_dalpha = T * S + px.neg_Tfinal_bg * inv;                                                                       \
+	if constexpr (PAIRS) {                                                                                                  \
+		/* the reference's per-pair terms (:561-580), summed as they are; the epilogue passes them through */               \
+		const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x;                                                       \
+		const float gdx = G * dx, gdy = G * dy;                                                                             \
+		const float dG_ddelx = -gdx * ca - gdy * cb;                                                                        \
+		const float dG_ddely = -gdy * cc - gdx * cb;                                                                        \
+		float dL_dG = q1.z * dL_dalpha;                                                                                     \
+		v[0] = dL_dG * dG_ddelx * px.ddelx_dx;                                                                              \
+		v[1] = dL_dG * dG_ddely * px.ddely_dy;                                                                              \
+		v[2] = -0.5f * gdx * dx * dL_dG;                                                                                    \
+		v[3] = -0.5f * gdx * dy * dL_dG;                                                                                    \
+		v[4] = -0.5f * gdy * dy * dL_dG;                                                                                    \
+		v[5] = G * dL_dalpha;                                                                                               \
+		if (DEPTH && CHAN) { /* the oracle's second pass: the same terms for dL_dalpha = T * (d_i - Rd) */                  \
+			const float dLa = T * Sd;                                                                                       \
+			dL_dG = q1.z * dLa;                                                                                             \
+			v[0] += dL_dG * dG_ddelx * px.ddelx_dx;                                                                         \
+			v[1] += dL_dG * dG_ddely * px.ddely_dy;                                                                         \
+			v[2] += -0.5f * gdx * dx * dL_dG;                                                                               \
+			v[3] += -0.5f * gdx * dy * dL_dG;                                                                               \
+			v[4] += -0.5f * gdy * dy * dL_dG;                                                                               \
+			v[5] += G * dLa;                                                                                                \
+		}                                                                                                                   \
+	} else {                                                                                                                \
+		if (DEPTH && CHAN) dL_dalpha += T * Sd;                                                                             \
+		const float gd = G * dL_dalpha;                                                                                     \
+		const float gx = gd * dx, gy = gd * dy;                                                                             \
+		v[0] = gx;                                                                                                          \
+		v[1] = gy;                                                                                                          \
+		v[2] = gx * dx;                                                                                                     \
+		v[3] = gx * dy;                                                                                                     \
+		v[4] = gy * dy;                                                                                                     \
+		v[5] = gd;                                                                                                          \
+	}                                                                                                                       \
+	const float aT = alpha * T;                                                                                             \
+	v[6] = aT * px.dpx0;                                                                                                    \
+	v[7] = aT * px.dpx1;                                                                                                    \
+	v[8] = aT * px.dpx2;                                                                                                    \
+	v[9] = DEPTH ? aT * px.gz : 0.f;
+
+template <bool DEPTH, bool DIV, bool PAIRS, bool CHAN>
+__device__ __forceinline__ void pair_terms_contracted(PairState<DEPTH, CHAN>& st, const PixelConst& px, const float4 q0,
+                                                      const float4 q1, const float4 q2, const float dx, const float dy,
+                                                      const float G, const float alpha, float (&v)[10])
+{
+#pragma clang fp contract(fast)
+	BSR_PAIR_TERMS
+}
+template <bool DEPTH, bool DIV, bool PAIRS, bool CHAN>
+__device__ __forceinline__ void pair_terms_source_order(PairState<DEPTH, CHAN>& st, const PixelConst& px, const float4 q0,
+                                                        const float4 q1, const float4 q2, const float dx, const float dy,
+                                                        const float G, const float alpha, float (&v)[10])
+{
+	BSR_PAIR_TERMS
+}
+#undef BSR_PAIR_TERMS
+
 // DEPTH = false: the reference's backward (dL_depths ignored).  DEPTH = true: the opt-in extension
 // that also differentiates the normalised depth target (math in
 // oracle/bsr_oracle.c:bsro_render_backward_depth): a tenth partial sum dL/dz per instance and one more
 // term in dL/dalpha.  out_depth is the forward's depth image (its zeros are the acc <= 0.5 gate).
-template <bool DEPTH>
+// STRICT (BSR_FLAG_EXACT_GRAD): every arithmetic shortcut off, see the switches above.
+template <bool DEPTH, bool STRICT>
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, int W, int H,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
@@ -189,6 +345,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                                                           float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
+	constexpr bool X_EXP = STRICT || BSR_A_EXP, X_DIV = STRICT || BSR_A_DIV, X_NOCONTRACT = STRICT || BSR_A_NOCONTRACT,
+	               X_PAIRS = STRICT || BSR_A_PAIRS, X_CHAN = STRICT || BSR_A_CHAN;
 	__shared__ BwdShared<NV> sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
@@ -212,36 +370,31 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 	const int n = (int)(tile_start[tile + 1] - start);
 
 	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
-	float T = T_final;
+	PairState<DEPTH, X_CHAN> pst = {};
+	pst.T = T_final;
 	const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
-	float Srec = 0.f;   // sum_ch accum_rec[ch] * dL_dpixel[ch] (+ the depth channel in the extension)
-#ifdef BSR_BWD_CHANNEL_ACCUM
-	float acc_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f}, last_alpha = 0.f;
-	(void)Srec;
-#endif
-	float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+	PixelConst pc = {};
 	if (inside) {
-		dpx0 = dL_dpixels[pix_id];
-		dpx1 = dL_dpixels[plane + pix_id];
-		dpx2 = dL_dpixels[2 * plane + pix_id];
+		pc.dpx0 = dL_dpixels[pix_id];
+		pc.dpx1 = dL_dpixels[plane + pix_id];
+		pc.dpx2 = dL_dpixels[2 * plane + pix_id];
 	}
-	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
-	const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;
+	const float bg_dot_dpixel = bg_color[0] * pc.dpx0 + bg_color[1] * pc.dpx1 + bg_color[2] * pc.dpx2;
+	pc.neg_Tfinal_bg = -T_final * bg_dot_dpixel;
 	// depth extension: d_i = gz * z_i + g1 plays the role of a fourth colour channel
-	float gz = 0.f, g1 = 0.f;
 	if (DEPTH && inside) {
 		const float depth_px = out_depth[pix_id];
 		if (depth_px != 0.0f) {   // the forward's acc > 0.5 decision
-			gz = dL_depths[pix_id] / (1e-6f + (1.0f - T_final));
-			g1 = -gz * depth_px;
+			pc.gz = dL_depths[pix_id] / (1e-6f + (1.0f - T_final));
+			pc.g1 = -pc.gz * depth_px;
 		}
 	}
 	// component whose wave total lands in this lane after the reduction; one lane per component stores
 	bool stores;
 	const int comp_of_lane = calibrate_components<DEPTH>(lane, stores);
 	float* const part_mine = &sh.part[wave][stores ? comp_of_lane : 0][0];
-	const float ddelx_dx = (float)(0.5 * W);
-	const float ddely_dy = (float)(0.5 * H);
+	pc.ddelx_dx = (float)(0.5 * W);
+	pc.ddely_dy = (float)(0.5 * H);
 
 	// Entries at list positions >= max(last_contributor) are skipped by every pixel of the tile
 	// (reference :498-500): start the walk at the deepest entry any pixel blended.
@@ -343,18 +496,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			// alpha < 1/255 test below, which skipped them in the forward (alpha < 0) -- the fast path would blend them.
 			// Inside the rare branch each lane picks its exp with the FORWARD's expression (render_fwd.hip): per lane the
 			// same exp the forward's default mode used on this pair, so alpha is the forward's alpha bit for bit.
-#ifdef BSR_BWD_EXACT_EXP
-			const bool in_band = true;   // attribution build: the pinned exp on every visit
-#else
-			const bool in_band = (wave_ballot(!(power >= q2.w)) & cand_mask) != 0ull;   // rare: ~1 % of the visits
-#endif
+			// X_EXP (strict gradients / attribution build): the pinned exp on every visit.
+			const bool in_band = X_EXP ? true : (wave_ballot(!(power >= q2.w)) & cand_mask) != 0ull;   // rare: ~1 % of the visits
 			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
 			if (in_band) {
-#ifdef BSR_BWD_EXACT_EXP
-				const bool lane_in_band = true;
-#else
-				const bool lane_in_band = !(fabsf(power - (q1.y + 1.0e-3f)) >= 1.1e-3f);
-#endif
+				const bool lane_in_band = X_EXP ? true : !(fabsf(power - (q1.y + 1.0e-3f)) >= 1.1e-3f);
 				const float Ge = bsr_expf_walk(power);
 				Gx = lane_in_band ? Ge : Gx;
 			}
@@ -378,95 +524,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				STAT_ADD(8 + ((live - 1) >> 3), 1);             // histogram of live lanes: 1-8, 9-16, ..., 57-64
 			}
 #endif
-			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
-			{
-				// Gradients are compared with a tolerance, not bitwise (the reference's own sums are
-				// unordered), so this block may fuse multiply-adds and use a refined reciprocal
-				// instead of the reference's two IEEE divisions (:521,:557).
-				// Attribution builds (make attrib, tools/attribute_gradient_error.py) switch the shortcuts off one by one:
-				// BSR_BWD_NO_CONTRACT, BSR_BWD_IEEE_DIV, BSR_BWD_PAIR_PRODUCTS, BSR_BWD_CHANNEL_ACCUM (+ BSR_BWD_EXACT_EXP above).
-#ifndef BSR_BWD_NO_CONTRACT
-#pragma clang fp contract(fast)
-#endif
-				const float om = 1.f - alpha;
-#ifdef BSR_BWD_IEEE_DIV
-				const float inv = 1.0f / om;
-				T = T / om;                                     // reference :521
-#else
-				const float inv = __builtin_amdgcn_rcpf(om);   // 1 ulp
-				// T/(1-alpha): quotient estimate + one residual correction (the residual T - om * qT is exact in the
-				// fma, so the 1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare
-				// cases: the T chain (hundreds of steps in dense tiles) does not drift.
-				const float qT = T * inv;
-				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);   // (plain T * inv: -2 % time, +20 % elements off by > 1e-4)
-#endif
-				// The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it
-				// only through sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so
-				// the projection Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence
-				// Srec' = alpha * u + (1 - alpha) * Srec with u = sum_ch c[ch] * dL_dpixel[ch]: one scalar
-				// instead of three channels (the depth extension adds its term d_i to u).
-#ifdef BSR_BWD_CHANNEL_ACCUM
-				// reference :527-536 channel by channel (attribution build; the depth extension is not carried here):
-				// accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, then (c - accum_rec) * dL_dpixel.
-				// A pair the reference skips must leave (accum_rec, last_color, last_alpha) standing.
-				float S = 0.f;
-				{
-					const bool live = G != 0.f;
-					const float c3[3] = {q2.x, q2.y, q2.z}, dp[3] = {dpx0, dpx1, dpx2};
-#pragma unroll
-					for (int ch = 0; ch < 3; ch++) {
-						const float ar = last_alpha * last_color[ch] + (1.f - last_alpha) * acc_rec[ch];
-						acc_rec[ch] = live ? ar : acc_rec[ch];
-						last_color[ch] = live ? c3[ch] : last_color[ch];
-						S += (c3[ch] - acc_rec[ch]) * dp[ch];
-					}
-					last_alpha = live ? alpha : last_alpha;
-				}
-#else
-				float u = q2.x * dpx0 + q2.y * dpx1 + q2.z * dpx2;
-				if (DEPTH) u += __builtin_fmaf(gz, q1.w, g1);
-				const float S = u - Srec;
-				Srec = Srec + alpha * S;
-#endif
-				const float dL_dalpha = T * S + neg_Tfinal_bg * inv;
-				// Per pair the reference adds (:574-583), with gd = G * dL_dalpha and w = o * gd:
-				//   dL_dmean2D.x += -w * ddelx_dx * (a dx + b dy)      dL_dconic.x += -0.5 w dx dx
-				//   dL_dmean2D.y += -w * ddely_dy * (c dy + b dx)      dL_dconic.y += -0.5 w dx dy
-				//   dL_dopacity  += gd                                  dL_dconic.w += -0.5 w dy dy
-				// o, a, b, c and the two scale factors are constants of the ENTRY, so the wave sums only the six
-				// moments of gd over its pixels (1, dx, dy, dx dx, dx dy, dy dy); the entry's row is assembled from
-				// the four quadrants' moments once, when it is written (5 multiplies per pair instead of 13).
-				const float gd = G * dL_dalpha;
-#ifdef BSR_BWD_PAIR_PRODUCTS
-				{
-					// the reference's per-pair terms (:561-580), summed as they are; the epilogue passes them through
-					const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x;
-					const float dL_dG = q1.z * dL_dalpha;
-					const float gdx = G * dx, gdy = G * dy;
-					const float dG_ddelx = -gdx * ca - gdy * cb;
-					const float dG_ddely = -gdy * cc - gdx * cb;
-					v0 = dL_dG * dG_ddelx * ddelx_dx;
-					v1 = dL_dG * dG_ddely * ddely_dy;
-					v2 = -0.5f * gdx * dx * dL_dG;
-					v3 = -0.5f * gdx * dy * dL_dG;
-					v4 = -0.5f * gdy * dy * dL_dG;
-				}
-#else
-				const float gx = gd * dx, gy = gd * dy;
-				v0 = gx;
-				v1 = gy;
-				v2 = gx * dx;
-				v3 = gx * dy;
-				v4 = gy * dy;
-#endif
-				v5 = gd;
-				const float aT = alpha * T;
-				v6 = aT * dpx0;
-				v7 = aT * dpx1;
-				v8 = aT * dpx2;
-				if (DEPTH) v9 = aT * gz;
-			}
-			const float tot = wave_sums_masked<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+			float v[10];
+			if constexpr (X_NOCONTRACT) pair_terms_source_order<DEPTH, X_DIV, X_PAIRS, X_CHAN>(pst, pc, q0, q1, q2, dx, dy, G, alpha, v);
+			else pair_terms_contracted<DEPTH, X_DIV, X_PAIRS, X_CHAN>(pst, pc, q0, q1, q2, dx, dy, G, alpha, v);
+			const float tot = wave_sums_masked<DEPTH>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
 			if (stores) *reinterpret_cast<float*>(reinterpret_cast<char*>(part_mine) + (joff >> 2)) = tot;   // part_mine[j]
 		};
 		// four list entries per trip: one address computation and one 16-byte LDS read for the list
@@ -495,15 +556,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float no = -e1.z;
 			const float h = 0.5f * no;
 			float* const row = reinterpret_cast<float*>(slab) + (size_t)my_row * slab_row_floats(DEPTH);
-#ifdef BSR_BWD_PAIR_PRODUCTS
-			(void)ca; (void)cb; (void)cc; (void)h;
-			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{a9[0], a9[1], a9[2], a9[3]};
-			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{a9[4], a9[5], a9[6], a9[7]};
-#else
-			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{no * ddelx_dx * (ca * a9[0] + cb * a9[1]),
-			                                                   no * ddely_dy * (cc * a9[1] + cb * a9[0]), h * a9[2], h * a9[3]};
-			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{h * a9[4], a9[5], a9[6], a9[7]};
-#endif
+			if constexpr (X_PAIRS) {
+				*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{a9[0], a9[1], a9[2], a9[3]};
+				*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{a9[4], a9[5], a9[6], a9[7]};
+			} else {
+				*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{no * pc.ddelx_dx * (ca * a9[0] + cb * a9[1]),
+				                                                   no * pc.ddely_dy * (cc * a9[1] + cb * a9[0]), h * a9[2], h * a9[3]};
+				*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{h * a9[4], a9[5], a9[6], a9[7]};
+			}
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
@@ -544,17 +604,21 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, hipStream_t s)
+                       float4* slab, bool strict, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_BWD");
-	if (out_depth && dL_depths)
-		hipLaunchKernelGGL(k_render_bwd<true>, dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,
-		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, out_depth, dL_depths, slab);
-	else
-		hipLaunchKernelGGL(k_render_bwd<false>, dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,
-		                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, nullptr, nullptr, slab);
+	const bool depth = out_depth && dL_depths;
+#define BSR_LAUNCH_BWD(D_, S_)                                                                                          \
+	hipLaunchKernelGGL((k_render_bwd<D_, S_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
+	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
+	                   depth ? dL_depths : nullptr, slab)
+	if (depth && strict) BSR_LAUNCH_BWD(true, true);
+	else if (depth) BSR_LAUNCH_BWD(true, false);
+	else if (strict) BSR_LAUNCH_BWD(false, true);
+	else BSR_LAUNCH_BWD(false, false);
+#undef BSR_LAUNCH_BWD
 }
 
 }  // namespace bsr

@@ -3,7 +3,7 @@
 // Semantics: reference renderCUDA, cuda_rasterizer/forward.cu:341-471 (under
 // /root/reference/submodules/depth-diff-gaussian-rasterization).  Per pixel the arithmetic and
 // every decision (power > 0, alpha < 1/255, T*(1-alpha) < 1e-4, depth normalisation) are
-// evaluated in the reference's order.  EXACT = true (bsr_set_option("exact_exp", 1)): exp(power) is the pinned
+// evaluated in the reference's order.  EXACT = true (BSR_FLAG_EXACT_EXP of bsr_forward_ex): exp(power) is the pinned
 // bsr_expf on every evaluation and the results match the CPU oracle bit for bit.  EXACT = false (the default):
 // the VALUE of exp(power) comes from v_exp_f32 (1 ulp, 2 issue slots instead of 13) and only a wave with a pixel
 // inside the decision band around the alpha >= 1/255 cut evaluates the pinned exp -- see the visit below.
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* point_list,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, hipStream_t s)
+                       float* out_depth, bool exact, hipStream_t s)
 {
 	const int n_tiles = gx * gy * n_views;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
@@ -316,7 +316,6 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	// Both instantiations produce identical bits.
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD");
 	const bool split = (long long)capacity >= 48ll * n_tiles;
-	const bool exact = opt_exact_exp() != 0;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
 	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_BLOCK, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
 	                   n_ptr, capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth)

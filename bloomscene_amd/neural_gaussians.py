@@ -131,7 +131,7 @@ class _NeuralRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                depth_gradient):
+                depth_gradient, flags=0):
         from .rasterizer import _Scratch, _dev_f32
         _need_gpu(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot)
         lib = _capi.lib()
@@ -175,7 +175,7 @@ class _NeuralRender(torch.autograd.Function):
                 gauss_cb, None, geom.callback, None, binning.callback, None, img.callback, None,
                 _ptr(bg), W, H, float(rs.scale_modifier), _ptr(view), _ptr(proj), _ptr(campos), float(rs.tanfovx),
                 float(rs.tanfovy), out_color.data_ptr(), out_depth.data_ptr(), int(bool(rs.debug)), stream,
-                C.byref(S), C.byref(R))
+                C.byref(S), C.byref(R), int(flags))
         _capi.check(rc, "bsr_anchor_render_forward")
         S, R = S.value, R.value
         # (the last buffer asked for: the first request may have been a guess made before the count was known)
@@ -191,6 +191,7 @@ class _NeuralRender(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii, mask, viewspace)
         ctx.dims = (N, K, S, R, H, W)
+        ctx.flags = int(flags)
         ctx.raster_settings = rs
         ctx.shapes = tuple(t.shape for t in (anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot))
         ctx.cam = (bg, view, proj, campos)
@@ -234,19 +235,21 @@ class _NeuralRender(torch.autograd.Function):
                     _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), _ptr(g_image), _ptr(ctx.out_depth),
                     _ptr(g_depth), _ptr(g_xyz), _ptr(g_rgb), _ptr(g_opacity), _ptr(g_scaling), _ptr(g_rot),
                     _ptr(grads) if S else None, _ptr(d_anchor), _ptr(d_gs), _ptr(d_go), _ptr(d_no), _ptr(d_co), _ptr(d_sr),
-                    int(bool(rs.debug)), stream)
+                    int(bool(rs.debug)), stream, ctx.flags)
             _capi.check(rc, "bsr_anchor_render_backward")
         # the screen-space gradient, where the reference's consumers look for it (viewspace_points.grad)
         ctx.viewspace.grad = grads[14 * S:17 * S].view(S, 3)
         sh = ctx.shapes
         return (d_anchor.view(sh[0]), d_gs.view(sh[1]), d_go.view(sh[2]), d_no.view(sh[3]), d_co.view(sh[4]),
-                d_sr.view(sh[5]), None, None)
+                d_sr.view(sh[5]), None, None, None)
 
 
 def render_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                   depth_gradient=False):
+                   depth_gradient=False, flags=None):
     """-> (image [3,H,W], depth [1,H,W], radii int32 [S], mask bool [N*K], xyz, color, opacity, scaling, rot,
     viewspace_points [S,3]) -- expand_anchors followed by GaussianRasterizer(raster_settings)(colors_precomp=color, ...)
-    in one native call each way; after backward ``viewspace_points.grad`` holds the screen-space gradient."""
+    in one native call each way; after backward ``viewspace_points.grad`` holds the screen-space gradient.
+    ``flags``: BSR_FLAG_* of the call; None = the calling thread's ``numerics(...)`` context."""
+    from .numerics import resolve_flags
     return _NeuralRender.apply(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                               bool(depth_gradient))
+                               bool(depth_gradient), resolve_flags() if flags is None else int(flags))

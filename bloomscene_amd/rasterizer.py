@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi
+from .numerics import FLAG_EXACT_EXP, FLAG_EXACT_GRAD, numerics, resolve_flags  # noqa: F401  (re-exported)
 
 
 def cpu_deep_copy_tuple(input_tuple):  # PYW:17-19
@@ -85,8 +86,10 @@ def _check_means3D(means3D):
 # ------------------------------------------------------------------ native entry points
 def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                                campos, prefiltered, debug):
-    """Counterpart of `_C.rasterize_gaussians` = RasterizeGaussiansCUDA (RP:35-117)."""
+                                campos, prefiltered, debug, flags=None):
+    """Counterpart of `_C.rasterize_gaussians` = RasterizeGaussiansCUDA (RP:35-117).  ``flags``: the call's numerics
+    (BSR_FLAG_* of include/bloomscene_rast.h); None = the calling thread's `numerics` context (default 0, the fast path)."""
+    flags = resolve_flags() if flags is None else int(flags)
     _check_means3D(means3D)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
@@ -105,23 +108,24 @@ def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations,
              campos=_dev_f32(campos, "campos", dev))
     num_rendered = C.c_int(0)
     with torch.cuda.device(dev):
-        rc = _capi.lib().bsr_forward(
+        rc = _capi.lib().bsr_forward_ex(
             geom.callback, None, binning.callback, None, img.callback, None,
             P, int(degree), int(M), _ptr(t["bg"]), W, H, _ptr(t["means3D"]), _ptr(t["sh"]), _ptr(t["colors"]),
             _ptr(t["opacity"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
             _ptr(t["view"]), _ptr(t["proj"]), _ptr(t["campos"]), float(tan_fovx), float(tan_fovy),
             int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr() if P else None,
-            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered))
+            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered), int(flags))
     _capi.check(rc, "rasterize_gaussians")
     return num_rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 
 def _rasterize_gaussians_views_native(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                       viewmatrices, projmatrices, tan_fovx, tan_fovy, image_height, image_width, sh,
-                                      degree, camposes, prefiltered, debug):
+                                      degree, camposes, prefiltered, debug, flags=None):
     """Forward of V views in one native call (bsr_forward_views; no reference counterpart -- the reference renders a
     camera sweep view by view): returns (num_rendered summed over the views, color [V,3,H,W], depth [V,1,H,W],
     radii [V,P]), view by view bit-identical to `_rasterize_gaussians_native`.  Forward only."""
+    flags = resolve_flags() if flags is None else int(flags)
     _check_means3D(means3D)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
@@ -152,7 +156,7 @@ def _rasterize_gaussians_views_native(bg, means3D, colors, opacity, scales, rota
             _ptr(t["opacity"]), _ptr(t["scales"]), float(scale_modifier), _ptr(t["rotations"]), _ptr(t["cov3D"]),
             _ptr(view), _ptr(proj), _ptr(campos), float(tan_fovx), float(tan_fovy),
             int(bool(prefiltered)), out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr() if P and V else None,
-            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered))
+            int(bool(debug)), _stream_handle(dev), C.byref(num_rendered), int(flags))
     _capi.check(rc, "rasterize_gaussians_views")
     return num_rendered.value, out_color, out_depth, radii
 
@@ -160,12 +164,14 @@ def _rasterize_gaussians_views_native(bg, means3D, colors, opacity, scales, rota
 def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rotations, scale_modifier,
                                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                          dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                         imageBuffer, debug, out_depth=None, all_outputs=False):
+                                         imageBuffer, debug, out_depth=None, all_outputs=False, flags=None):
     """Counterpart of `_C.rasterize_gaussians_backward` = RasterizeGaussiansBackwardCUDA (RP:119-200).
-    ``out_depth`` (the forward's depth image) selects the depth-gradient extension bsr_backward_depth.
+    ``out_depth`` (the forward's depth image) selects the depth-gradient extension; ``flags``: the call's numerics
+    (BSR_FLAG_EXACT_GRAD = the reference's per-pair operations).
     The reference also materialises dL_dconic, and dL_dcolors / dL_dcov3D even when SH / scale+rotation inputs make
     them intermediate results nobody reads (RP:154-162); here those are declined (None is returned in their place)
     unless ``all_outputs`` asks for the reference's full set."""
+    flags = resolve_flags() if flags is None else int(flags)
     dev = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -201,12 +207,9 @@ def _rasterize_gaussians_backward_native(bg, means3D, radii, colors, scales, rot
                 _ptr(dL_dconic), dL_dopacity.data_ptr(), _ptr(dL_dcolors), dL_dmeans3D.data_ptr(),
                 _ptr(dL_dcov3D), dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(),
                 dL_drotations.data_ptr(), int(bool(debug)), _stream_handle(dev))
+        od = None if out_depth is None else _dev_f32(out_depth, "out_depth", dev)
         with torch.cuda.device(dev):
-            if out_depth is None:
-                rc = _capi.lib().bsr_backward(*head, *tail)
-            else:
-                od = _dev_f32(out_depth, "out_depth", dev)
-                rc = _capi.lib().bsr_backward_depth(*head, od.data_ptr(), *tail)
+            rc = _capi.lib().bsr_backward_ex(*head, _ptr(od), *tail, int(flags))
         _capi.check(rc, "rasterize_gaussians_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
@@ -330,11 +333,16 @@ def _rasterize_gaussians_filter_groups_native(means3D, scales, rotations, scale_
         c = _dev_f32(cov3D_precomp, "cov3D_precomp", dev)
         v, p = _dev_f32(viewmatrices, "viewmatrices", dev), _dev_f32(projmatrices, "projmatrices", dev)
         gv = group_of_view.to(device=dev, dtype=torch.int32).contiguous()
+        lib = _capi.lib()
+        # the kernel's per-workgroup partial counts: the caller's scratch, like every other byte the library uses
+        scratch = torch.empty(lib.bsr_visible_groups_scratch_bytes(P, int(n_groups)), dtype=torch.uint8,
+                              device=dev) if return_counts else None
         with torch.cuda.device(dev):
-            rc = _capi.lib().bsr_visible_filter_groups(
+            rc = lib.bsr_visible_filter_groups(
                 P, V, int(n_groups), int(image_width), int(image_height), m.data_ptr(), _ptr(s), float(scale_modifier),
                 _ptr(r), _ptr(c), _ptr(v), _ptr(p), float(tan_fovx), float(tan_fovy), gv.data_ptr() if V else None,
-                mask.data_ptr(), counts.data_ptr() if return_counts else None, int(bool(debug)), _stream_handle(dev))
+                mask.data_ptr(), counts.data_ptr() if return_counts else None, _ptr(scratch), int(bool(debug)),
+                _stream_handle(dev))
         _capi.check(rc, "rasterize_gaussians_filter_groups")
     return (mask, counts) if return_counts else mask
 
@@ -388,9 +396,11 @@ def _pack_rows_native(tensors, idx, idx_stride=1, rows=None, debug=False):
 
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, depth_gradient=False, return_final_T=False):
+                        raster_settings, depth_gradient=False, return_final_T=False, flags=None):
+    """``flags``: BSR_FLAG_* word of this call; None = the calling thread's `numerics(...)` context (default 0)."""
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                    cov3Ds_precomp, raster_settings, depth_gradient, return_final_T)
+                                    cov3Ds_precomp, raster_settings, depth_gradient, return_final_T,
+                                    resolve_flags() if flags is None else int(flags))
     return out if return_final_T else out[:3]
 
 
@@ -398,7 +408,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, depth_gradient=False, return_final_T=False):
+                raster_settings, depth_gradient=False, return_final_T=False, flags=0):
         # same argument order as the reference hands to its C++ lib (PYW:60-80)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -411,14 +421,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted (PYW:84)
             try:
                 num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
-                    _rasterize_gaussians_native(*args)
+                    _rasterize_gaussians_native(*args, flags=flags)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
             num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
-                _rasterize_gaussians_native(*args)
+                _rasterize_gaussians_native(*args, flags=flags)
 
         # accumulated opacity of the call (extension, GaussianRasterizer.forward(return_alpha=True)): final_T lives in the
         # image buffer, where the library says it is; the view is handed out as a fourth, non-differentiable output
@@ -441,6 +451,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.depth_gradient = bool(depth_gradient)
+        ctx.flags = int(flags)   # the backward runs on an autograd worker thread: the mode travels with the node
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         if ctx.depth_gradient:
@@ -466,18 +477,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                 binningBuffer, imgBuffer, raster_settings.debug)
         if ctx.depth_gradient:
             args = args + (ctx.out_depth,)
+        kw = dict(flags=ctx.flags)
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:
                 grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
-                    grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args)
+                    grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args, **kw)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_bw.dump")
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
             grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, \
-                grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args)
+                grad_scales, grad_rotations = _rasterize_gaussians_backward_native(*args, **kw)
 
         # Absent optional inputs were empty tensors: their gradient must have the input's (empty)
         # shape for autograd's shape check; the reference relies on older, laxer torch here.
@@ -496,19 +508,32 @@ class _RasterizeGaussians(torch.autograd.Function):
             None,
             None,
             None,
+            None,
         )
         return grads
 
 
 class GaussianRasterizer(nn.Module):  # PYW:172-249
-    def __init__(self, raster_settings, depth_gradient=False):
+    def __init__(self, raster_settings, depth_gradient=False, exact_exp=None, strict_gradients=None):
         """``depth_gradient`` (extension, default off = the reference's behaviour): also backpropagate the
         gradient of the depth output.  The reference accepts grad_depth and drops it (backward.cu:457-463,
         539-554), so depth losses never move the Gaussians there; see include/bloomscene_rast.h
-        bsr_backward_depth."""
+        bsr_backward_depth.
+
+        Numerics of THIS rasterizer's calls (per call through the C ABI's flags, include/bloomscene_rast.h BSR_FLAG_*;
+        None = whatever the calling thread's ``bloomscene_amd.numerics(...)`` context says, by default the fast path):
+        ``exact_exp=True`` -- the pinned exp on every evaluation of the forward blend (bit-equal to the CPU oracle);
+        ``strict_gradients=True`` -- the backward tile walk performs the reference's per-pair operations
+        (backward.cu:521,527-536,557,561-583), which meets SURVEY.md 8(d)'s elementwise gradient bar at ~1.8x the
+        cost of that kernel."""
         super().__init__()
         self.raster_settings = raster_settings
         self.depth_gradient = bool(depth_gradient)
+        self.exact_exp = exact_exp
+        self.strict_gradients = strict_gradients
+
+    def _flags(self):
+        return resolve_flags(self.exact_exp, self.strict_gradients)
 
     def markVisible(self, positions):
         # Mark visible points (based on frustum culling for camera) with a boolean
@@ -544,10 +569,11 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
 
         if not return_alpha:
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, self.depth_gradient)
+                                       cov3D_precomp, raster_settings, self.depth_gradient, flags=self._flags())
         color, radii, depth, final_T = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
                                                            rotations, cov3D_precomp, raster_settings,
-                                                           self.depth_gradient, return_final_T=True)
+                                                           self.depth_gradient, return_final_T=True,
+                                                           flags=self._flags())
         return color, radii, depth, (1.0 - final_T).detach()
 
     def visible_filter_indices(self, means3D, scales=None, rotations=None, cov3D_precomp=None):

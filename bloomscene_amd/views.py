@@ -465,6 +465,7 @@ def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_m
     (matrices already stacked on the device); ``idx``: which of them (default: all).  Cameras must share image size
     and field of view (they do in the rotate360 sweep: utils/trajectory.py:110-121).  No gradients."""
     from .rasterizer import _rasterize_gaussians_views_native
+    from .numerics import resolve_flags
     xyz = gaussians["means3D"]
     dev = xyz.device
     idx = list(range(len(cams))) if idx is None else list(idx)
@@ -482,7 +483,8 @@ def render_views_batched(cams, gaussians: dict, bg_color, sh_degree=0, scaling_m
         _, color, depth, radii = _rasterize_gaussians_views_native(
             bg_color, xyz, opt("colors_precomp"), gaussians["opacities"], opt("scales"), opt("rotations"),
             scaling_modifier, opt("cov3D_precomp"), vms, pms, math.tan(c0.FoVx * 0.5), math.tan(c0.FoVy * 0.5),
-            int(c0.image_height), int(c0.image_width), opt("shs"), sh_degree, cps, False, debug)
+            int(c0.image_height), int(c0.image_width), opt("shs"), sh_degree, cps, False, debug,
+            flags=resolve_flags())   # (the calling thread's numerics context; default: the fast path)
     return color, depth, radii
 
 

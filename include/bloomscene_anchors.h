@@ -99,7 +99,7 @@ int bsr_anchor_render_forward(int n_anchors, int n_offsets,
                               const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                               float tan_fovx, float tan_fovy,
                               float* out_color, float* out_depth, int debug, void* stream,
-                              int* num_selected, int* num_rendered);
+                              int* num_selected, int* num_rendered, unsigned flags);
 
 /* Backward of bsr_anchor_render_forward: bsr_backward (bsr_backward_depth when out_depth is non-NULL) into
  * `gradient_scratch`, then bsr_anchor_expand_backward from it.  gradient_scratch: bsr_anchor_gradient_bytes(S) bytes,
@@ -123,7 +123,7 @@ int bsr_anchor_render_backward(int n_anchors, int n_offsets, int num_selected, i
                                float* gradient_scratch,
                                float* dL_danchor, float* dL_dgrid_scaling, float* dL_dgrid_offsets,
                                float* dL_dneural_opacity, float* dL_dcolor, float* dL_dscale_rot,
-                               int debug, void* stream);
+                               int debug, void* stream, unsigned flags);
 
 #ifdef __cplusplus
 }

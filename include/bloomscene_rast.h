@@ -9,14 +9,17 @@
  * Every function returns 0 on success, non-zero on failure; bsr_last_error() then describes it.
  * Memory ownership is the reference's (rasterize_points.cu:27-33, rasterizer_impl.h:22-27): every byte of device
  * memory -- inputs, outputs, gradients and ALL scratch of forward and backward -- belongs to the caller; the library
- * allocates no device memory and touches no allocator or memory-pool setting.  (The one exception is 4 bytes of
- * stream-ordered memory for the error flag of a prefiltered = 1 call to bsr_visible_filter.)  The backward's 48
- * bytes per instance of partial sums live in the binning buffer the forward sized, over sections that are dead by
- * then.  The library keeps no results between calls (per host thread: a pinned 32-byte HOST landing buffer, an
- * event and the previous call's shape / num_rendered -- and, for the fused anchor front end, its selection count -- as
- * size hints; process-wide: the two switches of bsr_set_option and the opt-in stage profiler); the three
- * scratch buffers handed from forward to backward are opaque, as in the reference
- * (__init__.py:97,106).
+ * allocates no device memory (no hipMalloc / hipMallocAsync on any path) and touches no allocator or memory-pool
+ * setting.  The backward's 36 bytes (40 with the depth-gradient extension) per kept instance of partial sums live in
+ * the binning buffer the forward sized, over sections that are dead by then.  The library keeps no results between
+ * calls (per host thread: a pinned 32-byte HOST landing buffer -- which also receives the error word of a
+ * prefiltered = 1 call to bsr_visible_filter straight from the kernel --, an event and the previous call's shape /
+ * num_rendered -- and, for the fused anchor front end, its selection count -- as size hints; process-wide: the
+ * opt-in stage profiler and one test hook, bsr_set_option); the three scratch buffers handed from forward to backward
+ * are opaque, as in the reference (__init__.py:97,106).
+ * NUMERICS ARE PER CALL: the `flags` argument of bsr_forward_ex / bsr_backward_ex (BSR_FLAG_*).  There is no
+ * process-wide numerics switch; two host threads may run different modes side by side (the reference interface has
+ * no global mutable state either, rasterizer_impl.cu:228,241,286,435-437).
  *
  * Reference paths below are relative to
  *   /root/reference/submodules/depth-diff-gaussian-rasterization/
@@ -31,7 +34,28 @@
 extern "C" {
 #endif
 
-#define BSR_VERSION 1
+#define BSR_VERSION 2
+
+/* ---- per-call numerics flags (bsr_forward_ex, bsr_backward_ex, bsr_forward_views, the fused anchor front end) ------
+ * BSR_FLAG_EXACT_EXP   forward: 0 (default) = the blend takes exp(power) from the hardware's v_exp_f32 (1 ulp) wherever
+ *                      only its VALUE is needed, and from the library's pinned exp (the one the CPU oracle restates)
+ *                      wherever the `alpha >= 1/255` decision of forward.cu:423-428 could depend on the last bit (a wave
+ *                      with a pixel within 1.1e-3 of the cut in the exponent): every such decision, radii, num_rendered
+ *                      and the per-tile lists are identical to the exact mode; colour / depth / final_T move by a few ulp
+ *                      (the reference's own CUDA expf is a 2-ulp function), and the `T (1 - alpha) < 1e-4` stop of
+ *                      :433-437 sees a T that differs by those ulps.  Set: the pinned exp on every evaluation -- the
+ *                      forward then matches the CPU oracle bit for bit.  Accepted and ignored by the backward (a caller
+ *                      may hand one flags word to both).
+ * BSR_FLAG_EXACT_GRAD  backward: 0 (default) = k_render_bwd evaluates each (pixel, Gaussian) pair with hardware exp
+ *                      outside the decision band, reciprocal + one refinement instead of the two divisions, fused
+ *                      multiply-adds, moment sums and one projected accum_rec (DESIGN.md "Numerics").  Set: the reference's
+ *                      per-pair operations on the reference's operands (backward.cu:521,527-536,557,561-583: IEEE
+ *                      divisions, no contraction, the pinned exp, per-channel accum_rec, per-pair products) -- only the
+ *                      ORDER of the sums then differs from a sequential evaluation; SURVEY.md 8(d)'s share of elements off
+ *                      by more than 1e-4 falls below the summation-order floor.  Costs ~1.8x in that kernel.  Accepted
+ *                      and ignored by the forward. */
+#define BSR_FLAG_EXACT_EXP  1u
+#define BSR_FLAG_EXACT_GRAD 2u
 
 /* Resize callback for an opaque scratch buffer: must return a device pointer to at least
  * `bytes` bytes (256-byte aligned) that stays valid until the matching backward call.
@@ -98,6 +122,35 @@ int bsr_forward(bsr_alloc_fn geometryBuffer, void* geometry_user,
                 void* stream,
                 int* num_rendered);
 
+/* bsr_forward with per-call numerics: flags = BSR_FLAG_EXACT_EXP or 0 (bsr_forward == flags 0).  Same reference
+ * counterpart (cuda_rasterizer/rasterizer.h:31-54); the reference has one numerics mode, nvcc's expf. */
+int bsr_forward_ex(bsr_alloc_fn geometryBuffer, void* geometry_user,
+                   bsr_alloc_fn binningBuffer, void* binning_user,
+                   bsr_alloc_fn imageBuffer, void* image_user,
+                   int P, int D, int M,
+                   const float* background,
+                   int width, int height,
+                   const float* means3D,
+                   const float* shs,
+                   const float* colors_precomp,
+                   const float* opacities,
+                   const float* scales,
+                   float scale_modifier,
+                   const float* rotations,
+                   const float* cov3D_precomp,
+                   const float* viewmatrix,
+                   const float* projmatrix,
+                   const float* cam_pos,
+                   float tan_fovx, float tan_fovy,
+                   int prefiltered,
+                   float* out_color,
+                   float* out_depth,
+                   int* radii,
+                   int debug,
+                   void* stream,
+                   int* num_rendered,
+                   unsigned flags);
+
 /* radii[P] of the Gaussians as the forward pass would compute them (0 = culled); nothing else.
  * Needs no scratch (the reference allocates and discards full state, rasterizer_impl.cu:361-375).
  * Replaces CudaRasterizer::Rasterizer::visible_filter, cuda_rasterizer/rasterizer.h:57-73
@@ -126,7 +179,8 @@ int bsr_visible_filter(int P, int M,
  * image of n_views * ceil(H/16) tile rows, so binning, per-tile sort and render run once over all of them:
  * the sparse views of a camera sweep (few visible Gaussians each) are launch/latency bound one at a time.
  * Scratch grows with n_views (geometry: n_views * P rows).  No reference counterpart: the reference renders
- * the rotate360 sweep view by view (bloomscene.py:191-193 -> gaussian_renderer/__init__.py:224-262). */
+ * the rotate360 sweep view by view (bloomscene.py:191-193 -> gaussian_renderer/__init__.py:224-262).
+ * flags: BSR_FLAG_EXACT_EXP or 0, as bsr_forward_ex. */
 int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user,
                       bsr_alloc_fn binningBuffer, void* binning_user,
                       bsr_alloc_fn imageBuffer, void* image_user,
@@ -151,7 +205,8 @@ int bsr_forward_views(bsr_alloc_fn geometryBuffer, void* geometry_user,
                       int* radii,
                       int debug,
                       void* stream,
-                      int* num_rendered);
+                      int* num_rendered,
+                      unsigned flags);
 
 /* bsr_visible_filter plus the index list of the visible points: radii[P] exactly as bsr_visible_filter writes it,
  * visible_idx[P] (int32) whose first *num_visible (HOST int) entries are, ascending, the indices i with
@@ -207,7 +262,11 @@ int bsr_visible_filter_views(int P, int n_views,
  * bytes per rank written instead of 4 P per view, and no radii > 0 / any() passes afterwards.
  * group_counts (DEVICE uint32[n_groups], may be NULL): the number of ones in each row of group_mask, written by this
  * call (what the caller needs to size its compaction: a 4*n_groups-byte read-back instead of a
- * reduction over the masks). */
+ * reduction over the masks).  count_scratch: DEVICE, bsr_visible_groups_scratch_bytes(P, n_groups) bytes, needed
+ * (and touched) only when group_counts is non-NULL -- per-workgroup partial counts; the caller's memory like every
+ * other scratch of this library.  P == 0 or n_groups == 0: group_mask has no elements and is not touched;
+ * group_counts (if given) is zeroed. */
+size_t bsr_visible_groups_scratch_bytes(int P, int n_groups);
 int bsr_visible_filter_groups(int P, int n_views, int n_groups,
                               int width, int height,
                               const float* means3D, const float* scales, float scale_modifier,
@@ -215,6 +274,7 @@ int bsr_visible_filter_groups(int P, int n_views, int n_groups,
                               const float* viewmatrices, const float* projmatrices,
                               float tan_fovx, float tan_fovy,
                               const int* group_of_view, uint8_t* group_mask, uint32_t* group_counts,
+                              void* count_scratch,
                               int debug, void* stream);
 
 /* EXTENSION (views.scatter_visible_gaussians): dst[r] = the rows idx[r * idx_stride] of n_src (<= 8) per-Gaussian fp32
@@ -320,10 +380,49 @@ int bsr_backward_depth(int P, int D, int M, int R,
                        int debug,
                        void* stream);
 
+/* bsr_backward / bsr_backward_depth with per-call numerics.  out_depth == NULL: the reference's backward (dL_depths
+ * accepted and ignored, == bsr_backward); non-NULL: the depth-gradient extension (== bsr_backward_depth).
+ * flags: BSR_FLAG_EXACT_GRAD or 0 (BSR_FLAG_EXACT_EXP is accepted and ignored).  Same reference counterpart as
+ * bsr_backward (cuda_rasterizer/rasterizer.h:75-105; the per-pair operations BSR_FLAG_EXACT_GRAD restores are
+ * backward.cu:521,527-536,557,561-583). */
+int bsr_backward_ex(int P, int D, int M, int R,
+                    const float* background,
+                    int width, int height,
+                    const float* means3D,
+                    const float* shs,
+                    const float* colors_precomp,
+                    const float* scales,
+                    float scale_modifier,
+                    const float* rotations,
+                    const float* cov3D_precomp,
+                    const float* viewmatrix,
+                    const float* projmatrix,
+                    const float* campos,
+                    float tan_fovx, float tan_fovy,
+                    const int* radii,
+                    char* geom_buffer,
+                    char* binning_buffer,
+                    char* image_buffer,
+                    const float* out_depth,
+                    const float* dL_dpix,
+                    const float* dL_depths,
+                    float* dL_dmean2D,
+                    float* dL_dconic,
+                    float* dL_dopacity,
+                    float* dL_dcolor,
+                    float* dL_dmean3D,
+                    float* dL_dcov3D,
+                    float* dL_dsh,
+                    float* dL_dscale,
+                    float* dL_drot,
+                    int debug,
+                    void* stream,
+                    unsigned flags);
+
 /* Scratch sizes, for callers that pre-allocate instead of growing inside the callback
  * (the reference's required<T>(n), cuda_rasterizer/rasterizer_impl.h:68-73). */
 size_t bsr_geometry_bytes(int P);
-size_t bsr_binning_bytes(int num_rendered);   /* 44 B / instance + 2 MB: point list, radix ping-pong buffers = backward slab */
+size_t bsr_binning_bytes(int num_rendered);   /* 44 B / instance + 2 MB: point list (4 B) + radix ping-pong buffers (2 x 12 B) or, over the same bytes, the backward slab (40 B) */
 size_t bsr_image_bytes(int width, int height);
 
 /* Byte offset, inside the image buffer a forward call filled, of its float final_T[height * width] (the
@@ -332,20 +431,11 @@ size_t bsr_image_bytes(int width, int height);
  * used by the host's opt-in return_alpha extension. */
 size_t bsr_transmittance_offset(const void* image_buffer);
 
-/* ---- process-wide options (no reference counterpart) ------------------------------------
+/* ---- process-wide test hook (no reference counterpart; changes no result) -----------------------
  * bsr_set_option(name, value) -> 0, or 1 for an unknown name; bsr_get_option(name) -> value, or -1.
- *   "exact_exp"       0 (default): the forward blend takes exp(power) from the hardware's v_exp_f32 (1 ulp) wherever
- *                     only its VALUE is needed, and from the library's pinned, correctly-ordered exp (the one the CPU
- *                     oracle restates) wherever the `alpha >= 1/255` decision of forward.cu:423-428 could depend on
- *                     the last bit (a wave with a pixel within 1e-3 of the cut in the exponent): every such decision,
- *                     radii, num_rendered and the per-tile lists are identical to the exact mode; colour / depth /
- *                     final_T move by a few ulp (<= 1e-6 relative, the reference's own CUDA expf is a 2-ulp function),
- *                     and the `T (1 - alpha) < 1e-4` stop of :433-437 sees a T that differs by those ulps.
- *                     1: the pinned exp on every evaluation -- the forward then matches the CPU oracle bit for bit
- *                     (what the parity tests switch on to prove every other operation of the forward exact).
- *   "sort_force_int"  test hook, default 0: 1 sends every per-tile sort through the integer compare-exchange flavour
- *                     that real inputs reach only with NaN / non-positive depth bits.
- * Options are read at every launch (atomics); calls already enqueued keep the value they were launched with. */
+ *   "sort_force_int"  default 0: 1 sends every per-tile sort through the integer compare-exchange flavour
+ *                     that real inputs reach only with NaN / non-positive depth bits (same order either way).
+ * Numerics are NOT options: see BSR_FLAG_* above.  Read at every launch (atomic). */
 int bsr_set_option(const char* name, int value);
 int bsr_get_option(const char* name);
 

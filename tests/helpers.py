@@ -112,8 +112,9 @@ def hip_settings(c, device, debug=False, prefiltered=False):
         prefiltered=prefiltered, debug=debug)
 
 
-def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False):
-    """The reference call shape (gaussian_renderer/__init__.py:224-262) against the HIP path."""
+def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False, strict_gradients=None, exact_exp=None):
+    """The reference call shape (gaussian_renderer/__init__.py:224-262) against the HIP path.  Numerics: the calling
+    thread's bloomscene_amd.numerics context unless given explicitly."""
     from bloomscene_amd import GaussianRasterizer
     dev = torch.device(device)
 
@@ -124,7 +125,8 @@ def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False):
                           cov3D_precomp=leaf(c.cov3D_precomp))
     means2D = torch.zeros_like(inp.means3D, requires_grad=True) + 0
     means2D.retain_grad()
-    rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug), depth_gradient=depth_gradient)
+    rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug), depth_gradient=depth_gradient,
+                              exact_exp=exact_exp, strict_gradients=strict_gradients)
     color, radii, depth = rast(means3D=inp.means3D, means2D=means2D, opacities=inp.opacities, shs=inp.shs,
                                colors_precomp=inp.colors_precomp, scales=inp.scales, rotations=inp.rotations,
                                cov3D_precomp=inp.cov3D_precomp)
@@ -170,6 +172,45 @@ def rel_err(a, b):
 GRAD_KEYS = ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
 
 
+def forward_outliers(got, ref):
+    """SURVEY.md 8(d) on one image: (number of elements whose |a-b| / max(|b|, 1e-6 max|b|) exceeds 1e-4, the largest
+    such ratio among the others, element count)."""
+    a = np.asarray(got, dtype=np.float64).reshape(-1)
+    b = np.asarray(ref, dtype=np.float64).reshape(-1)
+    if b.size == 0:
+        return 0, 0.0, 0
+    scale = max(np.abs(b).max(), 1e-30)
+    e = np.abs(a - b) / np.maximum(np.abs(b), 1e-6 * scale)
+    out = e > 1e-4
+    return int(out.sum()), float(e[~out].max()) if (~out).any() else 0.0, int(b.size)
+
+
+def assert_forward_parity(mode, color, depth, st, label="", radii=None, allow=0):
+    """Forward images of one call against the oracle state `st`, by the call's mode:
+      "exact"   (BSR_FLAG_EXACT_EXP)  colour and depth BIT-EQUAL;
+      "default" (what bench.py times) SURVEY.md 8(d)'s own metric on colour and on depth: every element within 1e-4
+                relative (denominator max(|ref|, 1e-6 max|ref|)) except a COUNTED outlier set of at most a 1e-5 share
+                of the elements (+ `allow` for cases pinned because a stop / depth-validity decision moves there:
+                DESIGN.md "Numerics"); the counts are printed (pytest -s) and returned.
+    radii (if given) must be identical in either mode."""
+    color, depth = np.asarray(color), np.asarray(depth)
+    if radii is not None:
+        np.testing.assert_array_equal(np.asarray(radii), st.radii)
+    if mode == "exact":
+        np.testing.assert_array_equal(color.view(np.uint32), st.color.view(np.uint32))
+        np.testing.assert_array_equal(depth.view(np.uint32), st.depth.view(np.uint32))
+        return dict(color=0, depth=0)
+    assert mode == "default", mode
+    counts = {}
+    for name, got, ref in (("color", color, st.color), ("depth", depth, st.depth)):
+        n_out, worst, numel = forward_outliers(got, ref)
+        counts[name] = n_out
+        print(f"[8d-fwd] {label:28s} {name:5s} default mode: {n_out} of {numel} elements beyond 1e-4 relative "
+              f"(allowed {1e-5 * numel + allow:.1f}); largest ratio among the rest {worst:.2e}")
+        assert n_out <= 1e-5 * numel + allow, (label, name, n_out, numel)
+    return counts
+
+
 def contracted_oracle_grads(c):
     """The oracle's gradients of case `c` from oracle/libbsr_oracle_fma.so (make -C oracle fma): bsro_render_backward
     compiled WITH fp contraction -- what nvcc does to the reference by default (its setup.py passes no -fmad=false).
@@ -197,6 +238,39 @@ def contracted_oracle_grads(c):
             return None
         with np.load(os.path.join(d, "g.npz")) as z:
             return SimpleNamespace(**{k: (z[k] if k in z.files else None) for k in GRAD_KEYS})
+
+
+def assert_strict_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS):
+    """Gradients of a BSR_FLAG_EXACT_GRAD (strict_gradients=True) call against the oracle: k_render_bwd then performs
+    the reference's per-pair operations on the reference's operands (backward.cu:521,527-536,557,561-583) and only the
+    ORDER of the nine sums differs, so SURVEY.md 8(d)'s share of elements beyond 1e-4 relative must not exceed what
+    summation order alone costs the reference -- the oracle's fp32 terms added in binary32 in one fixed order against
+    its own binary64 sums (`floor`) -- or 8(d)'s own 1e-5 allowance where that floor is smaller.  Both shares are COUNTS
+    of elements that happen to sit near the 1e-4 line (a dozen of 12 000 on the small cases), so the comparison allows the
+    counting noise of the floor: 3 sigma of a Poisson count + 4 elements.  At C3 / C5 (hundreds of counted elements)
+    that slack is 4 % / 2 % of the floor, and the measured share is 0.5 - 0.65 x the floor.  Norm-wise < 1e-5 as
+    everywhere."""
+    og = oracle_grads(c, g)
+    og32 = oracle_grads(c, O.backward(st, c.gC, c.gD, f32_sums=True))
+    rows = {}
+    for k in keys:
+        ref, got = getattr(og, k), getattr(grads, k)
+        if ref is None:
+            assert got is None, k
+            continue
+        assert got is not None and got.shape == ref.shape, k
+        assert np.isfinite(got).all(), k
+        m, frac = rel_err(got, ref)
+        _, floor = rel_err(getattr(og32, k), ref)
+        scale = max_err_over_scale(got, ref)
+        rows[k] = dict(max_rel=m, frac=frac, floor_frac=floor, scale=scale, numel=int(ref.size))
+        print(f"[8d-strict] {label:24s} dL_d{k:14s} frac>1e-4 {frac:.2e} (summation-order floor {floor:.2e}) "
+              f"max_rel {m:.2e} norm-wise {scale:.1e}")
+        assert scale < 1e-5, (label, k, scale)
+        bar = max(floor, 1e-5)
+        noise = (3.0 * math.sqrt(max(bar * ref.size, 1.0)) + 4.0) / ref.size
+        assert frac <= bar + noise, (label, k, frac, floor, noise)
+    return rows
 
 
 def assert_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS, report=None):

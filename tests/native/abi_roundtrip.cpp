@@ -79,14 +79,19 @@ static bool write_from_device(FILE* f, const T* d, size_t n)
 int main(int argc, char** argv)
 {
 	if (argc != 3 && argc != 4) {
-		fprintf(stderr, "usage: %s inputs.bin outputs.bin [exact]\n", argv[0]);
+		fprintf(stderr, "usage: %s inputs.bin outputs.bin [exact|strict]\n", argv[0]);
 		return 2;
 	}
-	// "exact": the pinned exp on every evaluation of the forward blend, for a bit-for-bit comparison with the CPU
-	// oracle; without it the library's default (hardware exp outside the decision bands)
-	if (argc == 4 && bsr_set_option("exact_exp", strcmp(argv[3], "exact") == 0) != 0) {
-		fprintf(stderr, "bsr_set_option failed: %s\n", bsr_last_error());
-		return 2;
+	// Numerics are per call.  No third argument: the reference-shaped entry points bsr_forward / bsr_backward (the
+	// library's default).  "exact": bsr_forward_ex / bsr_backward_ex with BSR_FLAG_EXACT_EXP (the pinned exp on every
+	// evaluation of the forward blend: bit-for-bit comparable with the CPU oracle); "strict": BSR_FLAG_EXACT_GRAD as well
+	// (the reference's per-pair operations in the backward tile walk).
+	const bool use_ex = argc == 4;
+	unsigned flags = 0;
+	if (use_ex) {
+		if (!strcmp(argv[3], "exact")) flags = BSR_FLAG_EXACT_EXP;
+		else if (!strcmp(argv[3], "strict")) flags = BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD;
+		else { fprintf(stderr, "unknown mode %s\n", argv[3]); return 2; }
 	}
 	FILE* fi = fopen(argv[1], "rb");
 	if (!fi) { perror(argv[1]); return 2; }
@@ -119,9 +124,13 @@ int main(int argc, char** argv)
 	}
 	Scratch geom, binning, img;
 	int num_rendered = -1;
-	int rc = bsr_forward(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
+	int rc = use_ex
+	    ? bsr_forward_ex(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
 	                     use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view,
-	                     d_proj, d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &num_rendered);
+	                     d_proj, d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &num_rendered, flags)
+	    : bsr_forward(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
+	                  use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view,
+	                  d_proj, d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &num_rendered);
 	if (rc != 0) { fprintf(stderr, "bsr_forward: %s\n", bsr_last_error()); return 1; }
 
 	float* g_mean2D = device_out<float>((size_t)3 * P);
@@ -133,10 +142,16 @@ int main(int argc, char** argv)
 	float* g_sh = device_out<float>(use_sh ? (size_t)3 * M * P : 1);
 	float* g_scale = device_out<float>((size_t)3 * P);
 	float* g_rot = device_out<float>((size_t)4 * P);
-	rc = bsr_backward(P, D, use_sh ? M : 0, num_rendered, d_bg, W, H, d_means, use_sh ? d_col : nullptr,
-	                  use_sh ? nullptr : d_col, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, d_cam, fl[0], fl[1], radii,
-	                  geom.ptr, binning.ptr, img.ptr, d_gC, d_gD, g_mean2D, g_conic, g_opac, g_col, g_mean3D, g_cov3D,
-	                  use_sh ? g_sh : nullptr, g_scale, g_rot, 0, stream);
+	rc = use_ex
+	    ? bsr_backward_ex(P, D, use_sh ? M : 0, num_rendered, d_bg, W, H, d_means, use_sh ? d_col : nullptr,
+	                      use_sh ? nullptr : d_col, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, d_cam, fl[0], fl[1], radii,
+	                      geom.ptr, binning.ptr, img.ptr, /*out_depth: the reference's backward*/ nullptr, d_gC, d_gD,
+	                      g_mean2D, g_conic, g_opac, g_col, g_mean3D, g_cov3D, use_sh ? g_sh : nullptr, g_scale, g_rot, 0,
+	                      stream, flags)
+	    : bsr_backward(P, D, use_sh ? M : 0, num_rendered, d_bg, W, H, d_means, use_sh ? d_col : nullptr,
+	                   use_sh ? nullptr : d_col, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, d_cam, fl[0], fl[1], radii,
+	                   geom.ptr, binning.ptr, img.ptr, d_gC, d_gD, g_mean2D, g_conic, g_opac, g_col, g_mean3D, g_cov3D,
+	                   use_sh ? g_sh : nullptr, g_scale, g_rot, 0, stream);
 	if (rc != 0) { fprintf(stderr, "bsr_backward: %s\n", bsr_last_error()); return 1; }
 	HIP_OK(hipStreamSynchronize(stream));
 
@@ -154,8 +169,10 @@ int main(int argc, char** argv)
 		HIP_OK(hipMemcpy(d_group, &group0, sizeof(int), hipMemcpyHostToDevice));
 		HIP_OK(hipMalloc((void**)&d_mask, (size_t)P + 16));
 		HIP_OK(hipMalloc((void**)&d_count, sizeof(uint32_t)));
+		void* d_count_scratch = nullptr;   // the filter's per-workgroup counts: the caller's memory, sized by the library
+		HIP_OK(hipMalloc(&d_count_scratch, bsr_visible_groups_scratch_bytes(P, 1) + 16));
 		rc = bsr_visible_filter_groups(P, 1, 1, W, H, d_means, d_sc, fl[2], d_rot, nullptr, d_view, d_proj, fl[0], fl[1],
-		                               d_group, d_mask, d_count, 0, stream);
+		                               d_group, d_mask, d_count, d_count_scratch, 0, stream);
 		if (rc != 0) { fprintf(stderr, "bsr_visible_filter_groups: %s\n", bsr_last_error()); return 1; }
 		HIP_OK(hipStreamSynchronize(stream));
 		std::vector<uint8_t> h_mask((size_t)P);

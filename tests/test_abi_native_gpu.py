@@ -1,7 +1,9 @@
 """The C ABI used from a program that knows nothing about torch or python: tests/native/abi_roundtrip.cpp
-(plain hipMalloc'd buffers, C scratch callbacks, its own stream) runs bsr_forward + bsr_backward on a seeded
-scene written to a file; its outputs must match the CPU oracle exactly as the python host's do -- forward bit-exact,
-gradients within 1e-5 of each tensor's scale."""
+(plain hipMalloc'd buffers, C scratch callbacks, its own stream) runs bsr_forward + bsr_backward -- or, given a mode,
+bsr_forward_ex + bsr_backward_ex with that mode's per-call flags -- on a seeded scene written to a file; its outputs
+must match the CPU oracle exactly as the python host's do: forward bit-exact with BSR_FLAG_EXACT_EXP and by SURVEY.md
+8(d)'s elementwise metric through the plain entry points, gradients within 1e-5 of each tensor's scale, and at the
+summation-order floor with BSR_FLAG_EXACT_GRAD."""
 import os
 import subprocess
 
@@ -23,7 +25,8 @@ def _f32(t):
                                 dict(P=2500, W=96, H=64, deg=0, seed=52, scale_mul=5.0, color_mode="precomp",
                                      free_camera=True)],
                          ids=["sh3", "precomp_free_camera"])
-def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
+@pytest.mark.parametrize("mode", ["plain", "exact", "strict"])
+def test_forward_backward_through_a_torch_free_consumer(kw, mode, tmp_path):
     if not os.path.exists(EXE):   # normally built by __graft_entry__.build(); hipcc is on the GPU box too
         subprocess.run(["make", "-C", os.path.dirname(EXE)], capture_output=True, timeout=300)
     assert os.path.exists(EXE), "tests/native/abi_roundtrip missing: run __graft_entry__.build()"
@@ -40,7 +43,8 @@ def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
         for a in (c.bg, c.means3D, c.shs if use_sh else c.colors_precomp, c.opacities, c.scales, c.rotations,
                   c.cam.world_view_transform, c.cam.full_proj_transform, c.cam.camera_center, c.gC, c.gD):
             _f32(a).tofile(f)
-    r = subprocess.run([EXE, str(inp), str(outp), "exact"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([EXE, str(inp), str(outp)] + ([] if mode == "plain" else [mode]), capture_output=True, text=True,
+                       timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_roundtrip ok" in r.stdout and "sweep helpers ok" in r.stdout
     N = W * H
@@ -58,13 +62,17 @@ def test_forward_backward_through_a_torch_free_consumer(kw, tmp_path):
                    rotations=np.fromfile(f, np.float32, 4 * P).reshape(P, 4))
         assert f.read() == b""
     assert nr == st.num_rendered
-    np.testing.assert_array_equal(radii, st.radii)
-    np.testing.assert_array_equal(color.view(np.uint32), st.color.view(np.uint32))
-    np.testing.assert_array_equal(depth.view(np.uint32), st.depth.view(np.uint32))
+    Hh.assert_forward_parity("default" if mode == "plain" else "exact", color, depth, st, label="abi:" + mode, radii=radii)
     og = Hh.oracle_grads(c, g)
     keys = ["means3D", "means2D", "opacities", "scales", "rotations"] + (["shs"] if use_sh else ["colors_precomp"])
     for k in keys:
         ref = getattr(og, k)
         assert np.isfinite(got[k]).all(), k
         assert Hh.max_err_over_scale(got[k], ref) < 1e-5, k
+    if mode == "strict":
+        from types import SimpleNamespace
+        grads = SimpleNamespace(**{k: got.get(k) for k in Hh.GRAD_KEYS})
+        if use_sh:
+            grads.colors_precomp = None   # (an intermediate result when SH is the colour input)
+        Hh.assert_strict_gradient_parity(c, st, g, grads, label="abi:strict", keys=keys)
 

@@ -76,3 +76,42 @@ def test_bounding_square_cull_never_drops_a_visible_pair():
             kept += int(vis.sum())
             culled += int(outside.sum())
     assert kept > 1000 and culled > 10 * kept // 100      # the test saw visible pairs, and the cull is not vacuous
+
+
+def test_radius_bound_holds_for_adversarial_indefinite_covariances():
+    """the kernel's comment derives lambda_max <= 1.5 B + 0.62 with a step that reads as if S were
+    positive semi-definite.  The bound itself needs no such assumption: the reference's lambda_1 = mid + sqrt(max(0.1,
+    mid^2 - det)) is max(largest eigenvalue of cov2D, mid + sqrt(0.1)), cov2D = A S A^T + 0.3 I, and for ANY symmetric
+    S the eigenvalues of A S A^T lie in [-B', B'] with B' = |A|_2^2 |S|_2 <= B, so lambda_1 <= B + 0.3 + sqrt(0.1)
+    < 1.5 B + 0.62.  Checked where it would break first: rank-2 covariances s (u u^T - w w^T) with u, w orthonormal (one
+    eigenvalue +s, one -s: the widest eigenvalue gap a given Frobenius norm allows), u swept over directions including
+    the rows of the projection Jacobian, s over ten decades; the oracle's radius must stay below the cull's bound and no
+    visible pair may be dropped."""
+    gen = torch.Generator().manual_seed(321)
+    P, W, H = 60000, 200, 120
+    sc = scene_b(P, W, H, 1, n_views=4, seed=9)
+    means = (sc.means3D * torch.exp(torch.rand(P, 1, generator=gen) * 4.0 - 2.0)).numpy().astype(np.float32)
+    u = torch.randn(P, 3, generator=gen)
+    u[: P // 3] = torch.tensor([1.0, 0.0, 0.0])       # along / across the image axes of an axis-aligned camera
+    u[P // 3: 2 * P // 3] = torch.tensor([0.0, 1.0, 0.0])
+    u = u / u.norm(dim=1, keepdim=True)
+    w = torch.randn(P, 3, generator=gen)
+    w = w - (w * u).sum(1, keepdim=True) * u
+    w = w / w.norm(dim=1, keepdim=True)
+    s = torch.exp(torch.rand(P, 1, 1, generator=gen) * 23.0 - 16.0)          # 1e-7 .. 1e3
+    S = s * (u[:, :, None] * u[:, None, :] - w[:, :, None] * w[:, None, :])
+    sym = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1).numpy().astype(np.float32)
+    tanx, tany = math.tan(sc.cameras[0].FoVx * 0.5), math.tan(sc.cameras[0].FoVy * 0.5)
+    kept = 0
+    for v, cam in enumerate(sc.cameras):
+        vm = cam.world_view_transform.numpy().astype(np.float32).copy()
+        pm = cam.full_proj_transform.numpy().astype(np.float32)
+        rs = O.make_settings(H, W, tanx, tany, [0, 0, 0], 1.0, vm, pm, 1, cam.camera_center)
+        st = O._preprocess(rs, means, None, None, None, None, None, sym, True)
+        radii = np.asarray(st.radii)
+        outside, rb = cull_outside(means, sym, vm.reshape(-1), pm.reshape(-1), W, H, tanx, tany)
+        vis = radii > 0
+        assert not (outside & vis).any(), (v, int((outside & vis).sum()))
+        assert (rb[vis] >= radii[vis]).all(), (v, float((radii[vis] / rb[vis]).max()))
+        kept += int(vis.sum())
+    assert kept > 2000

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bloomscene_rast.h but not exported"
     assert declared == set(_capi.SIGNATURES), "ctypes table and header disagree"
-    assert lib.bsr_version() == 1
+    assert lib.bsr_version() == 2
     assert lib.bsr_last_error() == b""
     # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
     assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)
@@ -313,11 +313,12 @@ def test_camera_pack_and_multi_view_helpers_on_cpu():
     with pytest.raises(RuntimeError, match="GPU"):
         render_anchors(torch.zeros(2, 3), torch.ones(2, 6), torch.zeros(2, 5, 3), torch.ones(10, 1), torch.zeros(10, 3),
                        torch.zeros(10, 7), _settings())
-    # process-wide options: known names round-trip, unknown ones are an error with a message
-    assert _capi.get_option("exact_exp") == 0
-    _capi.set_option("exact_exp", 1)
-    assert _capi.get_option("exact_exp") == 1
-    _capi.set_option("exact_exp", 0)
+    # the process-wide test hook round-trips; numerics are NOT options (per call: BSR_FLAG_*), unknown names are an error
+    assert _capi.get_option("sort_force_int") == 0
+    _capi.set_option("sort_force_int", 1)
+    assert _capi.get_option("sort_force_int") == 1
+    _capi.set_option("sort_force_int", 0)
+    assert _capi.get_option("exact_exp") == -1
     assert _capi.get_option("no_such_option") == -1
     with pytest.raises(RuntimeError, match="unknown option"):
         _capi.set_option("no_such_option", 1)
@@ -333,3 +334,29 @@ def test_bench_refuses_more_ranks_than_gpus_with_a_message():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "GPU(s)" in (r.stderr + r.stdout)
+
+
+def test_numerics_context_is_thread_local_and_nests():
+    """The python host's default mode of a call (bloomscene_amd.numerics) is per THREAD and nests; explicit arguments
+    win over it.  (The C library itself holds no numerics state: include/bloomscene_rast.h BSR_FLAG_*.)"""
+    import threading
+    from bloomscene_amd import numerics
+    from bloomscene_amd.numerics import FLAG_EXACT_EXP, FLAG_EXACT_GRAD, resolve_flags
+    assert resolve_flags() == 0
+    seen = {}
+    with numerics(exact_exp=True):
+        assert resolve_flags() == FLAG_EXACT_EXP
+        with numerics(strict_gradients=True):
+            assert resolve_flags() == FLAG_EXACT_EXP | FLAG_EXACT_GRAD
+            assert resolve_flags(exact_exp=False) == FLAG_EXACT_GRAD
+            with numerics(exact_exp=False, strict_gradients=False):
+                assert resolve_flags() == 0
+            t = threading.Thread(target=lambda: seen.setdefault("other", resolve_flags()))
+            t.start()
+            t.join()
+        assert resolve_flags() == FLAG_EXACT_EXP
+        assert resolve_flags(strict_gradients=True) == FLAG_EXACT_EXP | FLAG_EXACT_GRAD
+    assert resolve_flags() == 0 and seen["other"] == 0
+    from bloomscene_amd import GaussianRasterizer
+    r = GaussianRasterizer(_settings(), exact_exp=True, strict_gradients=True)
+    assert r._flags() == 3 and GaussianRasterizer(_settings())._flags() == 0

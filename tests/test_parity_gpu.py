@@ -2,9 +2,12 @@
 oracle and the committed golden fixtures.  Run on the MI355X box: pytest -m gpu.
 
 Bars (north_star: outputs within 1e-4 rel fp32):
-* forward -- radii, num_rendered, final_T, colour, depth: BIT-EXACT.  The kernels evaluate every fp32
-  expression in the reference's order (no FMA contraction) and use the same pinned exp as the oracle,
-  so there is no tolerance to argue about.  Per-tile lists: order-preserving sub-sequences of the
+* forward, exact mode (BSR_FLAG_EXACT_EXP; every test here runs inside bloomscene_amd.numerics(exact_exp=True)
+  unless it takes the `exp_mode` fixture) -- radii, num_rendered, final_T, colour, depth: BIT-EXACT.  The kernels
+  evaluate every fp32 expression in the reference's order (no FMA contraction) and use the same pinned exp as the
+  oracle, so there is no tolerance to argue about.  Tests that take `exp_mode` run a second time in the library's
+  DEFAULT mode (the one bench.py times): discrete results identical, colour and depth by SURVEY.md 8(d)'s
+  elementwise metric with a counted outlier set (helpers.assert_forward_parity).  Per-tile lists: order-preserving sub-sequences of the
   reference's stable-sort order; the (Gaussian, tile) instances missing from them are checked, pixel by
   pixel in float64, to be unable to contribute (helpers.check_lists_against_oracle).
 * backward, stage A (the 9 per-Gaussian sums the reference forms with unordered float atomicAdd):
@@ -93,20 +96,23 @@ def _native_forward(c, debug=False, prefiltered=False):
     return rs, t, R, color, depth, radii, gb, bb, ib
 
 
-def _assert_forward_bit_exact(c, st):
+def _assert_forward_bit_exact(c, st, mode="exact", label=""):
+    """mode "exact": everything bit-equal.  mode "default": the discrete results (radii, num_rendered, projected centres,
+    depths) bit-equal, images by SURVEY.md 8(d) (helpers.assert_forward_parity); the per-tile lists of the default mode
+    are compared with the exact mode's in test_round3_gpu._compare_default_with_exact."""
     rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
     assert R == st.num_rendered
     np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
     b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
     # lists: order-preserving sub-sequences of the reference's (tile, depth bits, id) order; what the
     # exact tile-level cull dropped is inert; n_contrib designates the same Gaussian
-    if c.W * c.H <= 1920 * 1080 // 4:
+    if c.W * c.H <= 1920 * 1080 // 4 and mode == "exact":
         kept_fraction = Hh.check_lists_against_oracle(c, st, b)
         assert 0.0 < kept_fraction <= 1.0 or R == 0
     assert b.kept <= R
-    np.testing.assert_array_equal(b.final_T.view(np.uint32), st.final_T.view(np.uint32))
-    np.testing.assert_array_equal(color.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
-    np.testing.assert_array_equal(depth.cpu().numpy().view(np.uint32), st.depth.view(np.uint32))
+    if mode == "exact":
+        np.testing.assert_array_equal(b.final_T.view(np.uint32), st.final_T.view(np.uint32))
+    Hh.assert_forward_parity(mode, color.cpu().numpy(), depth.cpu().numpy(), st, label=label)
     vis = st.radii > 0
     np.testing.assert_array_equal(b.rec[vis][:, 0:2], st.means2D[vis])
     np.testing.assert_array_equal(b.rec[vis][:, 7], st.depths[vis])
@@ -121,8 +127,10 @@ def test_forward_bit_exact_vs_oracle(name):
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_forward_and_backward_vs_golden_fixture(path):
-    """HIP path against the committed vectors alone (inputs and expected outputs from the .npz)."""
+def test_forward_and_backward_vs_golden_fixture(path, exp_mode):
+    """HIP path against the committed vectors alone (inputs and expected outputs from the .npz), in both forward
+    modes."""
+    from types import SimpleNamespace
     from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer
     z = np.load(path)
     dev = _dev()
@@ -141,9 +149,9 @@ def test_forward_and_backward_vs_golden_fixture(path):
         sh_degree=deg, campos=torch.from_numpy(z["in_campos"]).to(dev), prefiltered=False, debug=False)
     means2D = torch.zeros_like(means3D, requires_grad=True)
     color, radii, depth = GaussianRasterizer(rs)(means3D=means3D, means2D=means2D, opacities=opac, **inp)
-    np.testing.assert_array_equal(radii.cpu().numpy(), z["radii"])
-    np.testing.assert_array_equal(color.detach().cpu().numpy().view(np.uint32), z["color"].view(np.uint32))
-    np.testing.assert_array_equal(depth.detach().cpu().numpy().view(np.uint32), z["depth"].view(np.uint32))
+    Hh.assert_forward_parity(exp_mode, color.detach().cpu().numpy(), depth.detach().cpu().numpy(),
+                             SimpleNamespace(color=z["color"], depth=z["depth"], radii=z["radii"]),
+                             label=os.path.basename(path)[:-4], radii=radii.cpu().numpy())
     torch.autograd.backward((color, depth), (torch.from_numpy(z["in_gC"]).to(dev), torch.from_numpy(z["in_gD"]).to(dev)))
     pairs = [(means3D.grad, "dL_dmeans3D"), (means2D.grad, "dL_dmeans2D"), (opac.grad, "dL_dopacity")]
     for k, gname in (("shs", "dL_dsh"), ("colors_precomp", "dL_dcolors"), ("scales", "dL_dscales"),
@@ -154,8 +162,9 @@ def test_forward_and_backward_vs_golden_fixture(path):
         assert Hh.max_err_over_scale(got.cpu().numpy(), z[gname]) < 1e-5, gname
 
 
-def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD):
-    """bsr_backward straight through ctypes, so the internal dL_dconic/dL_dcolor are visible."""
+def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD, flags=None):
+    """bsr_backward (flags None) / bsr_backward_ex straight through ctypes, so the internal dL_dconic/dL_dcolor are
+    visible."""
     from bloomscene_amd import _capi
     dev = _dev()
     P = c.P
@@ -171,14 +180,18 @@ def _raw_backward(c, rs, t, R, radii, gb, bb, ib, gC, gD):
     def p(x):
         return None if x is None or x.numel() == 0 else x.data_ptr()
     gC, gD = gC.to(dev).contiguous(), gD.to(dev).contiguous()
-    rc = _capi.lib().bsr_backward(
-        P, c.deg, M, R, rs.bg.data_ptr(), c.W, c.H, t["means3D"].data_ptr(), p(t["shs"]), p(t["colors"]),
-        p(t["scales"]), float(rs.scale_modifier), p(t["rot"]), p(t["cov"]), rs.viewmatrix.data_ptr(),
-        rs.projmatrix.data_ptr(), rs.campos.data_ptr(), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
-        gb.data_ptr(), p(bb), ib.data_ptr(), gC.data_ptr(), gD.data_ptr(), out["mean2D"].data_ptr(),
-        out["conic"].data_ptr(), out["opacity"].data_ptr(), out["color"].data_ptr(), out["mean3D"].data_ptr(),
-        out["cov3D"].data_ptr(), out["sh"].data_ptr() if M else None, out["scale"].data_ptr(), out["rot"].data_ptr(),
-        0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    head = (P, c.deg, M, R, rs.bg.data_ptr(), c.W, c.H, t["means3D"].data_ptr(), p(t["shs"]), p(t["colors"]),
+            p(t["scales"]), float(rs.scale_modifier), p(t["rot"]), p(t["cov"]), rs.viewmatrix.data_ptr(),
+            rs.projmatrix.data_ptr(), rs.campos.data_ptr(), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
+            gb.data_ptr(), p(bb), ib.data_ptr())
+    tail = (gC.data_ptr(), gD.data_ptr(), out["mean2D"].data_ptr(),
+            out["conic"].data_ptr(), out["opacity"].data_ptr(), out["color"].data_ptr(), out["mean3D"].data_ptr(),
+            out["cov3D"].data_ptr(), out["sh"].data_ptr() if M else None, out["scale"].data_ptr(), out["rot"].data_ptr(),
+            0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if flags is None:
+        rc = _capi.lib().bsr_backward(*head, *tail)
+    else:   # (out_depth NULL: the reference's backward)
+        rc = _capi.lib().bsr_backward_ex(*head, None, *tail, int(flags))
     _capi.check(rc, "bsr_backward")
     torch.cuda.synchronize()
     return {k: v.cpu().numpy() for k, v in out.items()}, M
@@ -191,10 +204,10 @@ BWD_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "precomp_cov", "extraM_s
 
 
 @pytest.mark.parametrize("name", BWD_CASES)
-def test_backward_stagewise_vs_oracle(name):
+def test_backward_stagewise_vs_oracle(name, exp_mode):
     c = Hh.make_case(**CASES[name])
     st, g = Hh.run_oracle(c, backward=True, want_abs_sums=True)
-    rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+    rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st, exp_mode, label=name)
     out, M = _raw_backward(c, rs, t, R, radii, gb, bb, ib, c.gC, c.gD)
 
     # ---- stage A: the nine unordered sums
@@ -383,7 +396,7 @@ def test_alpha_target_extension():
     np.testing.assert_array_equal(color.cpu().numpy().view(np.uint32), st.color.view(np.uint32))
 
 
-def test_gradients_and_outputs_are_bit_reproducible():
+def test_gradients_and_outputs_are_bit_reproducible(exp_mode):
     """No atomics and fixed summation orders everywhere: two runs give identical bits, gradients
     included (the reference's float atomicAdd sums vary from run to run, backward.cu:537-583)."""
     c = Hh.make_case(P=60000, W=400, H=300, deg=2, seed=77, scale_mul=3.0)
@@ -539,6 +552,11 @@ def test_full_size_c3_properties_and_parity():
     np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
     np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
     Hh.assert_gradient_parity(c, st, g, out.grads, label="c3_1M_1920x1080_sh3")
+    # strict gradients (BSR_FLAG_EXACT_GRAD): SURVEY 8(d)'s elementwise share at or below the summation-order floor
+    strict = Hh.run_hip(c, strict_gradients=True)
+    np.testing.assert_array_equal(strict.color.view(np.uint32), st.color.view(np.uint32))
+    Hh.assert_strict_gradient_parity(c, st, g, strict.grads, label="c3_1M_1920x1080_sh3")
+    del strict
     # run-to-run: forward deterministic to the bit
     out2 = Hh.run_hip(c, backward=False)
     np.testing.assert_array_equal(out2.color.view(np.uint32), out.color.view(np.uint32))
@@ -561,16 +579,25 @@ def test_full_size_c3_properties_and_parity():
 
 
 def test_full_size_c5_forward_and_gradients():
-    """BASELINE config C5 (5 M Gaussians, SH 3, 1920x1080, fwd+bwd): forward bit-exact against the oracle at full
-    size (~22 M instances, ~2700 per tile), every gradient by the §8(d) metric, second run identical to the bit."""
+    """BASELINE config C5 (5 M Gaussians, SH 3, 1920x1080, fwd+bwd): forward against the oracle at full size (~22 M
+    instances, ~2700 per tile) in BOTH modes (exact: bit-equal; default: SURVEY 8(d) elementwise), every gradient by the
+    §8(d) metric in both and in the strict-gradient mode, second run identical to the bit.  (One test, one oracle run:
+    the oracle takes minutes at this size.)"""
+    from bloomscene_amd import numerics
     c = Hh.make_case(P=5_000_000, W=1920, H=1080, deg=3, seed=0)
     st, g = Hh.run_oracle(c)
     assert st.num_rendered > 20_000_000
+    with numerics(exact_exp=False):
+        dflt = Hh.run_hip(c)
+    Hh.assert_forward_parity("default", dflt.color, dflt.depth, st, label="c5_5M_1920x1080_sh3", radii=dflt.radii)
+    Hh.assert_gradient_parity(c, st, g, dflt.grads, label="default:c5_5M_1920x1080_sh3")
+    del dflt
     out = Hh.run_hip(c)
-    np.testing.assert_array_equal(out.radii, st.radii)
-    np.testing.assert_array_equal(out.color.view(np.uint32), st.color.view(np.uint32))
-    np.testing.assert_array_equal(out.depth.view(np.uint32), st.depth.view(np.uint32))
+    Hh.assert_forward_parity("exact", out.color, out.depth, st, label="c5_5M_1920x1080_sh3", radii=out.radii)
     Hh.assert_gradient_parity(c, st, g, out.grads, label="c5_5M_1920x1080_sh3")
+    strict = Hh.run_hip(c, strict_gradients=True)
+    Hh.assert_strict_gradient_parity(c, st, g, strict.grads, label="c5_5M_1920x1080_sh3")
+    del strict
     del st, g
     out2 = Hh.run_hip(c)
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
@@ -617,7 +644,7 @@ def test_24M_gaussians_past_4GiB_arrays():
         np.testing.assert_array_equal(getattr(out2.grads, k).view(np.uint32), getattr(out.grads, k).view(np.uint32), err_msg=k)
 
 
-def test_full_size_c4_rotate360_sweep():
+def test_full_size_c4_rotate360_sweep(exp_mode):
     """BASELINE config C4 at full size: scene B, 1 M Gaussians, SH 3, 1920x1080, the 64 views of the rotate360 sweep
     (bloomscene.py:191-193).  Every view rendered through the view-batched entry point (16 views per native call, as
     tools/bench_views.py and bench.py's C4 leg do) must be bit-identical to its own single-view call; six views spread
@@ -650,9 +677,7 @@ def test_full_size_c4_rotate360_sweep():
         rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
                              cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center)
         st = O.forward(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
-        np.testing.assert_array_equal(keep[2][v - 16], st.radii)
-        np.testing.assert_array_equal(keep[0][v - 16].view(np.uint32), st.color.view(np.uint32))
-        np.testing.assert_array_equal(keep[1][v - 16].view(np.uint32), st.depth.view(np.uint32))
+        Hh.assert_forward_parity(exp_mode, keep[0][v - 16], keep[1][v - 16], st, label=f"c4 view {v}", radii=keep[2][v - 16])
     for v in (0, 47):                                               # and two single-view calls elsewhere on the circle
         cam = sc.cameras[v]
         rs = O.make_settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), [0, 0, 0], 1.0,
@@ -660,8 +685,8 @@ def test_full_size_c4_rotate360_sweep():
         st = O.forward(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
         with torch.no_grad():
             res = V.render_view(cams[v], g, bg, 3)
-        np.testing.assert_array_equal(res["render"].cpu().numpy().view(np.uint32), st.color.view(np.uint32))
-        np.testing.assert_array_equal(res["radii"].cpu().numpy(), st.radii)
+        Hh.assert_forward_parity(exp_mode, res["render"].cpu().numpy(), res["depth"].cpu().numpy(), st,
+                                 label=f"c4 view {v}", radii=res["radii"].cpu().numpy())
     masks = V.prefilter_views(cams, g["means3D"], g["scales"], g["rotations"])
     for v in (0, 13, 40, 63):
         assert torch.equal(masks[v], V.prefilter(cams[v], g["means3D"], g["scales"], g["rotations"], bg))
@@ -670,7 +695,7 @@ def test_full_size_c4_rotate360_sweep():
 
 def test_library_owns_no_device_memory():
     """Boundary (SURVEY.md §8b 'memory ownership', rasterize_points.cu:27-33): every byte of scratch, the backward's
-    48 bytes per instance included, comes from the caller -- here torch's allocator.  Device memory in use outside
+    36 (40 with the depth gradient) bytes per kept instance included, comes from the caller -- here torch's allocator.  Device memory in use outside
     torch's pool must not move across a forward + backward whose scratch is ~100 MB, torch's own accounting must
     show that scratch, and the binning buffer handed from forward to backward is bsr_binning_bytes(num_rendered)
     or the forward's larger guess."""
@@ -695,6 +720,26 @@ def test_library_owns_no_device_memory():
     assert outside1 - outside0 < (8 << 20), (outside0, outside1)
     assert torch.cuda.max_memory_allocated() - alloc0 >= 44 * R          # the scratch is on torch's books
     assert np.isfinite(out["mean3D"]).all()
+    # the same for the group filter (its per-workgroup counts are the caller's scratch) and a prefiltered visible_filter
+    # (its error word lands in the calling thread's pinned HOST buffer): no device memory outside torch's pool
+    from bloomscene_amd import views, GaussianRasterizer
+    from bloomscene_amd.synthetic import scene_b
+    sc = scene_b(200_000, 640, 360, 1, n_views=8, seed=5)
+    cams = [cm.to(dev) for cm in sc.cameras]
+    m3, s3, r4 = sc.means3D.to(dev), sc.scales.to(dev), sc.rotations.to(dev)
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    outside2 = total - free2 - torch.cuda.memory_reserved()
+    masks, counts = views.group_visibility(cams, m3, s3, r4, [[0, 1, 2, 3], [4, 5, 6, 7]], return_counts=True)
+    assert counts.tolist() == masks.sum(dim=1).tolist()
+    c_all = Hh.make_case(P=5000, W=200, H=120, deg=1, seed=3)          # scene A: every Gaussian in view
+    rast_p = GaussianRasterizer(Hh.hip_settings(c_all, dev, prefiltered=True))
+    radii_p = rast_p.visible_filter(c_all.means3D.to(dev), c_all.scales.to(dev), c_all.rotations.to(dev))
+    assert (radii_p >= 0).all()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    outside3 = total - free3 - torch.cuda.memory_reserved()
+    assert outside3 - outside2 < (8 << 20), (outside2, outside3)
 
 
 def test_backward_rejects_a_degree_the_coefficients_cannot_hold():
@@ -707,7 +752,7 @@ def test_backward_rejects_a_degree_the_coefficients_cannot_hold():
         _raw_backward(c, rs, t, R, radii, gb, bb, ib, c.gC, c.gD)
 
 
-def test_view_batched_forward_equals_per_view_calls():
+def test_view_batched_forward_equals_per_view_calls(exp_mode):
     """bsr_forward_views: V cameras in one call, stacked into one virtual image.  Every view must be bit-identical
     to its own bsr_forward call (colour, depth, radii), num_rendered must be the sum; P is not a multiple of 256
     (padding rows between the views), the views differ (empty one included), SH and precomputed colours."""
@@ -812,19 +857,24 @@ def test_declined_intermediate_gradients_change_nothing_else():
 
 
 def test_two_host_threads_on_their_own_streams():
-    """Two python threads, each on its own torch stream, run forward + backward of different scenes at the same time:
-    the per-thread read-back state (pinned buffer, event, size hint) and the stream-ordered backward scratch must
-    not interfere.  Every result must equal the single-threaded one bit for bit."""
+    """Two python threads, each on its own torch stream, run forward + backward of different scenes at the same time
+    AND IN DIFFERENT NUMERICS MODES (thread 0: BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD, thread 1: the default) -- the
+    modes are per call, the library holds no numerics state (SURVEY.md 8b "no globals ... safe from N threads") -- : the
+    per-thread read-back state (pinned buffer, event, size hint) must not interfere either.  Every result must equal the
+    single-threaded one of the same mode bit for bit."""
     import threading
+    from bloomscene_amd import numerics
     dev = _dev()
     cases = [Hh.make_case(**CASES["sh3"]), Hh.make_case(**CASES["free_camera_sh3"])]
-    ref = [Hh.run_hip(c) for c in cases]
+    modes = [dict(exact_exp=True, strict_gradients=True), dict(exact_exp=False, strict_gradients=False)]
+    ref = [Hh.run_hip(c, **m) for c, m in zip(cases, modes)]
+    assert not np.array_equal(ref[1].color, Hh.run_hip(cases[1], exact_exp=True, backward=False).color)   # the modes differ
     errors = []
 
     def worker(i):
         try:
             s = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s), numerics(**modes[i]):   # (the context is thread-local: entered in the worker)
                 for _ in range(12):
                     o = Hh.run_hip(cases[i])
                     s.synchronize()

@@ -49,7 +49,8 @@ def main():
     from bloomscene_amd import _capi
     if lib:
         _capi.use_library(lib)
-    _capi.set_option("exact_exp", exact)
+    from bloomscene_amd import numerics
+    numerics(exact_exp=exact).__enter__()   # per-call flags of every call this process makes
     names = argv or ["c1", "c2", "c3"]
     for name in names:
         c = Hh.make_case(**CASES[name])

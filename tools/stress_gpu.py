@@ -275,9 +275,8 @@ def main():
         # half the cases in the library's default mode (hardware exp outside the decision bands: images within ulps),
         # half with the pinned exp everywhere (images bit-equal to the oracle)
         exact = bool(rng.random() < 0.5)
-        _capi.set_option("exact_exp", exact)
-        out = Hh.run_hip(c, depth_gradient=dg)
-        out2 = Hh.run_hip(c, depth_gradient=dg)
+        out = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact)
+        out2 = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact)
         assert (out.radii == st.radii).all(), kw
         if exact:
             assert (out.color.view(np.uint32) == st.color.view(np.uint32)).all(), kw
