@@ -177,7 +177,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, bool strict, hipStream_t s);
+                       float4* slab, bool strict, int num_rendered, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- options (bsr_set_option)
@@ -830,7 +830,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 			StageTimer t("render_bwd", s);
 			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
 			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slab,
-			                  (flags & BSR_FLAG_EXACT_GRAD) != 0, s);
+			                  (flags & BSR_FLAG_EXACT_GRAD) != 0, R, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);
 	}

@@ -601,10 +601,445 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 #endif
 }
 
+// =====================================================================================================================
+// k_render_bwd_t: the default backward walk (round 4).  Same staging, lists, decisions and per-pixel chain as
+// k_render_bwd above, but the cross-lane reduction is TRANSPOSED through LDS:
+//
+//   phase 1 (per visit; lane = pixel of the wave's 8x8 quadrant): power, candidate votes, exp, alpha, the T chain, Srec,
+//            dL_dalpha -- and then only the TWO numbers every one of the entry's sums is linear in,
+//                gd = G dL_dalpha      (mean2D / conic / opacity sums = sum over pixels of gd x (1, dx, dy, dx dx, dx dy, dy dy))
+//                aT = alpha T          (colour sums = sum over pixels of aT x dL_dpixel[ch])
+//            written as one 8-byte LDS store to the visit's SLOT of the wave's private buffer.  No cross-lane instruction,
+//            no per-pair products.
+//   phase 2 (once per CHUNK of 8 visits; lane = (slot e = lane >> 3, pixel row r = lane & 7)): the lane reads its row's
+//            8 x (gd, aT) with four 16-byte LDS reads and accumulates, serially in registers, the row's moments of gd
+//            about the TILE centre (pixel-column coordinates are compile-time constants: sum g, sum g x, sum g x^2 by
+//            the symmetric pairing x_c = -x_(7-c); the row coordinate y is a per-lane constant) and the three colour
+//            sums against dL_dpixel of its own 8 pixels (per-lane constants for the whole kernel).  The 8 rows of a slot
+//            are then added by a 3-step butterfly over the 8 lanes (19 DPP adds for 9 values, amortised over 8 visits)
+//            and stored to the wave's partial-sum slots part[wave][k][entry].
+//   epilogue (per batch, as before): the four quadrants' partial sums are added in a fixed order; the moments about the
+//            tile centre are shifted ONCE to the Gaussian's centre (d = centre - pixel: sum g dx = Dx M00 - M10, sum g dx^2
+//            = Dx^2 M00 - 2 Dx M10 + M20, ...) and the row is assembled as before.
+//
+// Why: the predecessor spent 24 DPP / permlane instructions (the most expensive issue slots of the walk, 4.3 cycles each)
+// plus 8 per-pair products on EVERY visit, at 22 useful lanes of 64 (the reduction alone was 0.18-0.20 ms of
+// 0.62 at C3).  Here every visit pays one LDS store, and the reduction work runs at full lane utilisation:
+// ~75 instructions per 8 visits.  Sums are still formed in a fixed order (bit-reproducible); no atomics.
+// LDS: 64-entry batches (the partial-sum slots shrink with the batch) + 4 x 4.1 KB of transposition buffers = 30.6 KB
+// per workgroup, 5 workgroups per CU.
+#ifndef BSR_BWT_BATCH
+#define BSR_BWT_BATCH 64
+#endif
+#define BSR_BWT_CHUNK 8
+#ifndef BSR_BWT_ILP
+#define BSR_BWT_ILP 2   // list entries per straight-line block of phase 1 (2 or 4): A/B on one box, 5 waves per SIMD: 2 is
+                        // 1 % faster than 4 and needs no spill; at 4 waves per SIMD the block of 4 was worth 8 %
+#endif
+#ifndef BSR_BWT_PAD
+#define BSR_BWT_PAD 4   // the lists are sentinel-padded to whole TRIPS of four; a chunk is one or two trips
+#endif
+// A slot = 8 pixel rows x 64 B.  Phase-1 store: ds_write_b64 is served in groups of 16 consecutive lanes = 2 rows = 32
+// consecutive dwords: conflict-free.  Phase-2 read: ds_read_b128 is served in four groups of 16 lanes that mix slots
+// (e, e+1, e+2, e+3) x 4 rows each; rows 16 dwords apart cover all 64 banks once per FOUR rows, so slot e is rotated by
+// 4 e dwords (16 bytes): slot stride 528 B makes every group hit 64 distinct banks (MI355X_MICROARCH.md "LDS").
+#define BSR_BWT_SLOT 528
+#define BSR_BWT_ROW (BSR_BWT_BATCH + 1)
+template <int NV>
+struct BwtShared {
+	TileStageS<BSR_BWT_BATCH, 1, unsigned int, BSR_BWT_PAD> st;   // one list per quadrant, sentinel-padded to whole trips
+	float part[4][NV][BSR_BWT_ROW];   // per-wave partial sums of the current batch (plain stores); column BATCH = the sentinel's
+	uint32_t max_contrib[4];
+	alignas(16) char tbuf[4][BSR_BWT_CHUNK * BSR_BWT_SLOT];   // per wave: [slot][row][col] x (gd, aT)
+};
+
+// Sum over the 8 lanes sharing (lane >> 3) of nine (ten) values.  On return, in every lane with bit 2 clear x0..x3 (x4
+// with TEN) hold the totals of inputs 0..3 (0..4) and x8 that of input 8; in lanes with bit 2 set x0..x3 (x4) hold the
+// totals of inputs 4..7 (5..9).  Step over lane bit 2 = halving on bank-masked row rotations (rotate by 12 = "from
+// lane + 4" into banks 0 and 2, rotate by 4 = "from lane - 4" into banks 1 and 3: both stay inside the 8-lane group), steps
+// over bits 1 and 0 = plain quad permutes.  19 (20) instructions.  Inline asm gets no automatic wait states: a DPP read
+// needs 2 after a VALU write of the same VGPR -- the order keeps >= 2 instructions between, s_nop at the start.
+template <bool TEN>
+__device__ __forceinline__ void row8_sums(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6,
+                                          float& x7, float& x8, float& x9)
+{
+	if (TEN) {
+		asm volatile(
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %4, %4, %4 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %0, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %1, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %2, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %3, %8, %8 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %4, %9, %9 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9));
+	} else {
+		asm volatile(
+		    "s_nop 1\n"
+		    "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %8, %8, %8 row_ror:12 row_mask:0xf bank_mask:0x5\n"
+		    "v_add_f32_dpp %0, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %1, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %2, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %3, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9));
+	}
+}
+
+template <bool DEPTH>
+// Occupancy target handed to the register allocator.  The kernel's LDS allows 5 workgroups per CU = 5 waves per SIMD = 96
+// VGPRs; left alone the allocator takes 113 (4 waves).  A/B on one box: 5 waves -7.5 % (the walk waits on LDS round trips
+// 40-55 % of a wave's cycles: occupancy is what hides them); 6 waves (80 VGPRs, 48-entry batches for the LDS) spills 17-29
+// dwords into the inner loop: +25..+60 %.
+#ifndef BSR_BWT_WAVES
+#define BSR_BWT_WAVES 5
+#endif
+#define BSR_BWT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(BSR_BWT_WAVES, BSR_BWT_WAVES)))
+__global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(int n_tiles, int gx, int W, int H,
+                                                            const uint32_t* __restrict__ tile_start,
+                                                            const uint32_t* __restrict__ point_list,
+                                                            const float4* __restrict__ rec,
+                                                            const uint32_t* __restrict__ wg_base,
+                                                            const float* __restrict__ bg_color,
+                                                            const float* __restrict__ final_Ts,
+                                                            const uint32_t* __restrict__ n_contrib,
+                                                            const float* __restrict__ dL_dpixels,
+                                                            const float* __restrict__ out_depth,   // DEPTH only
+                                                            const float* __restrict__ dL_depths,   // DEPTH only
+                                                            float4* __restrict__ slab)        // [R][9 or 10 floats]
+{
+	constexpr int NV = DEPTH ? 10 : 9;
+	constexpr int B = BSR_BWT_BATCH;
+	__shared__ BwtShared<NV> sh;
+
+	const int tile = xcd_tile(blockIdx.x, n_tiles);
+	if (tile >= n_tiles) return;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int tx = tile % gx, ty = tile / gx;
+	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
+	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
+	const bool inside = px < W && py < H;
+	const float pixfx = (float)px, pixfy = (float)py;
+	const float tile_x0 = (float)(tx * BSR_TILE), tile_y0 = (float)(ty * BSR_TILE);
+	const size_t pix_id = (size_t)W * py + px;
+	const size_t plane = (size_t)H * W;
+
+	const uint32_t start = tile_start[tile];
+	const int n = (int)(tile_start[tile + 1] - start);
+
+	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
+	float T = T_final, Srec = 0.f;
+	const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
+	float dpx0 = 0.f, dpx1 = 0.f, dpx2 = 0.f;
+	if (inside) {
+		dpx0 = dL_dpixels[pix_id];
+		dpx1 = dL_dpixels[plane + pix_id];
+		dpx2 = dL_dpixels[2 * plane + pix_id];
+	}
+	const float bg_dot_dpixel = bg_color[0] * dpx0 + bg_color[1] * dpx1 + bg_color[2] * dpx2;
+	const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;
+	float gz = 0.f, g1 = 0.f;   // depth extension: d_i = gz * z_i + g1 plays the role of a fourth colour channel
+	if (DEPTH && inside) {
+		const float depth_px = out_depth[pix_id];
+		if (depth_px != 0.0f) {   // the forward's acc > 0.5 decision
+			gz = dL_depths[pix_id] / (1e-6f + (1.0f - T_final));
+			g1 = -gz * depth_px;
+		}
+	}
+	const float ddelx_dx = (float)(0.5 * W);
+	const float ddely_dy = (float)(0.5 * H);
+
+	// ---- phase-2 identity of this lane: slot e2 = lane >> 3, pixel row r2 = lane & 7 of the wave's quadrant.  Its
+	// constants: dL_dpixel (and gz) of the row's 8 pixels, handed over through the wave's (still idle) transposition
+	// buffer -- lane p holds pixel p's; the row's y and the quadrant's first column as floats.
+	char* const tb_w = sh.tbuf[wave];
+	float cw0[8], cw1[8], cw2[8], cwz[DEPTH ? 8 : 1];
+	{
+		*reinterpret_cast<float4*>(tb_w + lane * 16) = make_float4(dpx0, dpx1, dpx2, gz);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		const float4* rowp = reinterpret_cast<const float4*>(tb_w + (lane & 7) * 128);
+#pragma unroll
+		for (int c = 0; c < 8; c++) {
+			const float4 v = rowp[c];
+			cw0[c] = v.x;
+			cw1[c] = v.y;
+			cw2[c] = v.z;
+			if (DEPTH) cwz[c] = v.w;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();   // (the buffer is reused by the walk)
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	const float py_row = (float)(ty * BSR_TILE + ((wave >> 1) << 3) + (lane & 7));   // phase 2: y of row r2
+	const float px_q0 = (float)(tx * BSR_TILE + ((wave & 1) << 3));                    //          x of the quadrant's column 0
+	char* const tb_store = tb_w + (lane >> 3) * 64 + (lane & 7) * 8;                  // phase 1: this pixel's place in slot 0
+	const char* const tb_load = tb_w + (lane >> 3) * BSR_BWT_SLOT + (lane & 7) * 64;  // phase 2: row r2 of slot e2
+	const bool lane_stores = (lane & 3) == 0;                            // lanes 0 and 4 of every 8-lane group
+	// part[wave][k0 + m][j]: k0 = 0 for the lanes holding the totals of values 0..3 (0..4), 4 (5) for the others
+	float* const part_k0 = &sh.part[wave][(lane & 4) ? (DEPTH ? 5 : 4) : 0][0];
+	const char* const rec0 = reinterpret_cast<const char*>(&sh.st.q0[0]);
+	stage_init(sh.st, tid);   // the sentinel record (read behind the staging's barriers)
+
+	// Entries at list positions >= max(last_contributor) are skipped by every pixel of the tile
+	// (reference :498-500): start the walk at the deepest entry any pixel blended.
+	uint32_t m = last_contributor;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+	if (lane == 0) sh.max_contrib[wave] = m;
+	if (tid < BSR_BWT_ROW) {
+#pragma unroll
+		for (int w = 0; w < 4; w++)
+#pragma unroll
+			for (int k = 0; k < NV; k++) sh.part[w][k][tid] = 0.f;
+	}
+	__syncthreads();
+	const int n_walk = (int)max(max(sh.max_contrib[0], sh.max_contrib[1]), max(sh.max_contrib[2], sh.max_contrib[3]));
+
+	for (int base = 0; base < n_walk; base += B) {
+		const int cnt = min(B, n_walk - base);
+		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
+		const bool valid = tid < cnt;
+		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+		uint32_t my_row = 0;
+		if (valid) {
+			const uint32_t my_slot = start + (uint32_t)(top - tid);
+			const uint32_t id = point_list[my_slot];
+			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
+			r0 = r[0];
+			r1 = r[1];
+			r2 = r[2];
+			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
+			r2.w = r1.y + 2.2e-3f;   // staged q2.w: just above the decision band, -ln(255 o) + 1.2e-3
+		}
+		// (the trailing barrier of the previous iteration fenced the staging buffers)
+		const int n_mine = stage_and_compact_s(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
+		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
+		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
+		const int joff_min = (top - (int)last_contributor) * 16;
+
+		// ---- phase 1: FOUR list entries per trip as one straight-line block (the forward walk's shape): the four
+		// entries' LDS reads and their power / exp / alpha chains are independent and the scheduler interleaves them; only
+		// T and Srec are serial.  No vote per entry, no early return: a lane that must not blend carries G = 0, hence
+		// alpha = 0, which leaves its state unchanged (T / 1 = T, Srec + 0 S = Srec) and stores gd = aT = 0; the rows are
+		// sentinel-padded to whole chunks and a sentinel is never a candidate.  Decisions exactly as k_render_bwd: the
+		// forward decided `alpha >= 1/255` with the pinned exp; only a trip holding a candidate lane inside the decision
+		// band (q2.w = its upper edge) evaluates the pinned exp and tests alpha, everywhere else the value comes from
+		// v_exp_f32.  (Testing alpha on a trip's other entries changes nothing: outside the band every candidate has
+		// alpha >= (1 + 1e-3) / 255.)
+		struct Ent { float4 q0, q1, q2; float power; bool cand; };
+		auto load = [&](const unsigned int joff) {
+			Ent e;
+			const char* rec = rec0 + joff;
+			e.q0 = srec_q0<B>(rec);      // x, y, -a/2, -b
+			e.q1 = srec_q1<B>(rec);      // -c/2, power cut, opacity, depth
+			e.q2 = srec_q2<B>(rec);      // r, g, b, upper edge of the decision band
+			if (!DEPTH) asm volatile("" : : "v"(e.q1.w));   // keep the read one ds_read_b128 (4 LDS cycles; narrowed to b96 it costs 8)
+			const float dx = e.q0.x - pixfx;
+			const float dy = e.q0.y - pixfy;
+			e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic (common.h): the forward's bits
+			e.cand = ((int)joff > joff_min) && !(e.power > 0.0f) && !(e.power < e.q1.y);
+			return e;
+		};
+		auto chain = [&](const Ent& e, float G, float alpha, const int slot) {
+			float gd, aT;
+			{
+#pragma clang fp contract(fast)
+				const float om = 1.f - alpha;
+				const float inv = __builtin_amdgcn_rcpf(om);   // 1 ulp
+				const float qT = T * inv;
+				T = __builtin_fmaf(__builtin_fmaf(-om, qT, T), inv, qT);   // T / (1 - alpha), residual-corrected (see k_render_bwd)
+				float u = e.q2.x * dpx0 + e.q2.y * dpx1 + e.q2.z * dpx2;
+				if (DEPTH) u += __builtin_fmaf(gz, e.q1.w, g1);
+				const float S = u - Srec;
+				Srec = Srec + alpha * S;
+				const float dL_dalpha = T * S + neg_Tfinal_bg * inv;
+				gd = G * dL_dalpha;
+				aT = alpha * T;
+			}
+			*reinterpret_cast<float2*>(tb_store + slot * BSR_BWT_SLOT) = make_float2(gd, aT);
+		};
+		// NE entries as one straight-line block
+		auto block = [&](const unsigned int (&l)[BSR_BWT_ILP], const int slot0) {
+			constexpr int NE = BSR_BWT_ILP;
+			Ent e[NE];
+			float g[NE], a[NE];
+			uint64_t vote = 0ull;
+#pragma unroll
+			for (int k = 0; k < NE; k++) {
+				e[k] = load(l[k]);
+				g[k] = __builtin_amdgcn_exp2f(e[k].power * 1.44269504088896341f);
+				// a candidate below the band's upper edge (or a NaN edge / power: opacity <= 0 or NaN) -> decide with the pinned exp
+				vote |= wave_ballot(e[k].cand && !(e[k].power >= e[k].q2.w));
+			}
+			const bool decide = vote != 0ull;
+			if (decide) {   // rare (a few % of the trips): each lane picks its exp with the FORWARD's expression
+#pragma unroll
+				for (int k = 0; k < NE; k++)
+					g[k] = !(fabsf(e[k].power - (e[k].q1.y + 1.0e-3f)) >= 1.1e-3f) ? bsr_expf_walk(e[k].power) : g[k];
+			}
+#pragma unroll
+			for (int k = 0; k < NE; k++) {
+				g[k] = e[k].cand ? g[k] : 0.f;
+				a[k] = fminf(0.99f, e[k].q1.z * g[k]);
+			}
+			if (decide) {
+#pragma unroll
+				for (int k = 0; k < NE; k++) {
+					const bool keep = !(a[k] < 1.0f / 255.0f);
+					g[k] = keep ? g[k] : 0.f;
+					a[k] = keep ? a[k] : 0.f;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < NE; k++) chain(e[k], g[k], a[k], slot0 + k);
+		};
+		auto trip = [&](const uint4 l, const int slot0) {
+#if BSR_BWT_ILP == 4
+			const unsigned int q[4] = {l.x, l.y, l.z, l.w};
+			block(q, slot0);
+#else
+			const unsigned int q0[2] = {l.x, l.y}, q1[2] = {l.z, l.w};
+			block(q0, slot0);
+			block(q1, slot0 + 2);
+#endif
+		};
+
+		// ---- phase 2: the chunk's slots, transposed: lane (e2, r2) sums row r2 of slot e2 about the ENTRY's centre
+		auto reduce_chunk = [&](const int i0, const int n_valid) {
+			const unsigned int joff = sh.st.list[wave][i0 + (lane >> 3)];      // the slot's entry (possibly the sentinel; beyond n_valid: not stored)
+			const float2 xy = *reinterpret_cast<const float2*>(rec0 + joff);
+			const float4 A = *reinterpret_cast<const float4*>(tb_load);        // g0 a0 g1 a1
+			const float4 Bv = *reinterpret_cast<const float4*>(tb_load + 16);  // g2 a2 g3 a3
+			const float4 C = *reinterpret_cast<const float4*>(tb_load + 32);   // g4 a4 g5 a5
+			const float4 D = *reinterpret_cast<const float4*>(tb_load + 48);   // g6 a6 g7 a7
+			float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9 = 0.f;
+			{
+#pragma clang fp contract(fast)
+				// d = centre - pixel, as the reference forms it (:501): the row's dy is one number, dx_c = dx_0 - c
+				const float dy = xy.y - py_row;
+				const float x0 = xy.x - px_q0, x1 = x0 - 1.0f, x2 = x0 - 2.0f, x3 = x0 - 3.0f, x4 = x0 - 4.0f, x5 = x0 - 5.0f,
+				            x6 = x0 - 6.0f, x7 = x0 - 7.0f;
+				const float t0 = A.x * x0, t1 = A.z * x1, t2 = Bv.x * x2, t3 = Bv.z * x3, t4 = C.x * x4, t5 = C.z * x5,
+				            t6 = D.x * x6, t7 = D.z * x7;                                       // g_c dx_c
+				const float s0 = ((A.x + A.z) + (Bv.x + Bv.z)) + ((C.x + C.z) + (D.x + D.z));   // sum g
+				const float s1 = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));             // sum g dx
+				const float s2 = ((t0 * x0 + t1 * x1) + (t2 * x2 + t3 * x3)) + ((t4 * x4 + t5 * x5) + (t6 * x6 + t7 * x7));   // sum g dx dx
+				v0 = s1;            // sum gd dx
+				v1 = dy * s0;       // sum gd dy
+				v2 = s2;            // sum gd dx dx
+				v3 = dy * s1;       // sum gd dx dy
+				v4 = dy * v1;       // sum gd dy dy
+				v5 = s0;            // sum gd
+				v6 = A.y * cw0[0] + A.w * cw0[1] + Bv.y * cw0[2] + Bv.w * cw0[3] + C.y * cw0[4] + C.w * cw0[5] + D.y * cw0[6] + D.w * cw0[7];
+				v7 = A.y * cw1[0] + A.w * cw1[1] + Bv.y * cw1[2] + Bv.w * cw1[3] + C.y * cw1[4] + C.w * cw1[5] + D.y * cw1[6] + D.w * cw1[7];
+				v8 = A.y * cw2[0] + A.w * cw2[1] + Bv.y * cw2[2] + Bv.w * cw2[3] + C.y * cw2[4] + C.w * cw2[5] + D.y * cw2[6] + D.w * cw2[7];
+				if (DEPTH)
+					v9 = A.y * cwz[0] + A.w * cwz[1] + Bv.y * cwz[2] + Bv.w * cwz[3] + C.y * cwz[4] + C.w * cwz[5] + D.y * cwz[6] + D.w * cwz[7];
+			}
+			row8_sums<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+			if (lane_stores && (lane >> 3) < n_valid) {   // (a sentinel slot's zeros land in the rows' pad column BATCH)
+				float* const p = reinterpret_cast<float*>(reinterpret_cast<char*>(part_k0) + (joff >> 2));   // part[wave][k0][j]
+				p[0] = v0;
+				p[BSR_BWT_ROW] = v1;
+				p[2 * BSR_BWT_ROW] = v2;
+				p[3 * BSR_BWT_ROW] = v3;
+				if (DEPTH) p[4 * BSR_BWT_ROW] = v4;
+				else if (!(lane & 4)) p[8 * BSR_BWT_ROW] = v8;
+			}
+		};
+
+		const int n_pad = (n_u + (BSR_BWT_PAD - 1)) & ~(BSR_BWT_PAD - 1);   // (the row is sentinel-padded to whole trips)
+		for (int i = 0; i < n_pad; i += BSR_BWT_CHUNK) {
+			const uint4 la = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i]);
+			const uint4 lb = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i + 4]);   // (past the padding: inside the struct, not used)
+			trip(la, 0);
+			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4);
+			// the wave's own stores, then its own loads: the LDS serves a wave's operations in order
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			reduce_chunk(i, min(BSR_BWT_CHUNK, n_pad - i));
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		__syncthreads();
+		if (valid) {
+			float a9[10];
+			a9[9] = 0.f;
+#pragma unroll
+			for (int k = 0; k < NV; k++) {   // fixed order over the 4 quadrants -> deterministic
+				a9[k] = ((sh.part[0][k][tid] + sh.part[1][k][tid]) + sh.part[2][k][tid]) + sh.part[3][k][tid];
+				sh.part[0][k][tid] = 0.f;
+				sh.part[1][k][tid] = 0.f;
+				sh.part[2][k][tid] = 0.f;
+				sh.part[3][k][tid] = 0.f;
+			}
+			// the wave sums -> the reference's sums (see k_render_bwd); this thread staged entry `tid` itself
+			const float4 e0 = sh.st.q0[tid], e1 = sh.st.q1[tid];   // (x, y, -a/2, -b), (-c/2, cut, o, depth)
+			const float ca = -2.0f * e0.z, cb = -e0.w, cc = -2.0f * e1.x;
+			const float no = -e1.z;
+			const float h = 0.5f * no;
+			float* const row = reinterpret_cast<float*>(slab) + (size_t)my_row * slab_row_floats(DEPTH);
+			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{no * ddelx_dx * (ca * a9[0] + cb * a9[1]),
+			                                                   no * ddely_dy * (cc * a9[1] + cb * a9[0]), h * a9[2], h * a9[3]};
+			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{h * a9[4], a9[5], a9[6], a9[7]};
+			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
+			else row[8] = a9[8];
+		}
+		__syncthreads();
+	}
+
+	// entries no pixel of the tile reached: zero rows, but they still need their map entry
+	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
+		const uint32_t slot = start + (uint32_t)pos;
+		const uint32_t id = point_list[slot];
+		float* const row = reinterpret_cast<float*>(slab) +
+		                   (size_t)instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3],
+		                                          tx, ty) * slab_row_floats(DEPTH);
+		const bsr_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+		*reinterpret_cast<bsr_f32x4_a4*>(row) = z;
+		*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = z;
+		if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{0.f, 0.f};
+		else row[8] = 0.f;
+	}
+}
+
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, bool strict, hipStream_t s)
+                       float4* slab, bool strict, int num_rendered, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
@@ -614,10 +1049,34 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	hipLaunchKernelGGL((k_render_bwd<D_, S_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, slab)
-	if (depth && strict) BSR_LAUNCH_BWD(true, true);
-	else if (depth) BSR_LAUNCH_BWD(true, false);
-	else if (strict) BSR_LAUNCH_BWD(false, true);
-	else BSR_LAUNCH_BWD(false, false);
+#define BSR_LAUNCH_BWT(D_)                                                                                              \
+	hipLaunchKernelGGL((k_render_bwd_t<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
+	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
+	                   depth ? dL_depths : nullptr, slab)
+	// Default: the transposed-reduction walk.  BSR_FLAG_EXACT_GRAD (and the attribution / diagnostic builds, which are
+	// variants of the per-visit network walk): k_render_bwd.  Frames whose tiles hold very long lists also take
+	// k_render_bwd: the transposed walk moves work from the vector ALU to the LDS (27 instead of 20 LDS cycles per visit)
+	// and stages 64 entries per batch instead of 128, which costs more than it saves once a tile's life is dominated by
+	// staging (5 M Gaussians: 2700 entries per tile, 1.1 visits per staged entry) or by visits alone (scales x 3).
+	// A/B on one box, k_render_bwd -> k_render_bwd_t, by reference instances per tile: 160: -5 %, 540 (C3): -15 %, 1000
+	// -1300: -4..-6 %, 1600: +1 %, 2200 (scales x 3): +4.5 %, 2700 (C5): +5 %.  Both walks take every decision alike;
+	// their sums differ in the order of the additions only (gradients carry a tolerance either way).
+#if defined(BSR_BWD_NETWORK_WALK) || defined(BSR_WALK_STATS)
+	const bool network = true;
+#else
+	const bool network = strict || (long long)num_rendered > 1500ll * n_tiles;
+#endif
+	if (network) {
+		if (depth && strict) BSR_LAUNCH_BWD(true, true);
+		else if (depth) BSR_LAUNCH_BWD(true, false);
+		else if (strict) BSR_LAUNCH_BWD(false, true);
+		else BSR_LAUNCH_BWD(false, false);
+	} else if (depth) {
+		BSR_LAUNCH_BWT(true);
+	} else {
+		BSR_LAUNCH_BWT(false);
+	}
+#undef BSR_LAUNCH_BWT
 #undef BSR_LAUNCH_BWD
 }
 

@@ -123,10 +123,11 @@ __device__ __forceinline__ int stage_and_compact(TileStageT<BATCH>& st, int tid,
 // conservative box test proves inert for its strip, so results stay bit-identical.
 // Lists are padded with the offset of a SENTINEL record (slot BATCH: no pixel can be a candidate of it) so that all
 // groups run the same number of visits.
-template <int BATCH, int NS, typename LT = unsigned int>   // LT: list entry type (uint16_t where LDS is tight; BATCH << 4 must fit)
+// PAD: the lists are sentinel-padded to a multiple of PAD entries (4: the forward's trips; 8: the backward's chunks)
+template <int BATCH, int NS, typename LT = unsigned int, int PAD = 4>   // LT: list entry type (uint16_t where LDS is tight; BATCH << 4 must fit)
 struct TileStageS {
 	static constexpr int NL = 4 * NS;        // lists per tile
-	static constexpr int ROW = BATCH + 4;    // list row, sentinel-padded to the next multiple of 4
+	static constexpr int ROW = BATCH + PAD;  // list row, sentinel-padded to the next multiple of PAD
 	float4 q0[BATCH + 1];                    // x, y, -conic a / 2, -conic b    ([BATCH] = sentinel)
 	float4 q1[BATCH + 1];                    // -conic c / 2, power cut, opacity, depth
 	float4 q2[BATCH + 1];                    // r, g, b, -
@@ -135,8 +136,8 @@ struct TileStageS {
 };
 #define BSR_SENTINEL_X (-1.0e15f)            // (finished forward lanes sit at +1e15: the sentinel must be far from that too)
 
-template <int BATCH, int NS, typename LT>
-__device__ __forceinline__ void stage_init(TileStageS<BATCH, NS, LT>& st, int tid)
+template <int BATCH, int NS, typename LT, int PAD>
+__device__ __forceinline__ void stage_init(TileStageS<BATCH, NS, LT, PAD>& st, int tid)
 {
 	if (tid == 0) {
 		st.q0[BATCH] = make_float4(BSR_SENTINEL_X, 0.f, -0.5f, 0.f);   // power = -0.5e30: below any cut, never > 0
@@ -151,8 +152,8 @@ __device__ __forceinline__ int my_list_index(int wave, int lane) { return wave *
 
 // As stage_and_compact, for the split lists.  Returns the number of visits the calling wave needs (the longest of
 // its NS lists); st.list[l][0 .. that, rounded up to 4) is valid for each of its lists.
-template <int BATCH, int NS, typename LT>
-__device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT>& st, int tid, bool valid, const float4 r0,
+template <int BATCH, int NS, typename LT, int PAD>
+__device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT, PAD>& st, int tid, bool valid, const float4 r0,
                                                    const float4 r1, const float4 r2, float tile_x0, float tile_y0)
 {
 	constexpr int NL = 4 * NS;
@@ -204,7 +205,7 @@ __device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT>& st
 		tot[sidx] = (int)(st.cnt[0][l] + st.cnt[1][l] + st.cnt[2][l] + st.cnt[3][l]);
 		longest = max(longest, tot[sidx]);
 	}
-	const int padded = (longest + 3) & ~3;
+	const int padded = (longest + (PAD - 1)) & ~(PAD - 1);
 #pragma unroll
 	for (int sidx = 0; sidx < NS; sidx++)
 		for (int i = tot[sidx] + lane; i < padded; i += 64) st.list[wave * NS + sidx][i] = (LT)(BATCH << 4);

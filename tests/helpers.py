@@ -246,12 +246,21 @@ def assert_strict_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS):
     ORDER of the nine sums differs, so SURVEY.md 8(d)'s share of elements beyond 1e-4 relative must not exceed what
     summation order alone costs the reference -- the oracle's fp32 terms added in binary32 in one fixed order against
     its own binary64 sums (`floor`) -- or 8(d)'s own 1e-5 allowance where that floor is smaller.  Both shares are COUNTS
-    of elements that happen to sit near the 1e-4 line (a dozen of 12 000 on the small cases), so the comparison allows the
-    counting noise of the floor: 3 sigma of a Poisson count + 4 elements.  At C3 / C5 (hundreds of counted elements)
-    that slack is 4 % / 2 % of the floor, and the measured share is 0.5 - 0.65 x the floor.  Norm-wise < 1e-5 as
-    everywhere."""
+    of values that happen to sit near the 1e-4 line (a handful of Gaussians on the small cases), so the comparison is made
+    on the number of affected Gaussians and allows the counting noise of the floor: 3 sigma of a Poisson count + 4.  At
+    C3 / C5 (hundreds of counted rows) that slack is a few % of the floor, and the measured share is 0.5 - 0.65 x the
+    floor.  Norm-wise < 1e-5 as everywhere."""
     og = oracle_grads(c, g)
     og32 = oracle_grads(c, O.backward(st, c.gC, c.gD, f32_sums=True))
+
+    def rows_off(a, b):
+        """number of GAUSSIANS (rows) with an element beyond 1e-4 relative, and the row count"""
+        a = np.asarray(a, dtype=np.float64).reshape(b.shape[0], -1)
+        bb = np.asarray(b, dtype=np.float64).reshape(b.shape[0], -1)
+        scale = max(np.abs(bb).max(), 1e-30)
+        e = np.abs(a - bb) / np.maximum(np.abs(bb), 1e-6 * scale)
+        return int((e > 1e-4).any(axis=1).sum()), int(bb.shape[0])
+
     rows = {}
     for k in keys:
         ref, got = getattr(og, k), getattr(grads, k)
@@ -267,9 +276,14 @@ def assert_strict_gradient_parity(c, st, g, grads, label="", keys=GRAD_KEYS):
         print(f"[8d-strict] {label:24s} dL_d{k:14s} frac>1e-4 {frac:.2e} (summation-order floor {floor:.2e}) "
               f"max_rel {m:.2e} norm-wise {scale:.1e}")
         assert scale < 1e-5, (label, k, scale)
-        bar = max(floor, 1e-5)
-        noise = (3.0 * math.sqrt(max(bar * ref.size, 1.0)) + 4.0) / ref.size
-        assert frac <= bar + noise, (label, k, frac, floor, noise)
+        if ref.size == 0:
+            continue
+        # the elements of one Gaussian's row move together (one colour sum off by an ulp too many moves all 48 SH
+        # gradients of that Gaussian), so the counting noise is that of ROWS: compare per-Gaussian counts
+        n_got, n_rows = rows_off(got, ref)
+        n_floor, _ = rows_off(getattr(og32, k), ref)
+        bar = max(n_floor, 1e-5 * n_rows)
+        assert n_got <= bar + 3.0 * math.sqrt(max(bar, 1.0)) + 4.0, (label, k, n_got, n_floor, n_rows)
     return rows
 
 
