@@ -505,33 +505,57 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                                    "value": round(n_views * P / t / 1e6, 1),
                                    "value_including_distribution": round(n_views * P / (t + dist_s) / 1e6, 1)}
     out["scatter_visible"] = sc_out
-    # ---- stated model for the first SCALE record to be checked against: t(N) = filter + pack + max_r bytes_r / link rate
-    # + ceil(views / N) * ms per view (this run's, rendering from a rank's subset); broadcast path: 236 B P / link rate
+    # ---- stated model for the first SCALE record to be checked against (views.modelled_scatter_sweep): the source filters,
+    # then packs and sends rank by rank (remote ranks first, own block last); every rank renders from its arrival on.
+    # Evaluated for even view blocks and for the best UNEVEN split (the source, busy distributing, takes fewer views);
+    # broadcast path: 236 B P / link rate + ceil(views / N) views per rank.
     if D.rank == 0:
         LINK_GBS = 153.0   # xGMI, one link (MI355X guide); point-to-point mesh: the N - 1 sends run on their own links
-        rows = views.visible_rows_per_rank(bufs, pack, worlds=(1, 2, 4, 8), assignment="contiguous")
         row_bytes = (3 + 3 + 4 + 1 + 3 * M) * 4
         per_view_ms = sc_out["views_per_call_16"]["ms_per_view_per_rank"]
         per_view_bcast_ms = out["views_per_call_16"]["ms_per_view_per_rank"]
-        prep_ms = info["filter_ms"] + info["pack_ms"]
-        pred = {"model": "t(N) = filter_ms + pack_ms + max_r(rows_r * row_bytes) / 153 GB/s + ceil(views / N) * ms_per_view "
-                         "(N = 1: no transfer); broadcast path: t(N) = P * row_bytes / 153 GB/s + ceil(views / N) * "
-                         "ms_per_view_broadcast_path; ms per view as measured in THIS run", "row_bytes": row_bytes,
-                "link_GBs": LINK_GBS, "ms_per_view": per_view_ms, "ms_per_view_broadcast_path": per_view_bcast_ms}
-        t1 = None
-        for w, rr in rows.items():
-            comm = 0.0 if w == 1 else max(rr[1:] or [0]) * row_bytes / (LINK_GBS * 1e6)
-            tw = prep_ms + comm + math.ceil(n_views / w) * per_view_ms
+        total_rows = max(1, sum(info["counts"]))
+        pack_per_row = info["pack_ms"] / total_rows
+        pred = {"model": "views.modelled_scatter_sweep: t(N) = max over ranks of [filter_ms + packs up to and including the "
+                         "rank's own (source: all packs) + rows_r * row_bytes / 153 GB/s + views_r * ms_per_view]; N = 1: "
+                         "views * ms_per_view; broadcast path: P * row_bytes / 153 GB/s + ceil(views / N) * "
+                         "ms_per_view_broadcast_path; stage times as measured in THIS run on one GPU",
+                "row_bytes": row_bytes, "link_GBs": LINK_GBS, "ms_per_view": per_view_ms,
+                "ms_per_view_broadcast_path": per_view_bcast_ms, "filter_ms": round(info["filter_ms"], 4),
+                "pack_ms_per_million_rows": round(pack_per_row * 1e6, 4)}
+        t1 = n_views * per_view_ms
+        for w in (1, 2, 4, 8):
+            best = None
+            for fewer in range(0, max(1, math.ceil(n_views / w))):
+                sizes = views.staggered_block_sizes(n_views, w, 0, fewer)
+                rr = views.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", src_fewer=fewer)[w]
+                m = views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
+                                                 per_view_ms, LINK_GBS, pipelined=True)
+                cand = (m["sweep_ms"], fewer, sizes, rr, m)
+                if fewer == 0:
+                    even = cand
+                    batched = views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row,
+                                                           row_bytes, per_view_ms, LINK_GBS, pipelined=False)
+                if best is None or cand[0] < best[0]:
+                    best = cand
+                if w == 1:
+                    break
             tb = (0.0 if w == 1 else P * row_bytes / (LINK_GBS * 1e6)) + math.ceil(n_views / w) * per_view_bcast_ms
-            t1 = tw if t1 is None else t1
             t_render = math.ceil(n_views / w) * per_view_ms
-            pred[str(w)] = {"rows_max": max(rr), "transfer_ms": round(comm, 3), "sweep_ms_scatter": round(tw, 3),
-                            "speedup_scatter": round(t1 / tw, 2), "sweep_ms_broadcast": round(tb, 3),
-                            "Msplats_per_s_scatter": round(n_views * P / (tw * 1e-3) / 1e6, 1),
-                            # the sweep alone, Gaussians already distributed (a second camera path over the same scene):
-                            # ceil(views / N) views per rank, no exchange at all
-                            "sweep_ms_resident": round(t_render, 3),
-                            "speedup_resident": round(n_views * per_view_ms / t_render, 2)}
+            pred[str(w)] = {
+                "rows_max": max(even[3]),
+                "sweep_ms_scatter": round(even[0], 3), "speedup_scatter": round(t1 / even[0], 2),
+                "critical_rank": even[4]["critical_rank"],
+                "sweep_ms_scatter_unpipelined": round(batched["sweep_ms"], 3),
+                # the source takes `src_fewer` views less than an even share (views.staggered_block_sizes)
+                "staggered": {"src_fewer": best[1], "views_per_rank": best[2], "sweep_ms_scatter": round(best[0], 3),
+                              "speedup_scatter": round(t1 / best[0], 2), "critical_rank": best[4]["critical_rank"]},
+                "sweep_ms_broadcast": round(tb, 3),
+                "Msplats_per_s_scatter": round(n_views * P / (best[0] * 1e-3) / 1e6, 1),
+                # the sweep alone, Gaussians already distributed (a second camera path over the same scene):
+                # ceil(views / N) views per rank, no exchange at all
+                "sweep_ms_resident": round(t_render, 3),
+                "speedup_resident": round(n_views * per_view_ms / t_render, 2)}
         out["predicted"] = pred
     del bufs, local
     torch.cuda.empty_cache()

@@ -937,7 +937,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 
 		// ---- phase 2: the chunk's slots, transposed: lane (e2, r2) sums row r2 of slot e2 about the ENTRY's centre
 		auto reduce_chunk = [&](const int i0, const int n_valid) {
-			const unsigned int joff = sh.st.list[wave][i0 + (lane >> 3)];      // the slot's entry (possibly the sentinel; beyond n_valid: not stored)
+			// the slot's entry (possibly the sentinel).  Beyond n_valid the list holds whatever earlier batches left there (or
+			// nothing yet): clamped, so that the reads below stay inside the staged records; those lanes store nothing
+			const unsigned int joff = min(sh.st.list[wave][i0 + (lane >> 3)], (unsigned int)(B << 4));
 			const float2 xy = *reinterpret_cast<const float2*>(rec0 + joff);
 			const float4 A = *reinterpret_cast<const float4*>(tb_load);        // g0 a0 g1 a1
 			const float4 Bv = *reinterpret_cast<const float4*>(tb_load + 16);  // g2 a2 g3 a3

@@ -78,17 +78,35 @@ def _camera_stack(cams, idx, dev):
             torch.stack([c.camera_center.to(dev) for c in sel]).contiguous(), c0)
 
 
-def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin"):
+def staggered_block_sizes(n_views: int, world: int, src: int = 0, src_fewer: int = 0):
+    """Sizes of the ranks' contiguous view blocks when the distributing rank `src` takes `src_fewer` views LESS than an
+    even share and the others share them out (the first ones served take one more): `src` spends the start of the sweep
+    filtering, packing and sending, its peers wait for their rows for a fraction of that -- an even split leaves `src`
+    (or its last-served peer) on the critical path (DESIGN.md "Multi-GPU").  src_fewer = 0: the even split of
+    assign_views(..., "contiguous")."""
+    per = -(-n_views // world)
+    sizes = [max(0, min(per, n_views - r * per)) for r in range(world)]
+    move = max(0, min(int(src_fewer), sizes[src]))
+    if world > 1 and move:
+        sizes[src] -= move
+        others = [r for r in range(world) if r != src]
+        for i in range(move):
+            sizes[others[i % len(others)]] += 1
+    return sizes
+
+
+def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin", src: int = 0, src_fewer: int = 0):
     """View indices of `rank`.  "round_robin": {i : i mod world == rank} (balances a yaw-dependent load; every rank sees
     the whole sweep, so it needs nearly every Gaussian any view sees).  "contiguous": the rank's block of ceil(n / world)
     neighbouring views -- neighbouring views of a rotate360 sweep overlap (utils/trajectory.py:110-121: 360 / n degrees
     apart against a ~57 degree field of view), so the Gaussians ONE rank needs are a small part of the scene; what
-    `scatter_visible_gaussians` sends."""
+    `scatter_visible_gaussians` sends.  With ``src_fewer`` > 0 the blocks are uneven (staggered_block_sizes)."""
     if mode == "round_robin":
         return list(range(rank, n_views, world))
     if mode == "contiguous":
-        per = -(-n_views // world)
-        return list(range(rank * per, min(n_views, (rank + 1) * per)))
+        sizes = staggered_block_sizes(n_views, world, src, src_fewer)
+        start = sum(sizes[:rank])
+        return list(range(start, start + sizes[rank]))
     raise ValueError(f"unknown view assignment '{mode}'")
 
 
@@ -127,7 +145,7 @@ def broadcast_gaussians(bufs: dict, src: int = 0, force: bool = False) -> float:
 
 
 def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "contiguous", masks=None,
-                              scaling_modifier: float = 1.0, device=None):
+                              scaling_modifier: float = 1.0, device=None, pipelined: bool = True, src_fewer: int = 0):
     """Hand every rank ONLY the Gaussians its views can see, instead of broadcasting all of them.
 
     xGMI is a point-to-point mesh: rank `src` reaches each of its peers over a link of its own (7 x ~153 GB/s on an
@@ -142,6 +160,13 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     ascending compaction keeps the (depth, id) tie order, so every frame rendered from the subset is bit-identical to
     the frame rendered from all Gaussians (tests/test_round3_gpu.py, tests/test_multigpu_gloo.py).
 
+    ``pipelined`` (default): `src` packs ONE rank's rows at a time and posts that rank's send as soon as they are packed
+    -- remote ranks first, in rank order, its own block last -- so that the first peer's rows are on the wire while the
+    next peer's are still being gathered (the pack kernels run on the compute stream, RCCL's sends on its own); every
+    peer starts rendering as soon as ITS message has arrived.  False: one pack of all rows, then all sends together
+    (round 3's form).  ``src_fewer``: uneven view blocks (staggered_block_sizes): `src`, which is busy distributing,
+    takes that many views fewer.
+
     ``bufs``: on `src` the dict of full per-Gaussian tensors ([P, ...] fp32; must hold means3D, scales, rotations for
     the filter); ignored elsewhere (pass None).  ``cams``: the whole camera path, on every rank.  ``masks``
     (optional, `src` only): bool [world, P] to use instead of running the filter (CPU plumbing tests).  ``device``:
@@ -152,8 +177,8 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
-    my_views = assign_views(len(cams), rank, world, assignment)
-    info = {"filter_ms": 0.0, "pack_ms": 0.0, "comm_ms": 0.0}
+    my_views = assign_views(len(cams), rank, world, assignment, src, src_fewer)
+    info = {"filter_ms": 0.0, "pack_ms": 0.0, "comm_ms": 0.0, "pipelined": bool(pipelined)}
 
     def sync(dev):
         if dev.type == "cuda":
@@ -171,8 +196,8 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         if masks is None:
             # the kernel counts each rank's rows while it writes the masks: 4 bytes per rank to read back
             masks, counts = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
-                                             [assign_views(len(cams), r, world, assignment) for r in range(world)],
-                                             scaling_modifier, return_counts=True)
+                                             [assign_views(len(cams), r, world, assignment, src, src_fewer)
+                                              for r in range(world)], scaling_modifier, return_counts=True)
         else:
             masks = masks.to(dev)
             counts = masks.sum(dim=1)
@@ -182,30 +207,37 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         sync(dev)
         t1 = time.perf_counter()
         trail = {k: tuple(bufs[k].shape[1:]) for k in keys}
-        if dev.type == "cuda" and len(keys) <= 8 and all(bufs[k].dtype == torch.float32 for k in keys):
-            # one pass: every packed row gathered straight from the tensors (bsr_pack_rows)
-            from .rasterizer import _pack_rows_native
-            flat_all = _pack_rows_native([bufs[k] for k in keys], pairs.reshape(-1)[1:], idx_stride=2,
-                                         rows=pairs.shape[0])
-        else:                                       # CPU plumbing tests (gloo)
-            idx_all = pairs[:, 1].contiguous()
-            flat_all = torch.cat([bufs[k].detach().index_select(0, idx_all).reshape(idx_all.numel(), -1).float()
-                                  for k in keys], dim=1).contiguous()      # [sum counts, floats per Gaussian]
-        sync(dev)
-        t2 = time.perf_counter()
-        info["filter_ms"], info["pack_ms"] = (t1 - t0) * 1e3, (t2 - t1) * 1e3
-        meta = [{"keys": keys, "trail": trail, "counts": counts}]
         offsets = [0]
         for c in counts:
             offsets.append(offsets[-1] + c)
+        native_pack = dev.type == "cuda" and len(keys) <= 8 and all(bufs[k].dtype == torch.float32 for k in keys)
+        flat_idx = pairs.reshape(-1)
+
+        def pack_rows(lo, hi):
+            """[hi - lo, floats per Gaussian]: the packed rows pairs[lo:hi] (rank-major, ids ascending)"""
+            if hi == lo:
+                return torch.empty((0, sum(int(np.prod(trail[k], dtype=np.int64)) if trail[k] else 1 for k in keys)),
+                                   dtype=torch.float32, device=dev)
+            if native_pack:   # one pass: every packed row gathered straight from the tensors (bsr_pack_rows)
+                from .rasterizer import _pack_rows_native
+                return _pack_rows_native([bufs[k] for k in keys], flat_idx[2 * lo + 1:], idx_stride=2, rows=hi - lo)
+            idx = pairs[lo:hi, 1].contiguous()              # CPU plumbing tests (gloo)
+            return torch.cat([bufs[k].detach().index_select(0, idx).reshape(idx.numel(), -1).float() for k in keys],
+                             dim=1).contiguous()
+
+        if not (multi and pipelined):
+            flat_all = pack_rows(0, offsets[-1])
+            sync(dev)
+            info["pack_ms"] = (time.perf_counter() - t1) * 1e3
+        info["filter_ms"] = (t1 - t0) * 1e3
+        meta = [{"keys": keys, "trail": trail, "counts": counts}]
     if multi:
         dist.broadcast_object_list(meta, src=src)
     keys, trail, counts = meta[0]["keys"], meta[0]["trail"], meta[0]["counts"]
     widths = [int(np.prod(trail[k], dtype=np.int64)) if trail[k] else 1 for k in keys]
     row = sum(widths)
     if rank == src:
-        dev = flat_all.device
-        mine = flat_all[offsets[rank]:offsets[rank + 1]]
+        mine = None if (multi and pipelined) else flat_all[offsets[rank]:offsets[rank + 1]]
     else:
         dev = torch.device(device) if device is not None else (
             cams.world_view.device if isinstance(cams, CameraPack) else cams[0].world_view_transform.device)
@@ -215,17 +247,40 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         t0 = time.perf_counter()
         # gloo moves host memory only (CPU test backend; two ranks on one GPU in the -m gpu tests): stage through it
         via_host = dist.get_backend() == "gloo" and dev.type == "cuda"
-        ops, landing = [], None
-        if rank == src:
-            wire = flat_all.cpu() if via_host else flat_all
-            ops = [dist.P2POp(dist.isend, wire[offsets[r]:offsets[r + 1]], r) for r in range(world)
-                   if r != src and counts[r] > 0]
-        elif counts[rank] > 0:
-            landing = torch.empty(mine.shape, dtype=torch.float32) if via_host else mine
-            ops = [dist.P2POp(dist.irecv, landing, src)]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
+        landing = None
+        if rank == src and pipelined:
+            # one rank at a time: pack -> post the send -> pack the next one; own block last.  The order in which the
+            # sends were posted is returned for the tests (info["send_order"]).
+            pending, order, keep = [], [], []
+            for r in [q for q in range(world) if q != src] + [src]:
+                part = pack_rows(offsets[r], offsets[r + 1])
+                if r == src:
+                    mine = part
+                elif counts[r] > 0:
+                    wire = part.cpu() if via_host else part
+                    keep.append(wire)                   # (alive until its send has completed)
+                    pending.append(dist.isend(wire, r))
+                    order.append(r)
+            sync(dev)
+            info["pack_ms"] = (time.perf_counter() - t0) * 1e3   # packing with the sends already under way
+            for w in pending:
                 w.wait()
+            info["send_order"] = order
+        else:
+            ops = []
+            if rank == src:
+                wire = flat_all.cpu() if via_host else flat_all
+                ops = [dist.P2POp(dist.isend, wire[offsets[r]:offsets[r + 1]], r) for r in range(world)
+                       if r != src and counts[r] > 0]
+            elif counts[rank] > 0:
+                landing = torch.empty(mine.shape, dtype=torch.float32) if via_host else mine
+                if pipelined:
+                    dist.irecv(landing, src).wait()
+                else:
+                    ops = [dist.P2POp(dist.irecv, landing, src)]
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
         if landing is not None and via_host:
             mine.copy_(landing)
         sync(dev)
@@ -266,12 +321,13 @@ def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier:
             len(groups), debug, return_counts)
 
 
-def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0):
+def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0,
+                          src_fewer: int = 0):
     """{world: [rows rank 0 .. world-1 would receive from scatter_visible_gaussians]} for several node sizes
     (bench.py's scaling prediction): one pass of the per-group visibility filter per node size."""
     out = {}
     for w in worlds:
-        groups = [assign_views(len(cams), r, w, assignment) for r in range(w)]
+        groups = [assign_views(len(cams), r, w, assignment, 0, src_fewer) for r in range(w)]
         _, c = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], groups, scaling_modifier,
                                 return_counts=True)
         out[int(w)] = [int(x) for x in c.tolist()]
@@ -552,3 +608,31 @@ def render_views_sharded(cams, gaussians: dict, bg_color, sh_degree, rank=None, 
             res = render_view(cam, gaussians, bg_color, sh_degree)
             out[i] = (res["render"], res["depth"]) if keep_outputs else None
     return out
+
+
+def modelled_scatter_sweep(n_views: int, world: int, rows, sizes, filter_ms: float, pack_ms_per_row: float,
+                           row_bytes: int, per_view_ms: float, link_GBs: float = 153.0, pipelined: bool = True):
+    """Critical path (ms) of a cold view-parallel sweep through scatter_visible_gaussians on `world` ranks, from measured
+    single-GPU stage times -- the model bench.py states for the first multi-GPU record to falsify:
+
+      the source (rank 0) filters for `filter_ms` (group filter + the count read-back + the pair list), then packs rank
+      by rank (rows_r x pack_ms_per_row each), remote ranks first and its own block last; pipelined: rank r's message
+      leaves when ITS rows are packed (otherwise when all are), needs rows_r x row_bytes / link rate on its own xGMI link
+      (point-to-point mesh: the links do not share bandwidth), and rank r then renders its sizes[r] views at
+      per_view_ms each; the source renders after its last pack.
+
+    Returns {"sweep_ms", "critical_rank", "finish_ms": [...]}.  world == 1: no distribution at all."""
+    if world == 1:
+        t = n_views * per_view_ms
+        return {"sweep_ms": t, "critical_rank": 0, "finish_ms": [t]}
+    pack = [rows[r] * pack_ms_per_row for r in range(world)]
+    total_pack = sum(pack)
+    finish = [0.0] * world
+    done = filter_ms
+    for r in range(1, world):
+        done += pack[r]
+        leave = done if pipelined else filter_ms + total_pack
+        finish[r] = leave + rows[r] * row_bytes / (link_GBs * 1e6) + sizes[r] * per_view_ms
+    finish[0] = filter_ms + total_pack + sizes[0] * per_view_ms
+    worst = max(range(world), key=lambda r: finish[r])
+    return {"sweep_ms": finish[worst], "critical_rank": worst, "finish_ms": finish}

@@ -69,7 +69,7 @@ def test_broadcast_and_view_sharding_world2():
     assert sorted(results) == [(0, True), (1, True)]
 
 
-def _scatter_worker(rank, world, port, q):
+def _scatter_worker(rank, world, port, q, pipelined=True, src_fewer=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -79,11 +79,14 @@ def _scatter_worker(rank, world, port, q):
         src = {"means3D": torch.randn(P, 3, generator=g), "scales": torch.rand(P, 3, generator=g),
                "rotations": torch.randn(P, 4, generator=g), "opacities": torch.rand(P, 1, generator=g),
                "shs": torch.randn(P, M, 3, generator=g)}
-        masks = torch.rand(world, P, generator=g) < torch.tensor([[0.1], [0.3], [0.0]])[:world]   # rank 2: nothing visible
+        masks = torch.rand(world, P, generator=g) < torch.tensor([[0.1], [0.3], [0.0], [0.2]])[:world]   # rank 2: nothing visible
         cams = [helpers.scene_b(1, 64, 48, 0, n_views=10).cameras[i] for i in range(10)]
         local, mine, info = views.scatter_visible_gaussians(src if rank == 0 else None, cams, src=0,
-                                                            assignment="contiguous", masks=masks if rank == 0 else None)
-        ok = mine == views.assign_views(10, rank, world, "contiguous")
+                                                            assignment="contiguous", masks=masks if rank == 0 else None,
+                                                            pipelined=pipelined, src_fewer=src_fewer)
+        ok = mine == views.assign_views(10, rank, world, "contiguous", 0, src_fewer)
+        if rank == 0 and pipelined:   # remote ranks in rank order (a rank that sees nothing gets no message), own block last
+            ok = ok and info["send_order"] == [r for r in range(1, world) if int(masks[r].sum()) > 0]
         ok = ok and info["counts"] == [int(m.sum()) for m in masks] and info["bytes"][rank] == info["counts"][rank] * (3 + 3 + 4 + 1 + 3 * M) * 4
         for k, v in src.items():
             ok = ok and torch.equal(local[k], v[masks[rank]]) and local[k].is_contiguous()
@@ -110,7 +113,33 @@ def test_scatter_of_per_rank_visible_subsets_world3():
     assert sorted(results) == [(0, True), (1, True), (2, True)]
 
 
+def test_pipelined_scatter_world4_and_the_batched_form():
+    """The pipelined distribution (one pack + one send per rank, posted as soon as that rank's rows are packed, the
+    source's own block last) over gloo with FOUR ranks, uneven view blocks (the source takes two views fewer), and the
+    round-3 form (one pack, all sends together) beside it: same rows on every rank either way."""
+    for world, pipelined, src_fewer in ((4, True, 2), (4, False, 0), (2, True, 1)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q, pipelined, src_fewer)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(results) == [(r, True) for r in range(world)], (world, pipelined, src_fewer, results)
+
+
 def test_view_assignments():
+    # uneven contiguous blocks: the distributing rank takes fewer views, its peers share them out; still a partition
+    assert views.staggered_block_sizes(64, 8, 0, 0) == [8] * 8
+    assert views.staggered_block_sizes(64, 8, 0, 3) == [5, 9, 9, 9, 8, 8, 8, 8]
+    assert views.staggered_block_sizes(10, 4, 0, 2) == [1, 4, 4, 1]
+    assert views.staggered_block_sizes(64, 1, 0, 5) == [64]
+    for n, world, fewer in ((64, 8, 3), (10, 4, 2), (7, 3, 9)):
+        parts = [views.assign_views(n, r, world, "contiguous", 0, fewer) for r in range(world)]
+        assert [i for p in parts for i in p] == list(range(n)), (n, world, fewer)
     for n, world in ((64, 8), (10, 4), (7, 3), (3, 5)):
         for mode in ("round_robin", "contiguous"):
             parts = [views.assign_views(n, r, world, mode) for r in range(world)]
@@ -125,3 +154,21 @@ def test_broadcast_is_a_noop_without_process_group():
     p = torch.ones(3, requires_grad=True)
     p.grad = torch.full((3,), 2.0)
     assert views.allreduce_gradients([p]) == 0.0 and torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def test_modelled_scatter_sweep_critical_path():
+    """views.modelled_scatter_sweep (the model bench.py states for a multi-GPU record to falsify) on numbers small enough
+    to follow by hand: filter 1.0; packs 0.1 per 1000 rows; 1000 rows = 1 MB on a 1 GB/s link = 1.0; 0.5 per view."""
+    kw = dict(filter_ms=1.0, pack_ms_per_row=1e-4, row_bytes=1000, per_view_ms=0.5, link_GBs=1.0)
+    one = views.modelled_scatter_sweep(8, 1, [5000], [8], **kw)
+    assert one["sweep_ms"] == 4.0
+    rows, sizes = [1000, 2000, 1000, 3000], [2, 2, 2, 2]
+    m = views.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=True, **kw)
+    # rank 1 leaves at 1.0 + 0.2, rank 2 at + 0.1, rank 3 at + 0.3; wire 2.0 / 1.0 / 3.0; render 1.0 each; the source:
+    # 1.0 + 0.7 + 1.0
+    assert [round(x, 6) for x in m["finish_ms"]] == [2.7, 4.2, 3.3, 5.6] and m["critical_rank"] == 3
+    b = views.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=False, **kw)
+    assert [round(x, 6) for x in b["finish_ms"]] == [2.7, 4.7, 3.7, 5.7]      # every message leaves after ALL packs
+    # fewer views for the rank on the critical path shortens it
+    m2 = views.modelled_scatter_sweep(8, 4, rows, [3, 2, 2, 1], pipelined=True, **kw)
+    assert round(m2["sweep_ms"], 6) == 5.1
