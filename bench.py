@@ -525,33 +525,40 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                 "pack_ms_per_million_rows": round(pack_per_row * 1e6, 4)}
         t1 = n_views * per_view_ms
         for w in (1, 2, 4, 8):
-            best = None
-            for fewer in range(0, max(1, math.ceil(n_views / w))):
-                sizes = views.staggered_block_sizes(n_views, w, 0, fewer)
-                rr = views.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", src_fewer=fewer)[w]
-                m = views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
-                                                 per_view_ms, LINK_GBS, pipelined=True)
-                cand = (m["sweep_ms"], fewer, sizes, rr, m)
-                if fewer == 0:
-                    even = cand
-                    batched = views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row,
-                                                           row_bytes, per_view_ms, LINK_GBS, pipelined=False)
-                if best is None or cand[0] < best[0]:
-                    best = cand
-                if w == 1:
-                    break
+            def model(sizes, pipelined=True):
+                rr = views.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", sizes=sizes)[w]
+                return rr, views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
+                                                        per_view_ms, LINK_GBS, pipelined=pipelined)
+            even_sizes = views.staggered_block_sizes(n_views, w)
+            rows_even, even = model(even_sizes)
+            _, batched = model(even_sizes, pipelined=False)
+            # uneven blocks: a rank whose rows leave late gets fewer views (views.balanced_block_sizes).  A block's rows
+            # (hence its pack and wire time) depend on its size, so the split is iterated: leave times from the previous
+            # split's rows -> new split, three rounds.
+            sizes, rows_b, bal = even_sizes, rows_even, even
+            for _ in range(3 if w > 1 else 0):
+                pk = [rows_b[r] * pack_per_row for r in range(w)]
+                leave = [info["filter_ms"] + sum(pk)] + [info["filter_ms"] + sum(pk[1:r + 1]) + rows_b[r] * row_bytes /
+                                                         (LINK_GBS * 1e6) for r in range(1, w)]
+                cand = views.balanced_block_sizes(n_views, w, leave, per_view_ms)
+                rows_c, m = model(cand)
+                if m["sweep_ms"] < bal["sweep_ms"]:
+                    sizes, rows_b, bal = cand, rows_c, m
             tb = (0.0 if w == 1 else P * row_bytes / (LINK_GBS * 1e6)) + math.ceil(n_views / w) * per_view_bcast_ms
             t_render = math.ceil(n_views / w) * per_view_ms
             pred[str(w)] = {
-                "rows_max": max(even[3]),
-                "sweep_ms_scatter": round(even[0], 3), "speedup_scatter": round(t1 / even[0], 2),
-                "critical_rank": even[4]["critical_rank"],
+                "rows_max": max(rows_even),
+                "sweep_ms_scatter": round(even["sweep_ms"], 3), "speedup_scatter": round(t1 / even["sweep_ms"], 2),
+                "critical_rank": even["critical_rank"],
                 "sweep_ms_scatter_unpipelined": round(batched["sweep_ms"], 3),
-                # the source takes `src_fewer` views less than an even share (views.staggered_block_sizes)
-                "staggered": {"src_fewer": best[1], "views_per_rank": best[2], "sweep_ms_scatter": round(best[0], 3),
-                              "speedup_scatter": round(t1 / best[0], 2), "critical_rank": best[4]["critical_rank"]},
+                # uneven contiguous blocks (scatter_visible_gaussians(sizes=...)): ranks served late render fewer views
+                "balanced": {"views_per_rank": sizes, "rows_per_rank": rows_b, "sweep_ms_scatter": round(bal["sweep_ms"], 3),
+                             "speedup_scatter": round(t1 / bal["sweep_ms"], 2), "critical_rank": bal["critical_rank"],
+                             # what no split can beat: the filter, one block's wire time and its share of the views
+                             "floor_ms": round(info["filter_ms"] + min(rows_b[1:] or [0]) * row_bytes / (LINK_GBS * 1e6)
+                                               + n_views / w * per_view_ms, 3) if w > 1 else None},
                 "sweep_ms_broadcast": round(tb, 3),
-                "Msplats_per_s_scatter": round(n_views * P / (best[0] * 1e-3) / 1e6, 1),
+                "Msplats_per_s_scatter": round(n_views * P / (bal["sweep_ms"] * 1e-3) / 1e6, 1),
                 # the sweep alone, Gaussians already distributed (a second camera path over the same scene):
                 # ceil(views / N) views per rank, no exchange at all
                 "sweep_ms_resident": round(t_render, 3),

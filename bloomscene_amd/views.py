@@ -95,16 +95,35 @@ def staggered_block_sizes(n_views: int, world: int, src: int = 0, src_fewer: int
     return sizes
 
 
-def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin", src: int = 0, src_fewer: int = 0):
+def balanced_block_sizes(n_views: int, world: int, leave_ms, per_view_ms: float, src: int = 0):
+    """Contiguous view-block sizes that let all ranks FINISH together when they cannot START together: rank r can begin
+    rendering at leave_ms[r] (for a peer: when its rows have arrived; for the distributing rank: when it has packed the
+    last block), and every view costs per_view_ms.  Views are dealt one at a time to the rank that would finish
+    earliest (water-filling); ties go to the lower rank.  A rank served late gets fewer views."""
+    sizes = [0] * world
+    finish = [float(t) for t in leave_ms]
+    for _ in range(n_views):
+        r = min(range(world), key=lambda k: (finish[k] + per_view_ms, k))
+        sizes[r] += 1
+        finish[r] += per_view_ms
+    return sizes
+
+
+def assign_views(n_views: int, rank: int, world: int, mode: str = "round_robin", src: int = 0, src_fewer: int = 0,
+                 sizes=None):
     """View indices of `rank`.  "round_robin": {i : i mod world == rank} (balances a yaw-dependent load; every rank sees
     the whole sweep, so it needs nearly every Gaussian any view sees).  "contiguous": the rank's block of ceil(n / world)
     neighbouring views -- neighbouring views of a rotate360 sweep overlap (utils/trajectory.py:110-121: 360 / n degrees
     apart against a ~57 degree field of view), so the Gaussians ONE rank needs are a small part of the scene; what
-    `scatter_visible_gaussians` sends.  With ``src_fewer`` > 0 the blocks are uneven (staggered_block_sizes)."""
+    `scatter_visible_gaussians` sends.  With ``src_fewer`` > 0 the blocks are uneven (staggered_block_sizes); ``sizes``
+    gives them outright (balanced_block_sizes)."""
     if mode == "round_robin":
         return list(range(rank, n_views, world))
     if mode == "contiguous":
-        sizes = staggered_block_sizes(n_views, world, src, src_fewer)
+        if sizes is None:
+            sizes = staggered_block_sizes(n_views, world, src, src_fewer)
+        if len(sizes) != world or sum(sizes) != n_views or min(sizes) < 0:
+            raise ValueError("sizes must hold one non-negative block size per rank and add up to the number of views")
         start = sum(sizes[:rank])
         return list(range(start, start + sizes[rank]))
     raise ValueError(f"unknown view assignment '{mode}'")
@@ -145,7 +164,8 @@ def broadcast_gaussians(bufs: dict, src: int = 0, force: bool = False) -> float:
 
 
 def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "contiguous", masks=None,
-                              scaling_modifier: float = 1.0, device=None, pipelined: bool = True, src_fewer: int = 0):
+                              scaling_modifier: float = 1.0, device=None, pipelined: bool = True, src_fewer: int = 0,
+                              sizes=None):
     """Hand every rank ONLY the Gaussians its views can see, instead of broadcasting all of them.
 
     xGMI is a point-to-point mesh: rank `src` reaches each of its peers over a link of its own (7 x ~153 GB/s on an
@@ -164,8 +184,8 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     -- remote ranks first, in rank order, its own block last -- so that the first peer's rows are on the wire while the
     next peer's are still being gathered (the pack kernels run on the compute stream, RCCL's sends on its own); every
     peer starts rendering as soon as ITS message has arrived.  False: one pack of all rows, then all sends together
-    (round 3's form).  ``src_fewer``: uneven view blocks (staggered_block_sizes): `src`, which is busy distributing,
-    takes that many views fewer.
+    (round 3's form).  ``src_fewer`` / ``sizes``: uneven view blocks (staggered_block_sizes / balanced_block_sizes; the
+    same on every rank): a rank whose rows leave late gets fewer views.
 
     ``bufs``: on `src` the dict of full per-Gaussian tensors ([P, ...] fp32; must hold means3D, scales, rotations for
     the filter); ignored elsewhere (pass None).  ``cams``: the whole camera path, on every rank.  ``masks``
@@ -177,7 +197,7 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if multi else 0
     world = dist.get_world_size() if multi else 1
-    my_views = assign_views(len(cams), rank, world, assignment, src, src_fewer)
+    my_views = assign_views(len(cams), rank, world, assignment, src, src_fewer, sizes)
     info = {"filter_ms": 0.0, "pack_ms": 0.0, "comm_ms": 0.0, "pipelined": bool(pipelined)}
 
     def sync(dev):
@@ -196,7 +216,7 @@ def scatter_visible_gaussians(bufs, cams, src: int = 0, assignment: str = "conti
         if masks is None:
             # the kernel counts each rank's rows while it writes the masks: 4 bytes per rank to read back
             masks, counts = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"],
-                                             [assign_views(len(cams), r, world, assignment, src, src_fewer)
+                                             [assign_views(len(cams), r, world, assignment, src, src_fewer, sizes)
                                               for r in range(world)], scaling_modifier, return_counts=True)
         else:
             masks = masks.to(dev)
@@ -322,12 +342,12 @@ def group_visibility(cams, means3D, scales, rotations, groups, scaling_modifier:
 
 
 def visible_rows_per_rank(bufs, cams, worlds=(1, 2, 4, 8), assignment: str = "contiguous", scaling_modifier: float = 1.0,
-                          src_fewer: int = 0):
+                          src_fewer: int = 0, sizes=None):
     """{world: [rows rank 0 .. world-1 would receive from scatter_visible_gaussians]} for several node sizes
     (bench.py's scaling prediction): one pass of the per-group visibility filter per node size."""
     out = {}
     for w in worlds:
-        groups = [assign_views(len(cams), r, w, assignment, 0, src_fewer) for r in range(w)]
+        groups = [assign_views(len(cams), r, w, assignment, 0, src_fewer, sizes) for r in range(w)]
         _, c = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], groups, scaling_modifier,
                                 return_counts=True)
         out[int(w)] = [int(x) for x in c.tolist()]

@@ -172,3 +172,16 @@ def test_modelled_scatter_sweep_critical_path():
     # fewer views for the rank on the critical path shortens it
     m2 = views.modelled_scatter_sweep(8, 4, rows, [3, 2, 2, 1], pipelined=True, **kw)
     assert round(m2["sweep_ms"], 6) == 5.1
+
+
+def test_balanced_block_sizes_deal_fewer_views_to_ranks_that_start_late():
+    sizes = views.balanced_block_sizes(64, 8, [0.53, 0.41, 0.45, 0.48, 0.51, 0.55, 0.58, 0.62], 0.05)
+    assert sum(sizes) == 64 and sizes[1] == max(sizes) and sizes[7] == min(sizes) and max(sizes) - min(sizes) >= 3
+    finish = [t + 0.05 * v for t, v in zip([0.53, 0.41, 0.45, 0.48, 0.51, 0.55, 0.58, 0.62], sizes)]
+    assert max(finish) - min(finish) <= 0.05 + 1e-9          # all ranks finish within one view of each other
+    assert views.balanced_block_sizes(10, 2, [0.0, 0.0], 1.0) == [5, 5]
+    parts = [views.assign_views(64, r, 8, "contiguous", sizes=sizes) for r in range(8)]
+    assert [i for p in parts for i in p] == list(range(64)) and [len(p) for p in parts] == sizes
+    import pytest
+    with pytest.raises(ValueError):
+        views.assign_views(64, 0, 8, "contiguous", sizes=[8] * 7)
