@@ -981,12 +981,19 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			}
 		};
 
+#ifdef BSR_BWT_KO_WALK   // knock-out build (timing only, results wrong): staging + epilogue without the walk
+		const int n_pad = 0;
+#else
 		const int n_pad = (n_u + (BSR_BWT_PAD - 1)) & ~(BSR_BWT_PAD - 1);   // (the row is sentinel-padded to whole trips)
+#endif
 		for (int i = 0; i < n_pad; i += BSR_BWT_CHUNK) {
 			const uint4 la = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i]);
 			const uint4 lb = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i + 4]);   // (past the padding: inside the struct, not used)
 			trip(la, 0);
 			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4);
+#ifdef BSR_BWT_KO_PHASE2   // knock-out build (timing only): phase 1 without the transposed reduction
+			continue;
+#endif
 			// the wave's own stores, then its own loads: the LDS serves a wave's operations in order
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
