@@ -737,6 +737,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 {
 	constexpr int NV = DEPTH ? 10 : 9;
 	constexpr int B = BSR_BWT_BATCH;
+	static_assert(B <= 64 && B % 4 == 0, "a wave stages a batch lane by lane");
 	__shared__ BwtShared<NV> sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
@@ -828,6 +829,38 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	for (int base = 0; base < n_walk; base += B) {
 		const int cnt = min(B, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
+#ifndef BSR_BWT_SHARED_STAGING
+		// ---- staging: EVERY wave looks at the batch's 64 entries itself (lane j <-> entry j: the same 64-B lines four
+		// times, three of them from the L1/L2) and tests them against ITS OWN quadrant: one box test per wave instead of
+		// four on one wave, its list straight from its own ballot -- no count table, one barrier instead of two.  Wave 0
+		// also writes the records to LDS and keeps the entries' slab rows for the epilogue.
+		// (the trailing barrier of the previous iteration fenced the staging buffers)
+		const bool valid = lane < cnt;      // (every wave; `valid` of the epilogue below: wave 0's)
+		uint32_t my_row = 0;
+		bool hit = false;
+		if (valid) {
+			const uint32_t id = point_list[start + (uint32_t)(top - lane)];
+			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
+			const float4 r0 = r[0], r1 = r[1];
+			if (wave == 0) {
+				float4 r2 = r[2];
+				my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
+				r2.w = r1.y + 2.2e-3f;   // staged q2.w: just above the decision band, -ln(255 o) + 1.2e-3
+				sh.st.q0[lane] = r0;
+				sh.st.q1[lane] = r1;
+				sh.st.q2[lane] = r2;
+			}
+			const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
+			const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
+			hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, tile_x0 + (float)((wave & 1) << 3),
+			                        tile_y0 + (float)((wave >> 1) << 3));
+		}
+		const unsigned long long hits = wave_ballot(hit);
+		const int n_u = __builtin_amdgcn_readfirstlane((int)__popcll(hits));
+		if (hit) sh.st.list[wave][__popcll(hits & ((1ull << lane) - 1ull))] = (unsigned int)(lane << 4);
+		if (lane < BSR_BWT_PAD - 1) sh.st.list[wave][n_u + lane] = (unsigned int)(B << 4);   // pad to whole trips
+		__syncthreads();
+#else
 		const bool valid = tid < cnt;
 		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		uint32_t my_row = 0;
@@ -844,6 +877,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact_s(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+#endif
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
 		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
 		const int joff_min = (top - (int)last_contributor) * 16;
@@ -1004,7 +1038,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
 		__syncthreads();
-		if (valid) {
+		if (valid && tid < B) {   // (wave 0: it holds the entries' slab rows)
 			float a9[10];
 			a9[9] = 0.f;
 #pragma unroll
@@ -1027,7 +1061,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
+#if defined(BSR_BWT_SHARED_STAGING) || defined(BSR_BWT_TRAILING_BARRIER)
 		__syncthreads();
+#endif
+		// (no barrier here: while wave 0 adds up the batch, the other waves already fetch and test the next one -- they
+		// write nothing but their own lists, which only they read; the records, the partial sums and their zeroing are
+		// wave 0's and the next walk starts behind the staging's barrier, which wave 0 reaches after this epilogue)
 	}
 
 	// entries no pixel of the tile reached: zero rows, but they still need their map entry
@@ -1067,13 +1106,16 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	// k_render_bwd: the transposed walk moves work from the vector ALU to the LDS (27 instead of 20 LDS cycles per visit)
 	// and stages 64 entries per batch instead of 128, which costs more than it saves once a tile's life is dominated by
 	// staging (5 M Gaussians: 2700 entries per tile, 1.1 visits per staged entry) or by visits alone (scales x 3).
-	// A/B on one box, k_render_bwd -> k_render_bwd_t, by reference instances per tile: 160: -5 %, 540 (C3): -15 %, 1000
-	// -1300: -4..-6 %, 1600: +1 %, 2200 (scales x 3): +4.5 %, 2700 (C5): +5 %.  Both walks take every decision alike;
-	// their sums differ in the order of the additions only (gradients carry a tolerance either way).
+	// A/B on one box, k_render_bwd -> k_render_bwd_t, by reference instances per tile: 160: -5 %, 540 (C3): -20 %, 1000
+	// -1300: -6..-9 %, 1600 (3 M Gaussians): -3 %, 2200 (scales x 3): +4 %, 2700 (C5): +3 %.  Both walks take every
+	// decision alike; their sums differ in the order of the additions only (gradients carry a tolerance either way).
 #if defined(BSR_BWD_NETWORK_WALK) || defined(BSR_WALK_STATS)
 	const bool network = true;
 #else
-	const bool network = strict || (long long)num_rendered > 1500ll * n_tiles;
+#ifndef BSR_BWT_MAX_PER_TILE
+#define BSR_BWT_MAX_PER_TILE 1900ll   // (A/B hook: make variant DEFS=-DBSR_BWT_MAX_PER_TILE=100000000ll)
+#endif
+	const bool network = strict || (long long)num_rendered > BSR_BWT_MAX_PER_TILE * n_tiles;
 #endif
 	if (network) {
 		if (depth && strict) BSR_LAUNCH_BWD(true, true);
