@@ -415,8 +415,45 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int cnt = min(BSR_BWD_BATCH, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
 		const bool valid = tid < cnt;
-		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		uint32_t my_row = 0;
+#if defined(BSR_BWD_WAVE_STAGING) && BSR_BWD_BATCH == 128
+		// Round 4 experiment (opt-in: measured +6 % on the dense scene, noise at C5 -- this walk is bound by its vector
+		// instructions at 6 waves per SIMD, not by its staging; docs/EXPERIMENTS.md).  As in k_render_bwd_t: EVERY wave
+		// looks at the batch itself -- lane j at entries j and j + 64, the same
+		// 64-B lines four times, three of them from the L1 / L2 -- and tests them against ITS OWN quadrant: two box tests
+		// per wave instead of four on each of two waves, its list straight from its own two ballots (no count table, one
+		// barrier instead of two).  Waves 0 and 1 also write the records to LDS (entry tid) and keep the rows.
+		// (the trailing barrier of the previous iteration fenced the staging buffers)
+		unsigned long long hits2[2];
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int j = lane + 64 * h;
+			bool hit = false;
+			if (j < cnt) {
+				const uint32_t id = point_list[start + (uint32_t)(top - j)];
+				const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
+				const float4 r0 = r[0], r1 = r[1];
+				if (wave == h) {   // this wave's lanes own entries 64 h .. 64 h + 63 = tid
+					float4 r2 = r[2];
+					my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
+					r2.w = r1.y + 2.2e-3f;   // staged q2.w (the mask half is used up): just above the decision band, -ln(255 o) + 1.2e-3
+					sh.st.q0[j] = r0;
+					sh.st.q1[j] = r1;
+					sh.st.q2[j] = r2;
+				}
+				const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
+				const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
+				hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, tile_x0 + (float)((wave & 1) << 3),
+				                        tile_y0 + (float)((wave >> 1) << 3));
+			}
+			hits2[h] = wave_ballot(hit);
+			const int before = h == 0 ? 0 : (int)__popcll(hits2[0]);
+			if (hit) sh.st.list[wave][before + (int)__popcll(hits2[h] & ((1ull << lane) - 1ull))] = (unsigned int)(j << 4);
+		}
+		const int n_u = __builtin_amdgcn_readfirstlane((int)(__popcll(hits2[0]) + __popcll(hits2[1])));
+		__syncthreads();
+#else
+		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		if (valid) {
 			const uint32_t my_slot = start + (uint32_t)(top - tid);
 			const uint32_t id = point_list[my_slot];
@@ -431,6 +468,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
 
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
+#endif
 #ifdef BSR_WALK_STATS
 		{
 			// what-if: per-wave lists split into the two 8x4 halves of the quadrant (rows 0-3 / 4-7), or its four 8x2
@@ -567,7 +605,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
+#if !(defined(BSR_BWD_WAVE_STAGING) && BSR_BWD_BATCH == 128)
 		__syncthreads();
+#endif
 	}
 
 	// entries no pixel of the tile reached: zero rows, but they still need their map entry
