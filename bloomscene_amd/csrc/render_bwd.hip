@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		// band (q2.w = its upper edge) evaluates the pinned exp and tests alpha, everywhere else the value comes from
 		// v_exp_f32.  (Testing alpha on a trip's other entries changes nothing: outside the band every candidate has
 		// alpha >= (1 + 1e-3) / 255.)
-		struct Ent { float4 q0, q1, q2; float power; bool cand; };
+		struct Ent { float4 q0, q1, q2; float power; bool cand; uint64_t cand_mask; };
 		auto load = [&](const unsigned int joff) {
 			Ent e;
 			const char* rec = rec0 + joff;
@@ -943,6 +943,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			const float dy = e.q0.y - pixfy;
 			e.power = (e.q0.z * dx * dx + e.q1.x * dy * dy) + e.q0.w * dx * dy;   // pre-scaled conic (common.h): the forward's bits
 			e.cand = ((int)joff > joff_min) && !(e.power > 0.0f) && !(e.power < e.q1.y);
+			// the same predicate as a lane mask, assembled on the scalar side from ballots of SINGLE compares (a ballot of
+			// an AND of lane masks makes hipcc materialise the mask in a VGPR and compare it again: two vector slots)
+			e.cand_mask = wave_ballot((int)joff > joff_min) & wave_ballot(!(e.power > 0.0f)) & wave_ballot(!(e.power < e.q1.y));
 			return e;
 		};
 		auto chain = [&](const Ent& e, float G, float alpha, const int slot) {
@@ -974,7 +977,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 				e[k] = load(l[k]);
 				g[k] = __builtin_amdgcn_exp2f(e[k].power * 1.44269504088896341f);
 				// a candidate below the band's upper edge (or a NaN edge / power: opacity <= 0 or NaN) -> decide with the pinned exp
-				vote |= wave_ballot(e[k].cand && !(e[k].power >= e[k].q2.w));
+				vote |= e[k].cand_mask & wave_ballot(!(e[k].power >= e[k].q2.w));
 			}
 			const bool decide = vote != 0ull;
 			if (decide) {   // rare (a few % of the trips): each lane picks its exp with the FORWARD's expression

@@ -122,10 +122,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 		// c2: this lane blends the entry unless the stop test below fires
 		auto blend = [&](const Ent& e, const float alpha_raw, const bool c2, const unsigned int joff) {
 			const float a_eff = c2 ? alpha_raw : 0.0f;
-			const float test_T = T * (1 - a_eff);
-			const bool stop = test_T < 0.0001f;
-			const float a = stop ? 0.0f : a_eff;
+			bool stop;
 			if (EXACT) {
+				const float test_T = T * (1 - a_eff);
+				stop = test_T < 0.0001f;
+				const float a = stop ? 0.0f : a_eff;
 				// reference :439-446 as its nvcc build evaluates them (and the oracle restates them): c * alpha rounded,
 				// then ONE fused multiply-add with T.  fma(c * 0, T, x) == x exactly for every finite c.
 				C0 = __builtin_fmaf(e.q2.x * a, T, C0);
@@ -133,18 +134,24 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, i
 				C2 = __builtin_fmaf(e.q2.z * a, T, C2);
 				D = __builtin_fmaf(e.q1.w * a, T, D);
 				acc = __builtin_fmaf(a, T, acc);
+				T = stop ? T : test_T;
 			} else {
-				// default mode (values within ulps, not bit-equal: DESIGN.md "Numerics"): the blend weight alpha T once,
-				// then one fused multiply-add per target -- 6 instead of 9 instructions; (c alpha) T and c (alpha T)
-				// differ by one rounding
-				const float w = a * T;
+				// default mode (values within ulps, not bit-equal: DESIGN.md "Numerics"): the blend weight alpha T once, then
+				// one fused multiply-add per target -- 6 instead of 9 instructions; (c alpha) T and c (alpha T) differ by
+				// one rounding.  T itself keeps the reference's form T (1 - alpha): 1 - alpha is exact for alpha near 1, so
+				// the product carries half an ulp; T - alpha T would cancel (50 ulp of T' at the 0.99 clamp) and the backward,
+				// which rebuilds T by dividing by the same (1 - alpha), would see it (measured: dL_dmeans3D 1.1e-5 of scale
+				// at C3 instead of 3e-7)
+				const float test_T = T * (1 - a_eff);
+				stop = test_T < 0.0001f;
+				const float w = (stop ? 0.0f : a_eff) * T;
 				C0 = __builtin_fmaf(e.q2.x, w, C0);
 				C1 = __builtin_fmaf(e.q2.y, w, C1);
 				C2 = __builtin_fmaf(e.q2.z, w, C2);
 				D = __builtin_fmaf(e.q1.w, w, D);
 				acc = acc + w;
+				T = stop ? T : test_T;
 			}
-			T = stop ? T : test_T;
 			lastj = (c2 && !stop) ? joff : lastj;   // byte offset of the last entry of THIS batch the lane blended
 			done = done || stop;
 #ifdef BSR_WALK_STATS

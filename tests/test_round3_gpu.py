@@ -124,7 +124,8 @@ def test_default_forward_where_a_stop_decision_moves(name):
     c = Hh.make_case(**STOP_MOVED[name])
     st, _ = Hh.run_oracle(c, backward=False)
     n_flip = _compare_default_with_exact(c, st, name)
-    assert n_flip >= 1
+    print(f"[stop-moved] {name}: {n_flip} pixel(s) with a moved decision")
+    assert n_flip >= 1   # (the seed still exercises the case: it depends on the last bits of the default mode's T chain)
 
 
 @pytest.mark.fast_exp
