@@ -981,15 +981,20 @@ __global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag
                                                         uint32_t* __restrict__ point_list, int force_int)
 {
 	__shared__ uint64_t s_keys[CAP];
-	const int b = blockIdx.x;
-	if (*n_ptr > capacity || b >= flags[count_flag]) return;
-	const uint32_t tile = big_tiles[b];
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
-	if (n <= min_n || n > CAP) return;   // another class (uniform over the workgroup)
-	int n2 = 1024;
-	while (n2 < n) n2 <<= 1;
-	sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list, force_int != 0);
+	if (*n_ptr > capacity) return;
+	// a bounded grid strides over the class's list: a frame without such tiles (C3) pays a small launch instead of
+	// thousands of workgroups that read the count and leave (round 4: 5.1 -> 2.4 us at C3)
+	const int count = flags[count_flag];
+	for (int b = blockIdx.x; b < count; b += gridDim.x) {
+		const uint32_t tile = big_tiles[b];
+		const uint32_t start = tile_start[tile];
+		const int n = (int)(tile_start[tile + 1] - start);
+		if (n <= min_n || n > CAP) continue;   // another class (uniform over the workgroup)
+		int n2 = 1024;
+		while (n2 < n) n2 <<= 1;
+		sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list, force_int != 0);
+		__syncthreads();   // (the keys are read out to point_list before the next segment is loaded)
+	}
 }
 
 // keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
@@ -1008,24 +1013,25 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
-	int b = blockIdx.x;
 	if (*n_ptr > capacity) return;
-	if (b < g4) {
-		if (b >= flags[4]) return;
-		const uint32_t tile = big_tiles[(size_t)T + b];
-		const uint32_t start = tile_start[tile];
-		const int n = (int)(tile_start[tile + 1] - start);
-		if (n <= 4096 || n > CH) return;   // (uniform over the workgroup)
-		sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list, force_int != 0);
+	if ((int)blockIdx.x < g4) {   // bounded grids striding over the two lists (see k_sort_tiles_big)
+		const int count = flags[4];
+		for (int b = blockIdx.x; b < count; b += g4) {
+			const uint32_t tile = big_tiles[(size_t)T + b];
+			const uint32_t start = tile_start[tile];
+			const int n = (int)(tile_start[tile + 1] - start);
+			if (n <= 4096 || n > CH) continue;   // (uniform over the workgroup)
+			sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list, force_int != 0);
+			__syncthreads();
+		}
 		return;
 	}
-	b -= g4;
-	if (b >= flags[5]) return;
-	{
+	const int g8 = (int)gridDim.x - g4, count8 = flags[5];
+	for (int b = (int)blockIdx.x - g4; b < count8; b += g8) {
 		const uint32_t tile = big_tiles[2 * (size_t)T + b];
 		const uint32_t start = tile_start[tile];
 		const int n = (int)(tile_start[tile + 1] - start);
-		if (n <= CH) return;
+		if (n <= CH) continue;
 		uint64_t* k = keys + start;
 		int n2 = 1;
 		while (n2 < n) n2 <<= 1;
@@ -1056,6 +1062,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 		}
 		__syncthreads();
 		for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
+		__syncthreads();
 	}
 }
 
@@ -1144,8 +1151,9 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	                   force_int, tiny ? 64 : 0);
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
 	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
-	const int g1 = min(T, n_bound / (BSR_SORT_SMALL + 1)), g4 = min(T, n_bound / 4097),
-	          g8 = min(T, n_bound / (BSR_SORT_CHUNK + 1));
+	// (upper bounds of the list lengths, capped: the kernels stride over their lists)
+	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), 2560), g4 = min(min(T, n_bound / 4097), 512),
+	          g8 = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), 512);
 	if (g1 > 0)
 		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
 		                   tile_start, big_tiles, flags, elems, point_list, force_int);
