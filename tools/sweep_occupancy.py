@@ -29,8 +29,13 @@ def main():
             pass
         rec = {"point": name, "bwd_batch": batch, "ms_per_step": b["ms_per_step"], "Msplats_per_s": b["value"],
                "stage_ms": {k: b["stage_ms"][k] for k in ("render_fwd", "render_bwd")}}
-        for key, kern in (("render_fwd", "bsr::k_render_fwd<"), ("render_bwd", "bsr::k_render_bwd<false>")):
-            r = next((v for k, v in pmc.items() if k.startswith(kern)), None)   # (template arguments follow the name)
+        # (template arguments follow the name; the backward is k_render_bwd<DEPTH, STRICT> on long-list frames such as C5
+        #  and k_render_bwd_t<DEPTH> otherwise: whichever the run launched)
+        for key, kerns in (("render_fwd", ("bsr::k_render_fwd<",)),
+                           ("render_bwd", ("bsr::k_render_bwd<false", "bsr::k_render_bwd_t<false"))):
+            r = next((v for k, v in pmc.items() if k.startswith(kerns)), None)
+            if r is not None:
+                rec.setdefault("kernels", {})[key] = next(k for k in pmc if k.startswith(kerns))
             if not r:
                 continue
             us = r.get("dur_us(profiled)", 0.0)

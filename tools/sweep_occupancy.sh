@@ -8,9 +8,21 @@
 # usage (GPU box, repo root): bash tools/sweep_occupancy.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/sweep_occ}
+CONFIG=${2:-c5}      # c5 (BASELINE's sweep: the network walk) or c3 (the transposed walk, 30.5 KB LDS: pads 10500 / 24100 / 51400 -> 4 / 3 / 2 workgroups per CU)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # name lib pad_fwd pad_bwd
+if [ "$CONFIG" = c3 ]; then
+POINTS=(
+ "native            libbsr_rast_sweep.so  0     0"
+ "bwd_wg4           libbsr_rast_sweep.so  0     10500"
+ "bwd_wg3           libbsr_rast_sweep.so  0     24100"
+ "bwd_wg2           libbsr_rast_sweep.so  0     51400"
+ "fwd_wg6           libbsr_rast_sweep.so  6500  0"
+ "fwd_wg4           libbsr_rast_sweep.so  20100 0"
+ "fwd_wg2           libbsr_rast_sweep.so  61000 0"
+)
+else
 POINTS=(
  "native            libbsr_rast_sweep.so  0     0"
  "bwd_wg5           libbsr_rast_sweep.so  0     5800"
@@ -24,16 +36,17 @@ POINTS=(
  "bwd_batch64_wg6   libbsr_batch64.so     0     13700"
  "bwd_batch256      libbsr_batch256.so    0     0"
 )
+fi
 for p in "${POINTS[@]}"; do
   set -- $p
   name=$1; lib=$2; export BSR_SWEEP_LDS_PAD_FWD=$3; export BSR_SWEEP_LDS_PAD_BWD=$4
   [ -f "$ROOT/bloomscene_amd/$lib" ] || { echo "skip $name: $lib missing"; continue; }
   LIBARG="--lib $ROOT/bloomscene_amd/$lib"
   d=$ROOT/$OUT/$name; mkdir -p "$d"
-  ( cd "$ROOT" && python bench.py $LIBARG --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$d/bench.json" )
+  ( cd "$ROOT" && python bench.py $LIBARG --config $CONFIG --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$d/bench.json" )
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "grbm GRBM_GUI_ACTIVE"; do
     set -- $pass; pn=$1; shift
-    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" $LIBARG --config c5 --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-c4 > "$d/$pn.log" 2>&1 )
+    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" $LIBARG --config $CONFIG --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-c4 > "$d/$pn.log" 2>&1 )
   done
   python "$ROOT/tools/pmc_summary.py" "$d" > "$d/pmc_summary.json"
   find "$d" -name "*.csv" -delete
