@@ -43,10 +43,10 @@ for p in "${POINTS[@]}"; do
   [ -f "$ROOT/bloomscene_amd/$lib" ] || { echo "skip $name: $lib missing"; continue; }
   LIBARG="--lib $ROOT/bloomscene_amd/$lib"
   d=$ROOT/$OUT/$name; mkdir -p "$d"
-  ( cd "$ROOT" && python bench.py $LIBARG --config $CONFIG --steps 10 --warmup 3 --no-cpu-baseline --no-c4 2>/dev/null | tail -1 > "$d/bench.json" )
+  ( cd "$ROOT" && python bench.py $LIBARG --config $CONFIG --steps 10 --warmup 3 --no-cpu-baseline --no-c4 --no-secondary 2>/dev/null | tail -1 > "$d/bench.json" )
   for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "grbm GRBM_GUI_ACTIVE"; do
     set -- $pass; pn=$1; shift
-    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" $LIBARG --config $CONFIG --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-c4 > "$d/$pn.log" 2>&1 )
+    ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$d/$pn" -- python3 "$ROOT/bench.py" $LIBARG --config $CONFIG --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline --no-c4 --no-secondary > "$d/$pn.log" 2>&1 )
   done
   python "$ROOT/tools/pmc_summary.py" "$d" > "$d/pmc_summary.json"
   find "$d" -name "*.csv" -delete
