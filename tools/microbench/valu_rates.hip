@@ -62,6 +62,32 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, in
 			                  "v_mul_f32 %4, %4, %9\n s_add_u32 %8, %8, %10\n v_mul_f32 %5, %5, %9\n s_add_u32 %8, %8, %10\n v_mul_f32 %6, %6, %9\n s_add_u32 %8, %8, %10\n v_mul_f32 %7, %7, %9\n s_add_u32 %8, %8, %10\n")
 			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0) : "v"(b), "s"(s1) : "scc");
 			mask ^= s0;
+		} else if (KIND >= 9 && KIND <= 12) {   // v_fma_f32 under a partial EXEC mask: does a half (quarter) with no live lane cost a pass?
+			const unsigned long long em = KIND == 9 ? 0x00000000ffffffffull : KIND == 10 ? 0x0000ffff0000ffffull
+			                              : KIND == 11 ? 0x000000000000ffffull : 0x0000000100000001ull;
+			unsigned long long save;
+			asm volatile("s_mov_b64 %8, exec\n s_mov_b64 exec, %11\n"
+			             REP8("v_fma_f32 %0, %0, %9, %10\n v_fma_f32 %1, %1, %9, %10\n v_fma_f32 %2, %2, %9, %10\n v_fma_f32 %3, %3, %9, %10\n"
+			                  "v_fma_f32 %4, %4, %9, %10\n v_fma_f32 %5, %5, %9, %10\n v_fma_f32 %6, %6, %9, %10\n v_fma_f32 %7, %7, %9, %10\n")
+			             "s_mov_b64 exec, %8\n"
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(save) : "v"(b), "v"(c), "s"(em));
+		} else if (KIND == 13) {   // v_exp_f32
+			asm volatile(REP8("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n")
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+		} else if (KIND == 14) {   // v_fma_f32 with one SGPR operand (the scalar-record walk's form)
+			asm volatile(REP8("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+			                  "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n")
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b), "v"(c));
+		} else if (KIND == 15) {   // compare into VCC (VOPC e32) + select on VCC (VOP2 e32)
+			asm volatile(REP8("v_cmp_lt_f32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %0, %1, %8, vcc\n v_cmp_lt_f32_e32 vcc, %2, %8\n v_cndmask_b32_e32 %2, %3, %8, vcc\n"
+			                  "v_cmp_lt_f32_e32 vcc, %4, %8\n v_cndmask_b32_e32 %4, %5, %8, vcc\n v_cmp_lt_f32_e32 vcc, %6, %8\n v_cndmask_b32_e32 %6, %7, %8, vcc\n")
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");
+		} else if (KIND == 16) {   // v_readlane_b32 with an SGPR lane select
+			unsigned s0 = 0, s1 = 5;
+			asm volatile(REP8("v_readlane_b32 %8, %0, %9\n v_readlane_b32 %8, %1, %9\n v_readlane_b32 %8, %2, %9\n v_readlane_b32 %8, %3, %9\n"
+			                  "v_readlane_b32 %8, %4, %9\n v_readlane_b32 %8, %5, %9\n v_readlane_b32 %8, %6, %9\n v_readlane_b32 %8, %7, %9\n")
+			             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0) : "s"(s1));
+			mask ^= s0;
 		}
 	}
 	const unsigned long long t1 = __builtin_readcyclecounter();
@@ -106,6 +132,14 @@ int main()
 		run<5>("v_rcp_f32", w, 64);
 		run<6>("v_ldexp_f32", w, 64);
 		run<8>("v_mul_f32 + s_add_u32 1:1", w, 64);
+		run<9>("v_fma_f32 exec = low half", w, 64);
+		run<10>("v_fma_f32 exec = 16 of each half", w, 64);
+		run<11>("v_fma_f32 exec = lanes 0-15", w, 64);
+		run<12>("v_fma_f32 exec = lanes 0 and 32", w, 64);
+		run<13>("v_exp_f32", w, 64);
+		run<14>("v_fma_f32 (SGPR operand)", w, 64);
+		run<15>("v_cmp -> vcc + v_cndmask vcc", w, 64);
+		run<16>("v_readlane_b32 (SGPR lane)", w, 64);
 	}
 	return 0;
 }
