@@ -35,8 +35,16 @@ __device__ unsigned long long g_fwd_times[4 * 70000];
 
 // View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
 // row tyv belongs to view tyv / gy; pixel coordinates, image outputs and the per-pixel state are per view.
+#ifndef BSR_FWD_BATCH
+#define BSR_FWD_BATCH BSR_BLOCK   // entries staged per batch (A/B hook)
+#endif
+#ifdef BSR_FWD_WAVES              // A/B hook: occupancy target handed to the register allocator
+#define BSR_FWD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(BSR_FWD_WAVES, BSR_FWD_WAVES)))
+#else
+#define BSR_FWD_WAVES_ATTR
+#endif
 template <int NS, int FB, bool EXACT>
-__global__ void __launch_bounds__(BSR_BLOCK) k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
+__global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ point_list,
@@ -336,7 +344,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_FWD");
 	const bool split = (long long)capacity >= 48ll * n_tiles;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
-	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_BLOCK, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
+	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_FWD_BATCH, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
 	                   n_ptr, capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth)
 	if (split && exact) BSR_LAUNCH_FWD(2, true);
 	else if (split) BSR_LAUNCH_FWD(2, false);
