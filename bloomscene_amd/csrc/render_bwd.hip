@@ -668,6 +668,19 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 // ~75 instructions per 8 visits.  Sums are still formed in a fixed order (bit-reproducible); no atomics.
 // LDS: 64-entry batches (the partial-sum slots shrink with the batch) + 4 x 4.1 KB of transposition buffers = 30.6 KB
 // per workgroup, 5 workgroups per CU.
+//
+// NS = 2 (the default instantiation; round 4, second half): one list per 8 x 4 HALF of the quadrant instead of one per
+// quadrant, as in the forward walk (tile_common.h).  A third of the quadrant visits touch one half only; with a list per
+// half the wave's two halves walk different entries side by side and the wave needs max(upper, lower) visits instead of
+// their union: 12-15 % fewer phase-1 visits and phase-2 chunks.  What round 2 could not afford in the per-visit network
+// walk (the two halves' sums of one entry had to meet in LDS on EVERY visit) costs little here: a slot of the
+// transposition buffer simply holds two entries (rows 0-3 | rows 4-7), phase 2 sums over the quad instead of the
+// 8-lane group (18 DPP adds instead of 19) and ADDS the quad's totals to the entry's partial sums -- upper halves
+// first, lower halves behind them, plain read-add-write (see reduce_chunk).  A/B on one box: render_bwd -4..-5 % at
+// C3, -4 % at 2 M Gaussians, -5 % with scales x 0.6 and with cycling cameras, -2 % at 300 k and scales x 1.5, +1 % at
+// scales x 2 (profiles/r04_v3/ab_bwd_split_lists_*.txt); with plain stores in place of the adds (wrong sums) -10.6 %:
+// the two-pass accumulation is what is left on the table.  The depth-gradient instantiation (ten sums per entry) keeps
+// NS = 1: with split lists it spills and loses 8 %.
 #ifndef BSR_BWT_BATCH
 #define BSR_BWT_BATCH 64
 #endif
@@ -688,9 +701,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 // 4 e dwords (16 bytes): slot stride 528 B makes every group hit 64 distinct banks (MI355X_MICROARCH.md "LDS").
 #define BSR_BWT_SLOT 528
 #define BSR_BWT_ROW (BSR_BWT_BATCH + 1)
-template <int NV>
+// NS = lists per quadrant: 1, or 2 = one per 8 x 4 half -- the wave's two halves then walk DIFFERENT entries side by side
+// (see the kernel's header)
+template <int NV, int NS>
 struct BwtShared {
-	TileStageS<BSR_BWT_BATCH, 1, unsigned int, BSR_BWT_PAD> st;   // one list per quadrant, sentinel-padded to whole trips
+	TileStageS<BSR_BWT_BATCH, NS, unsigned int, BSR_BWT_PAD> st;   // per-quadrant (per-half) lists, sentinel-padded to whole blocks
 	float part[4][NV][BSR_BWT_ROW];   // per-wave partial sums of the current batch (plain stores); column BATCH = the sentinel's
 	uint32_t max_contrib[4];
 	alignas(16) char tbuf[4][BSR_BWT_CHUNK * BSR_BWT_SLOT];   // per wave: [slot][row][col] x (gd, aT)
@@ -756,7 +771,34 @@ __device__ __forceinline__ void row8_sums(float& x0, float& x1, float& x2, float
 	}
 }
 
-template <bool DEPTH>
+// NS = 2: the 8 lanes of a slot hold TWO entries (rows 0-3 | rows 4-7): the sums stop at the quad.  On return every
+// lane holds the totals of its quad (its half of the slot) in all nine (ten) registers.  18 (20) instructions.
+template <bool TEN>
+__device__ __forceinline__ void row4_sums(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6,
+                                          float& x7, float& x8, float& x9)
+{
+#define BSR_QSTEP(P)                                                                   \
+	"v_add_f32_dpp %0, %0, %0 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %1, %1, %1 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %2, %2, %2 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %3, %3, %3 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %4, %4, %4 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %5, %5, %5 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %6, %6, %6 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %7, %7, %7 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"           \
+	"v_add_f32_dpp %8, %8, %8 quad_perm:" P " row_mask:0xf bank_mask:0xf\n"
+	if (TEN) {
+		asm volatile("s_nop 1\n" BSR_QSTEP("[2,3,0,1]") "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+		             BSR_QSTEP("[1,0,3,2]") "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+		             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9));
+	} else {
+		asm volatile("s_nop 1\n" BSR_QSTEP("[2,3,0,1]") BSR_QSTEP("[1,0,3,2]")
+		             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(x8), "+v"(x9));
+	}
+#undef BSR_QSTEP
+}
+
+template <bool DEPTH, int NS>
 // Occupancy target handed to the register allocator.  The kernel's LDS allows 5 workgroups per CU = 5 waves per SIMD = 96
 // VGPRs; left alone the allocator takes 113 (4 waves).  A/B on one box: 5 waves -7.5 % (the walk waits on LDS round trips
 // 40-55 % of a wave's cycles: occupancy is what hides them); 6 waves (80 VGPRs, 48-entry batches for the LDS) spills 17-29
@@ -781,7 +823,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	constexpr int NV = DEPTH ? 10 : 9;
 	constexpr int B = BSR_BWT_BATCH;
 	static_assert(B <= 64 && B % 4 == 0, "a wave stages a batch lane by lane");
-	__shared__ BwtShared<NV> sh;
+	__shared__ BwtShared<NV, NS> sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
@@ -851,6 +893,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	const bool lane_stores = (lane & 3) == 0;                            // lanes 0 and 4 of every 8-lane group
 	// part[wave][k0 + m][j]: k0 = 0 for the lanes holding the totals of values 0..3 (0..4), 4 (5) for the others
 	float* const part_k0 = &sh.part[wave][(lane & 4) ? (DEPTH ? 5 : 4) : 0][0];
+	float* const part_q = &sh.part[wave][(lane & 3) == 0 ? 0 : (lane & 3) == 1 ? 3 : (lane & 3) == 2 ? 5 : 7][0];   // NS = 2
 	const char* const rec0 = reinterpret_cast<const char*>(&sh.st.q0[0]);
 	stage_init(sh.st, tid);   // the sentinel record (read behind the staging's barriers)
 
@@ -881,6 +924,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		const bool valid = lane < cnt;      // (every wave; `valid` of the epilogue below: wave 0's)
 		uint32_t my_row = 0;
 		bool hit = false;
+		bool hit_lo = false;   // NS = 2: rows 4-7 of the quadrant (`hit`: rows 0-3)
 		if (valid) {
 			const uint32_t id = point_list[start + (uint32_t)(top - lane)];
 			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
@@ -895,13 +939,34 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			}
 			const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
 			const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
-			hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, tile_x0 + (float)((wave & 1) << 3),
-			                        tile_y0 + (float)((wave >> 1) << 3));
+			const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
+			if (NS == 2) {
+				hit = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
+				hit_lo = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy + 4.0f);
+			} else {
+				hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
+			}
 		}
-		const unsigned long long hits = wave_ballot(hit);
-		const int n_u = __builtin_amdgcn_readfirstlane((int)__popcll(hits));
-		if (hit) sh.st.list[wave][__popcll(hits & ((1ull << lane) - 1ull))] = (unsigned int)(lane << 4);
-		if (lane < BSR_BWT_PAD - 1) sh.st.list[wave][n_u + lane] = (unsigned int)(B << 4);   // pad to whole trips
+		int n_u;   // visits the wave needs for this batch (wave-uniform)
+		if (NS == 2) {
+			// one list per 8 x 4 half: the wave's two halves walk their own lists side by side (a visit then works on two
+			// different entries), both padded with the sentinel to the longer one's length rounded up to whole blocks
+			const unsigned long long hits = wave_ballot(hit), hits_lo = wave_ballot(hit_lo);
+			const int n_hi = __builtin_amdgcn_readfirstlane((int)__popcll(hits));
+			const int n_lo = __builtin_amdgcn_readfirstlane((int)__popcll(hits_lo));
+			n_u = max(n_hi, n_lo);
+			const int n_end = (n_u + (BSR_BWT_PAD - 1)) & ~(BSR_BWT_PAD - 1);
+			const unsigned long long below = (1ull << lane) - 1ull;
+			if (hit) sh.st.list[NS * wave][__popcll(hits & below)] = (unsigned int)(lane << 4);
+			if (hit_lo) sh.st.list[NS * wave + (NS - 1)][__popcll(hits_lo & below)] = (unsigned int)(lane << 4);
+			if (lane < n_end - n_hi) sh.st.list[NS * wave][n_hi + lane] = (unsigned int)(B << 4);
+			if (lane < n_end - n_lo) sh.st.list[NS * wave + (NS - 1)][n_lo + lane] = (unsigned int)(B << 4);
+		} else {
+			const unsigned long long hits = wave_ballot(hit);
+			n_u = __builtin_amdgcn_readfirstlane((int)__popcll(hits));
+			if (hit) sh.st.list[wave][__popcll(hits & ((1ull << lane) - 1ull))] = (unsigned int)(lane << 4);
+			if (lane < BSR_BWT_PAD - 1) sh.st.list[wave][n_u + lane] = (unsigned int)(B << 4);   // pad to whole blocks
+		}
 		__syncthreads();
 #else
 		const bool valid = tid < cnt;
@@ -1019,7 +1084,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		auto reduce_chunk = [&](const int i0, const int n_valid) {
 			// the slot's entry (possibly the sentinel).  Beyond n_valid the list holds whatever earlier batches left there (or
 			// nothing yet): clamped, so that the reads below stay inside the staged records; those lanes store nothing
-			const unsigned int joff = min(sh.st.list[wave][i0 + (lane >> 3)], (unsigned int)(B << 4));
+			// (NS = 2: rows 4-7 of the slot belong to the other list's entry)
+			const unsigned int joff = min(sh.st.list[NS * wave + (NS == 2 ? ((lane >> 2) & 1) : 0)][i0 + (lane >> 3)], (unsigned int)(B << 4));
 			const float2 xy = *reinterpret_cast<const float2*>(rec0 + joff);
 			const float4 A = *reinterpret_cast<const float4*>(tb_load);        // g0 a0 g1 a1
 			const float4 Bv = *reinterpret_cast<const float4*>(tb_load + 16);  // g2 a2 g3 a3
@@ -1049,6 +1115,33 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 				if (DEPTH)
 					v9 = A.y * cwz[0] + A.w * cwz[1] + Bv.y * cwz[2] + Bv.w * cwz[3] + C.y * cwz[4] + C.w * cwz[5] + D.y * cwz[6] + D.w * cwz[7];
 			}
+			if (NS == 2) {
+				// the slot's two halves belong to two entries: sums over the quad only, and the quad's four lanes ADD their
+				// shares of the nine (ten) totals to the entry's partial sums.  An entry that is in both of the wave's lists
+				// gets two contributions, from two slots that may sit in one chunk: the upper halves' lanes read, add and
+				// write first, the lower halves' behind them (a wave's LDS operations are served in order), so no two lanes
+				// of one instruction share an address.  A partial sum is 0 + a (+ b), and a + b = b + a exactly: the order of
+				// the two contributions does not show.  (LDS float atomics instead: the kernel takes 0.85 ms instead of 0.49.)
+				row4_sums<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+				const int q = lane & 3;   // lane q of the quad adds components {0,1,2}, {3,4(,9)}, {5,6}, {7,8}
+				const float wa = q == 0 ? v0 : q == 1 ? v3 : q == 2 ? v5 : v7;
+				const float wb = q == 0 ? v1 : q == 1 ? v4 : q == 2 ? v6 : v8;
+				float* const p = reinterpret_cast<float*>(reinterpret_cast<char*>(part_q) + (joff >> 2));   // part[wave][k_q][j]
+				const bool live = (lane >> 3) < n_valid;   // (a sentinel slot's zeros land in the rows' pad column BATCH)
+#pragma unroll
+				for (int hh = 0; hh < 2; hh++) {
+					if (live && ((lane >> 2) & 1) == hh) {
+						p[0] += wa;
+						p[BSR_BWT_ROW] += wb;
+						if (q == 0) p[2 * BSR_BWT_ROW] += v2;
+						if (DEPTH && q == 1) p[6 * BSR_BWT_ROW] += v9;
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				}
+				return;
+			}
 			row8_sums<DEPTH>(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
 			if (lane_stores && (lane >> 3) < n_valid) {   // (a sentinel slot's zeros land in the rows' pad column BATCH)
 				float* const p = reinterpret_cast<float*>(reinterpret_cast<char*>(part_k0) + (joff >> 2));   // part[wave][k0][j]
@@ -1066,9 +1159,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 #else
 		const int n_pad = (n_u + (BSR_BWT_PAD - 1)) & ~(BSR_BWT_PAD - 1);   // (the row is sentinel-padded to whole trips)
 #endif
+		const unsigned int* const my_list = &sh.st.list[NS * wave + (NS == 2 ? (lane >> 5) : 0)][0];   // NS = 2: rows 0-3 | rows 4-7 of the quadrant
 		for (int i = 0; i < n_pad; i += BSR_BWT_CHUNK) {
-			const uint4 la = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i]);
-			const uint4 lb = *reinterpret_cast<const uint4*>(&sh.st.list[wave][i + 4]);   // (past the padding: inside the struct, not used)
+			const uint4 la = *reinterpret_cast<const uint4*>(my_list + i);
+			const uint4 lb = *reinterpret_cast<const uint4*>(my_list + i + 4);   // (past the padding: inside the struct, not used)
 			trip(la, 0, i + 2 < n_pad);
 			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4, i + 6 < n_pad);
 #ifdef BSR_BWT_KO_PHASE2   // knock-out build (timing only): phase 1 without the transposed reduction
@@ -1143,8 +1237,8 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	hipLaunchKernelGGL((k_render_bwd<D_, S_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, slab)
-#define BSR_LAUNCH_BWT(D_)                                                                                              \
-	hipLaunchKernelGGL((k_render_bwd_t<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
+#define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
+	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, slab)
 	// Default: the transposed-reduction walk.  BSR_FLAG_EXACT_GRAD (and the attribution / diagnostic builds, which are
@@ -1169,9 +1263,9 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 		else if (strict) BSR_LAUNCH_BWD(false, true);
 		else BSR_LAUNCH_BWD(false, false);
 	} else if (depth) {
-		BSR_LAUNCH_BWT(true);
+		BSR_LAUNCH_BWT(true, 1);    // (ten sums per entry: with split lists the kernel spills and loses 8 %)
 	} else {
-		BSR_LAUNCH_BWT(false);
+		BSR_LAUNCH_BWT(false, 2);
 	}
 #undef BSR_LAUNCH_BWT
 #undef BSR_LAUNCH_BWD

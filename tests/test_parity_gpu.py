@@ -293,11 +293,13 @@ def test_depth_gradient_extension(name):
     assert Hh.max_err_over_scale(base.grads.means3D, g_ref.dL_dmeans3D) < 1e-5
     assert Hh.max_err_over_scale(out.grads.means3D, g_ref.dL_dmeans3D) > 1e-3
     assert Hh.max_err_over_scale(out.grads.opacities, g_ref.dL_dopacity) > 1e-3
-    # colour gradients do not depend on the depth loss at all
+    # colour gradients do not depend on the depth loss at all.  (To rounding: the depth-gradient instantiation of the
+    # backward walk keeps one list per quadrant while the default one splits them per 8 x 4 half, so the same pixel
+    # terms are added in another order.)
     if c.shs is not None:
-        np.testing.assert_array_equal(out.grads.shs, base.grads.shs)
+        assert Hh.max_err_over_scale(out.grads.shs, base.grads.shs) < 2e-6
     else:
-        np.testing.assert_array_equal(out.grads.colors_precomp, base.grads.colors_precomp)
+        assert Hh.max_err_over_scale(out.grads.colors_precomp, base.grads.colors_precomp) < 2e-6
 
 
 def test_every_size_class_of_the_tile_sort_is_covered():
