@@ -1,5 +1,5 @@
 set -u
-TAG=r04_v2
+TAG=${TAG:-r04_v3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
