@@ -690,10 +690,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
                         // 1 % faster than 4 and needs no spill; at 4 waves per SIMD the block of 4 was worth 8 %
 #endif
 #ifndef BSR_BWT_PAD
-#define BSR_BWT_PAD 2   // the lists are sentinel-padded to whole BLOCKS of two entries (a trip = two blocks, a chunk = two trips;
-                        // blocks past the padded end are skipped): A/B on one box against padding to trips of four, 4 rounds:
-                        // render_bwd 0.476 vs 0.486 ms (-2 %; a 64-entry batch gives a wave ~31 entries, so the average 1.5
-                        // sentinel visits of a four-padded list are 5 % of its visits)
+#define BSR_BWT_PAD 4   // the lists are sentinel-padded to whole TRIPS of four; a chunk is one or two trips.  (Padding to
+                        // blocks of two, the second block of a trip skipped past the end: -2 % in one four-round A/B, +6 % on
+                        // six other boxes -- the branch between a trip's blocks costs more than the sentinel visits; docs/EXPERIMENTS.md)
 #endif
 // A slot = 8 pixel rows x 64 B.  Phase-1 store: ds_write_b64 is served in groups of 16 consecutive lanes = 2 rows = 32
 // consecutive dwords: conflict-free.  Phase-2 read: ds_read_b128 is served in four groups of 16 lanes that mix slots
@@ -1069,14 +1068,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 #pragma unroll
 			for (int k = 0; k < NE; k++) chain(e[k], g[k], a[k], slot0 + k);
 		};
-		auto trip = [&](const uint4 l, const int slot0, const bool second) {
+		auto trip = [&](const uint4 l, const int slot0) {
 #if BSR_BWT_ILP == 4
 			const unsigned int q[4] = {l.x, l.y, l.z, l.w};
 			block(q, slot0);
 #else
 			const unsigned int q0[2] = {l.x, l.y}, q1[2] = {l.z, l.w};
 			block(q0, slot0);
-			if (BSR_BWT_PAD >= 4 || second) block(q1, slot0 + 2);   // (lists padded to pairs: the trip's second block may be past the end)
+			block(q1, slot0 + 2);
 #endif
 		};
 
@@ -1163,8 +1162,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		for (int i = 0; i < n_pad; i += BSR_BWT_CHUNK) {
 			const uint4 la = *reinterpret_cast<const uint4*>(my_list + i);
 			const uint4 lb = *reinterpret_cast<const uint4*>(my_list + i + 4);   // (past the padding: inside the struct, not used)
-			trip(la, 0, i + 2 < n_pad);
-			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4, i + 6 < n_pad);
+			trip(la, 0);
+			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4);
 #ifdef BSR_BWT_KO_PHASE2   // knock-out build (timing only): phase 1 without the transposed reduction
 			continue;
 #endif
@@ -1237,6 +1236,9 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	hipLaunchKernelGGL((k_render_bwd<D_, S_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, slab)
+#ifndef BSR_BWT_DEFAULT_NS
+#define BSR_BWT_DEFAULT_NS 2   // lists per quadrant of the default instantiation (A/B hook: make variant DEFS=-DBSR_BWT_DEFAULT_NS=1)
+#endif
 #define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
 	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
@@ -1265,7 +1267,7 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	} else if (depth) {
 		BSR_LAUNCH_BWT(true, 1);    // (ten sums per entry: with split lists the kernel spills and loses 8 %)
 	} else {
-		BSR_LAUNCH_BWT(false, 2);
+		BSR_LAUNCH_BWT(false, BSR_BWT_DEFAULT_NS);
 	}
 #undef BSR_LAUNCH_BWT
 #undef BSR_LAUNCH_BWD
