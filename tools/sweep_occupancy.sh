@@ -8,16 +8,16 @@
 # usage (GPU box, repo root): bash tools/sweep_occupancy.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/sweep_occ}
-CONFIG=${2:-c5}      # c5 (BASELINE's sweep: the network walk) or c3 (the transposed walk, 30.5 KB LDS: pads 10500 / 24100 / 51400 -> 4 / 3 / 2 workgroups per CU)
+CONFIG=${2:-c5}      # c5 (BASELINE's sweep: the network walk) or c3 (the transposed walk with split lists, 31.0 KB LDS: pads 5000 / 16000 / 36000 -> 4 / 3 / 2 workgroups per CU)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # name lib pad_fwd pad_bwd
 if [ "$CONFIG" = c3 ]; then
 POINTS=(
  "native            libbsr_rast_sweep.so  0     0"
- "bwd_wg4           libbsr_rast_sweep.so  0     10500"
- "bwd_wg3           libbsr_rast_sweep.so  0     24100"
- "bwd_wg2           libbsr_rast_sweep.so  0     51400"
+ "bwd_wg4           libbsr_rast_sweep.so  0     5000"
+ "bwd_wg3           libbsr_rast_sweep.so  0     16000"
+ "bwd_wg2           libbsr_rast_sweep.so  0     36000"
  "fwd_wg6           libbsr_rast_sweep.so  6500  0"
  "fwd_wg4           libbsr_rast_sweep.so  20100 0"
  "fwd_wg2           libbsr_rast_sweep.so  61000 0"
