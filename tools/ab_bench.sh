@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B builds of the library on ONE GPU box (boxes differ by +-4 %): tools/ab_bench.sh [-r ROUNDS] [-a "bench args"] libA.so libB.so ...
 # Interleaved runs; prints the bench JSON's value / ms_per_step / stage_ms per run.
+# One call = one box.  Boxes differ by +-4 % and can disagree on the SIGN of a 2 % effect (docs/EXPERIMENTS.md, round 4:
+# pair-padded lists won on one box and lost on six): confirm a small difference on two or more boxes before adopting it.
 ROUNDS=3; ARGS=""
 while getopts "r:a:" o; do case $o in r) ROUNDS=$OPTARG;; a) ARGS=$OPTARG;; esac; done
 shift $((OPTIND-1))
