@@ -263,6 +263,13 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
             prof[dominant] = prof_timed[dominant]   # the dominant stage: as measured inside the timed region
     return {"seconds": D.max_over_ranks(dt), "median_ms": per_step[len(per_step) // 2], "prof": prof,
             "step_ms": [round(x, 4) for x in in_order] if steps <= 64 else None,
+            "host_step_ms": [round(x, 4) for x in host_step_ms] if steps <= 64 else None,
+            "step_ms_first": in_order[0], "step_ms_max": per_step[-1],
+            "steps_over_1p15x_median": sum(1 for x in in_order if x > 1.15 * per_step[len(per_step) // 2]),
+            "host_median_ms": sorted(host_step_ms)[len(host_step_ms) // 2],
+            # time from the fence to the first timed kernel reaching the GPU is inside step_ms[0]; the tail between the last
+            # step's event and the closing fence: seconds - sum(step_ms)
+            "tail_ms": dt * 1e3 - sum(in_order),
             "device_allocs": int(device_allocs), "max_host_ms": max(host_step_ms), "prewarm_steps": prewarm_steps,
             "timed_region_events": {"stage": dominant, "every_nth_step": sample_every,
                                     "launches": prof_timed.get(dominant, (0.0, 0))[1] if dominant else None}}
@@ -350,7 +357,9 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
            "prof": tm["prof"], "R": R, "visible": visible, "step_bytes": sb, "bcast_ms": bcast_ms, "M": M, "deg": deg,
            "device_allocs": tm["device_allocs"], "max_host_ms": tm["max_host_ms"],
            "timed_region_events": tm["timed_region_events"], "prewarm_steps": tm["prewarm_steps"],
-           "step_ms": tm["step_ms"],
+           "step_ms": tm["step_ms"], "host_step_ms": tm["host_step_ms"], "step_ms_first": tm["step_ms_first"],
+           "step_ms_max": tm["step_ms_max"], "steps_over_1p15x_median": tm["steps_over_1p15x_median"],
+           "host_median_ms": tm["host_median_ms"], "tail_ms": tm["tail_ms"],
            "allreduce_ms_per_step": state.get("allreduce_ms", 0.0) / max(steps + warmup, 1),
            "workload": f"{label}: {P} Gaussians, {'precomputed colours' if precomp else f'SH deg {deg}'}, {W}x{H}, "
                        f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
@@ -684,6 +693,11 @@ def main():
                         # issued per SIMD and core-clock cycle
                         "valu_insts_per_simd_cycle": valu}
         whole = r["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9
+        src = (roofline or {}).get("traffic_source") or {}
+        # roofline.traffic is a CONSTANT read from a committed rocprofv3 --pmc profile of the same kernel sources, never
+        # a measurement of this run (counters cannot be collected inside it)
+        traffic_kind = (f"committed:{src.get('profile')}" if src.get("matches_timed_build") else
+                        "none (committed profile is of other kernel sources)" if src else "none")
         out = {
             "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if headline
             else f"Msplats/s ({args.config})",
@@ -696,7 +710,21 @@ def main():
                        "parallelism": f"view-parallel x{D.world}" + (" + gradient all-reduce" if args.allreduce_grads
                                                                       and D.multi and do_bwd else ""),
                        "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256(),
-                       "exact_exp": int(args.exact_exp), "strict_gradients": int(args.strict_gradients)},
+                       "exact_exp": int(args.exact_exp), "strict_gradients": int(args.strict_gradients),
+                       # ---- diagnostics of the timed region, flat, so that a record that keeps `config` whole can say
+                       # whether a slow headline was one outlier, a host-bound loop or a uniformly slow leg:
+                       # per-step GPU time (event to event) and per-step HOST time (enqueue loop), in order
+                       "ms_per_step_median": round(r["ms_per_step_median"], 4),
+                       "step_ms_first": round(r["step_ms_first"], 4), "step_ms_max": round(r["step_ms_max"], 4),
+                       "steps_over_1p15x_median": r["steps_over_1p15x_median"],
+                       "host_max_ms_per_step": round(r["max_host_ms"], 3),
+                       "host_median_ms_per_step": round(r["host_median_ms"], 3),
+                       "closing_fence_tail_ms": round(r["tail_ms"], 4),
+                       "device_allocs_in_timed_region": r["device_allocs"],
+                       "sum_stage_ms": round(sum(stages.values()), 4),
+                       "prewarm_steps": r["prewarm_steps"], "prewarm_ms": args.prewarm_ms,
+                       "step_ms": r["step_ms"], "host_step_ms": r["host_step_ms"],
+                       "traffic_kind": traffic_kind},
             "ms_per_step_median": round(r["ms_per_step_median"], 4),
             # every timed step on the GPU's clock (event to event), in order, when there are few enough to list
             "step_ms": r["step_ms"],
