@@ -171,24 +171,26 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
-                       const uint32_t* point_list,
+                       uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, bool exact_exp, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, bool strict, int num_rendered, hipStream_t s);
+                       const int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- options (bsr_set_option)
 // Numerics are per call (the `flags` of bsr_forward_ex / bsr_backward_ex); the one process-wide switch left is a test
 // hook that changes no result.
 static std::atomic<int> g_opt_sort_force_int{0};
+static std::atomic<int> g_opt_no_half_masks{0};   // the forward keeps its per-half box tests to itself: the backward tests again
 int opt_sort_force_int() { return g_opt_sort_force_int.load(std::memory_order_relaxed); }
 static std::atomic<int>* find_option(const char* name)
 {
 	if (!name) return nullptr;
 	if (!strcmp(name, "sort_force_int")) return &g_opt_sort_force_int;
+	if (!strcmp(name, "no_half_masks")) return &g_opt_no_half_masks;
 	return nullptr;
 }
 
@@ -445,7 +447,11 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		STAGE_CHECK("sort_tiles", debug, s);
 		{
 			StageTimer t("render_fwd", s);
-			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, geom.rec,
+			// one view of at most 2^24 Gaussians: the forward's split-list staging hands its per-half box tests to the
+			// backward in the top byte of the point_list words (flags[6] says whether it did)
+			int* const masks_flag = (V == 1 && P <= (1 << 24) && !g_opt_no_half_masks.load(std::memory_order_relaxed))
+			                            ? img.flags + 6 : nullptr;
+			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, masks_flag, geom.rec,
 			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
 			                  (flags & BSR_FLAG_EXACT_EXP) != 0, s);
 		}
@@ -829,7 +835,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 		{
 			StageTimer t("render_bwd", s);
 			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
-			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, slab,
+			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, img.flags + 6, slab,
 			                  (flags & BSR_FLAG_EXACT_GRAD) != 0, R, s);
 		}
 		STAGE_CHECK("render_bwd", debug, s);

@@ -66,7 +66,8 @@ __device__ __forceinline__ void store_elem(BinElem* p, const BinElem e)
 }
 #define BSR_HIST_BLOCKS_MAX 2048
 struct BinState {
-	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this)
+	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this); once
+	                      //     k_render_fwd has staged an entry (one view, ids < 2^24, split lists): id | half mask << 24
 	BinElem* elems_a;     // [R] (tile id, gaussian id, depth bits): ping-pong buffers of the radix passes
 	BinElem* elems_b;       // [R]
 	float4* slab;         // [R][9 or 10 floats, tight] the backward's per-instance partial sums (k_render_bwd -> k_preprocess_bwd): the SAME
@@ -80,7 +81,8 @@ struct ImgState {
 	uint32_t* n_contrib;   // [N]
 	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
 	int* flags;            // [8]: prefiltered violation | #tiles (1024, 4096] | kept instances | rect tiles (= reference
-	                       //      num_rendered) | #tiles (4096, 8192] | #tiles > 8192 | - | -
+	                       //      num_rendered) | #tiles (4096, 8192] | #tiles > 8192 | point_list words carry the forward's
+	                       //      per-half box tests in their top byte (k_render_fwd -> k_render_bwd*) | -
 	uint32_t* big_tiles;   // [3][T] tiles with more than 1024 instances, one list per size class (any order):
 	                       //        work lists of the wide sort kernels
 	static size_t bytes(size_t N, size_t T);

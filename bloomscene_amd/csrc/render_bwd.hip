@@ -25,17 +25,6 @@
 
 namespace bsr {
 
-// ---- diagnostic build only (make stats -> libbsr_rast_stats.so, read by tools/walk_stats.py): per-wave counters of the
-// walk (visits, votes passed, live lanes) and a per-workgroup timeline.  No stamp or counter exists in the product build.
-#ifdef BSR_WALK_STATS
-#define BSR_NSTAT 24
-__device__ unsigned long long g_walk_stats[BSR_NSTAT];
-__device__ unsigned long long g_wg_times[4 * 70000];   // per workgroup: start, end (s_memrealtime, 100 MHz), XCC id, tile
-#define STAT_ADD(i, v) (wstat[i] += (unsigned long long)(v))
-#else
-#define STAT_ADD(i, v) ((void)0)
-#endif
-
 // ---- halving reduction of 9 (10) values over the 64 lanes: lane-masked DPP writes ------------
 // Nine independent 6-step reductions would be 54 cross-lane adds.  Instead the values are split
 // between partner lanes at every step, halving the live set; a first version selected the kept value
@@ -152,48 +141,18 @@ __device__ __forceinline__ uint32_t instance_index(const uint32_t* __restrict__ 
 	return off + kept_rank(w * h, mask, k);
 }
 
-// Arithmetic shortcuts of the walk, each with a switch.  STRICT (BSR_FLAG_EXACT_GRAD of bsr_backward_ex) turns all five
-// off: the reference's per-pair operations on the reference's operands (backward.cu:521,527-536,557,561-583), IEEE
-// divisions, no fp contraction, the pinned exp on every pair, accum_rec per channel -- only the ORDER of the sums then
-// differs from the oracle's.  The attribution builds (make attrib, tools/attribute_gradient_error.py) switch one off at a
-// time through the macros.
-#ifdef BSR_BWD_EXACT_EXP
-#define BSR_A_EXP true
-#else
-#define BSR_A_EXP false
-#endif
-#ifdef BSR_BWD_IEEE_DIV
-#define BSR_A_DIV true
-#else
-#define BSR_A_DIV false
-#endif
-#ifdef BSR_BWD_NO_CONTRACT
-#define BSR_A_NOCONTRACT true
-#else
-#define BSR_A_NOCONTRACT false
-#endif
-#ifdef BSR_BWD_PAIR_PRODUCTS
-#define BSR_A_PAIRS true
-#else
-#define BSR_A_PAIRS false
-#endif
-#ifdef BSR_BWD_CHANNEL_ACCUM
-#define BSR_A_CHAN true
-#else
-#define BSR_A_CHAN false
-#endif
-
-#ifndef BSR_BWD_BATCH
-#define BSR_BWD_BATCH 128   // entries staged per batch (occupancy sweep: make batch BATCH=64|256, tools/sweep_occupancy.sh)
-#endif
-#ifndef BSR_BWD_PAD
-#define BSR_BWD_PAD 1
-#endif
+// ---- k_render_bwd_strict: BSR_FLAG_EXACT_GRAD ----------------------------------------------------------------------
+// The reference's per-pair operations on the reference's operands (backward.cu:521,527-536,557,561-583): IEEE
+// divisions, no fp contraction, the pinned exp on every pair, accum_rec channel by channel, the per-pair terms summed as
+// they are -- only the ORDER of the nine sums then differs from the oracle's.  The nine values of a visit are summed over
+// the wave by the masked DPP network above and filed per wave; 128-entry batches staged by waves 0 and 1
+// (stage_and_compact).  Until round 4 this walk (with the arithmetic shortcuts of k_render_bwd_t switched on one by one
+// through attribution builds: docs/EXPERIMENTS.md) was also the default; ~2x the time of k_render_bwd_t.
+#define BSR_BWD_BATCH 128
 // Row stride of the per-wave partial sums: the 9 (10) storing lanes of one entry write part[wave][k][j] for
 // k = 0..NV-1 with ONE ds_write_b32 (bank = dword address mod 32, lanes of a 32-lane half conflict).  With rows of
-// 128 floats all of them hit one bank (up to 9-way: SQ_LDS_BANK_CONFLICT was 21 % of the kernel's LDS cycles);
-// 129 puts component k on bank (k + j) mod 32.
-#define BSR_BWD_ROW (BSR_BWD_BATCH + BSR_BWD_PAD)
+// 128 floats all of them hit one bank; 129 puts component k on bank (k + j) mod 32.
+#define BSR_BWD_ROW (BSR_BWD_BATCH + 1)
 template <int NV>
 struct BwdShared {
 	TileStageT<BSR_BWD_BATCH> st;
@@ -201,162 +160,99 @@ struct BwdShared {
 	uint32_t max_contrib[4];
 };
 
-// ---- per-pair arithmetic of the walk -------------------------------------------------------------------------------
 // State a pixel carries along the list (back to front) and the constants of the pixel.
-template <bool DEPTH, bool CHAN>
 struct PairState {
 	float T;
-	float Srec;                 // fast form: sum_ch accum_rec[ch] * dL_dpixel[ch] (+ the depth channel in the extension)
-	float acc_rec[CHAN ? 4 : 1], last_color[CHAN ? 4 : 1], last_alpha;   // CHAN: reference :527-536 channel by channel ([3] = depth)
+	float acc_rec[4], last_color[4], last_alpha;   // reference :527-536 channel by channel ([3] = depth, extension)
 };
 struct PixelConst {
 	float dpx0, dpx1, dpx2, neg_Tfinal_bg, gz, g1, ddelx_dx, ddely_dy;
 };
-// Gradients are compared with a tolerance, not bitwise (the reference's own sums are unordered), so the default form
-// fuses multiply-adds (BSR_PAIR_TERMS is instantiated once under `#pragma clang fp contract(fast)` and once without) and
-// uses a refined reciprocal instead of the reference's two IEEE divisions (:521,:557).
-//   DIV    the reference's IEEE divisions                       PAIRS  the reference's per-pair terms (:561-580) instead of moments
-//   CHAN   accum_rec channel by channel (:527-536)
-// Per pair the reference adds (:574-583), with gd = G * dL_dalpha and w = o * gd:
-//   dL_dmean2D.x += -w * ddelx_dx * (a dx + b dy)      dL_dconic.x += -0.5 w dx dx
-//   dL_dmean2D.y += -w * ddely_dy * (c dy + b dx)      dL_dconic.y += -0.5 w dx dy
-//   dL_dopacity  += gd                                  dL_dconic.w += -0.5 w dy dy
-// o, a, b, c and the two scale factors are constants of the ENTRY, so the default form sums only the six moments of gd
-// over the pixels (1, dx, dy, dx dx, dx dy, dy dy); the entry's row is assembled from the four quadrants' moments once,
-// when it is written (5 multiplies per pair instead of 13).
-#define BSR_PAIR_TERMS                                                                                                      \
-	const float om = 1.f - alpha;                                                                                           \
-	float inv;                                                                                                              \
-	if constexpr (DIV) {                                                                                                    \
-		inv = 1.0f / om;                                                                                                    \
-		st.T = st.T / om; /* reference :521 */                                                                              \
-	} else {                                                                                                                \
-		inv = __builtin_amdgcn_rcpf(om); /* 1 ulp */                                                                        \
-		/* T/(1-alpha): quotient estimate + one residual correction (the residual T - om * qT is exact in the fma, so the  \
-		   1-ulp error of inv enters squared) = the correctly rounded quotient in all but rare cases: the T chain          \
-		   (hundreds of steps in dense tiles) does not drift.  (plain T * inv: -2 % time, +20 % elements off by > 1e-4) */  \
-		const float qT = st.T * inv;                                                                                        \
-		st.T = __builtin_fmaf(__builtin_fmaf(-om, qT, st.T), inv, qT);                                                      \
-	}                                                                                                                       \
-	const float T = st.T;                                                                                                   \
-	float S, Sd = 0.f;                                                                                                      \
-	if constexpr (CHAN) {                                                                                                   \
-		/* accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, then (c - accum_rec) * dL_dpixel.            \
-		   A pair the reference skips must leave (accum_rec, last_color, last_alpha) standing.  The depth extension is     \
-		   the oracle's separate pass (bsro_render_backward_depth): its own recurrence on d_i = gz z_i + g1. */             \
-		const bool live = G != 0.f;                                                                                         \
-		const float c4[4] = {q2.x, q2.y, q2.z, DEPTH ? px.gz * q1.w + px.g1 : 0.f};                                         \
-		const float dp[3] = {px.dpx0, px.dpx1, px.dpx2};                                                                    \
-		S = 0.f;                                                                                                            \
-		_Pragma("unroll") for (int ch = 0; ch < (DEPTH ? 4 : 3); ch++) {                                                    \
-			const float ar = st.last_alpha * st.last_color[ch] + (1.f - st.last_alpha) * st.acc_rec[ch];                    \
-			st.acc_rec[ch] = live ? ar : st.acc_rec[ch];                                                                    \
-			st.last_color[ch] = live ? c4[ch] : st.last_color[ch];                                                          \
-			if (ch < 3) S += (c4[ch] - st.acc_rec[ch]) * dp[ch];                                                            \
-			else Sd = c4[ch] - st.acc_rec[ch];                                                                              \
-		}                                                                                                                   \
-		st.last_alpha = live ? alpha : st.last_alpha;                                                                       \
-	} else {                                                                                                                \
-		/* The reference keeps accum_rec[ch], the colour accumulated behind the entry (:529), and uses it only through     \
-		   sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch].  dL_dpixel is fixed per pixel, so the projection                \
-		   Srec = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the same recurrence Srec' = alpha * u + (1 - alpha) * Srec    \
-		   with u = sum_ch c[ch] * dL_dpixel[ch]: one scalar instead of three channels (the depth extension adds its       \
-		   term d_i to u). */                                                                                               \
-		float u = q2.x * px.dpx0 + q2.y * px.dpx1 + q2.z * px.dpx2;                                                         \
-		if (DEPTH) u += __builtin_fmaf(px.gz, q1.w, px.g1);                                                                 \
-		S = u - st.Srec;                                                                                                    \
-		st.Srec = st.Srec + alpha * S;                                                                                      \
-	}                                                                                                                       \
-	float dL_dalpha = T * S + px.neg_Tfinal_bg * inv;                                                                       \
-	if constexpr (PAIRS) {                                                                                                  \
-		/* the reference's per-pair terms (:561-580), summed as they are; the epilogue passes them through */               \
-		const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x;                                                       \
-		const float gdx = G * dx, gdy = G * dy;                                                                             \
-		const float dG_ddelx = -gdx * ca - gdy * cb;                                                                        \
-		const float dG_ddely = -gdy * cc - gdx * cb;                                                                        \
-		float dL_dG = q1.z * dL_dalpha;                                                                                     \
-		v[0] = dL_dG * dG_ddelx * px.ddelx_dx;                                                                              \
-		v[1] = dL_dG * dG_ddely * px.ddely_dy;                                                                              \
-		v[2] = -0.5f * gdx * dx * dL_dG;                                                                                    \
-		v[3] = -0.5f * gdx * dy * dL_dG;                                                                                    \
-		v[4] = -0.5f * gdy * dy * dL_dG;                                                                                    \
-		v[5] = G * dL_dalpha;                                                                                               \
-		if (DEPTH && CHAN) { /* the oracle's second pass: the same terms for dL_dalpha = T * (d_i - Rd) */                  \
-			const float dLa = T * Sd;                                                                                       \
-			dL_dG = q1.z * dLa;                                                                                             \
-			v[0] += dL_dG * dG_ddelx * px.ddelx_dx;                                                                         \
-			v[1] += dL_dG * dG_ddely * px.ddely_dy;                                                                         \
-			v[2] += -0.5f * gdx * dx * dL_dG;                                                                               \
-			v[3] += -0.5f * gdx * dy * dL_dG;                                                                               \
-			v[4] += -0.5f * gdy * dy * dL_dG;                                                                               \
-			v[5] += G * dLa;                                                                                                \
-		}                                                                                                                   \
-	} else {                                                                                                                \
-		if (DEPTH && CHAN) dL_dalpha += T * Sd;                                                                             \
-		const float gd = G * dL_dalpha;                                                                                     \
-		const float gx = gd * dx, gy = gd * dy;                                                                             \
-		v[0] = gx;                                                                                                          \
-		v[1] = gy;                                                                                                          \
-		v[2] = gx * dx;                                                                                                     \
-		v[3] = gx * dy;                                                                                                     \
-		v[4] = gy * dy;                                                                                                     \
-		v[5] = gd;                                                                                                          \
-	}                                                                                                                       \
-	const float aT = alpha * T;                                                                                             \
-	v[6] = aT * px.dpx0;                                                                                                    \
-	v[7] = aT * px.dpx1;                                                                                                    \
-	v[8] = aT * px.dpx2;                                                                                                    \
+// Per pair the reference adds (:574-583), with dL_dG = o * dL_dalpha:
+//   dL_dmean2D.x += dL_dG * dG_ddelx * ddelx_dx      dL_dconic.x += -0.5 gdx dx dL_dG
+//   dL_dmean2D.y += dL_dG * dG_ddely * ddely_dy      dL_dconic.y += -0.5 gdx dy dL_dG
+//   dL_dopacity  += G * dL_dalpha                    dL_dconic.w += -0.5 gdy dy dL_dG
+// (source order: this translation unit is built with -ffp-contract=off)
+template <bool DEPTH>
+__device__ __forceinline__ void pair_terms_reference(PairState& st, const PixelConst& px, const float4 q0, const float4 q1,
+                                                     const float4 q2, const float dx, const float dy, const float G,
+                                                     const float alpha, float (&v)[10])
+{
+	const float om = 1.f - alpha;
+	const float inv = 1.0f / om;
+	st.T = st.T / om;   // reference :521
+	const float T = st.T;
+	// accum_rec = last_alpha * last_color + (1 - last_alpha) * accum_rec, then (c - accum_rec) * dL_dpixel.  A pair the
+	// reference skips must leave (accum_rec, last_color, last_alpha) standing.  The depth extension is the oracle's
+	// separate pass (bsro_render_backward_depth): its own recurrence on d_i = gz z_i + g1.
+	const bool live = G != 0.f;
+	const float c4[4] = {q2.x, q2.y, q2.z, DEPTH ? px.gz * q1.w + px.g1 : 0.f};
+	const float dp[3] = {px.dpx0, px.dpx1, px.dpx2};
+	float S = 0.f, Sd = 0.f;
+#pragma unroll
+	for (int ch = 0; ch < (DEPTH ? 4 : 3); ch++) {
+		const float ar = st.last_alpha * st.last_color[ch] + (1.f - st.last_alpha) * st.acc_rec[ch];
+		st.acc_rec[ch] = live ? ar : st.acc_rec[ch];
+		st.last_color[ch] = live ? c4[ch] : st.last_color[ch];
+		if (ch < 3) S += (c4[ch] - st.acc_rec[ch]) * dp[ch];
+		else Sd = c4[ch] - st.acc_rec[ch];
+	}
+	st.last_alpha = live ? alpha : st.last_alpha;
+	const float dL_dalpha = T * S + px.neg_Tfinal_bg * inv;
+	const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x;
+	const float gdx = G * dx, gdy = G * dy;
+	const float dG_ddelx = -gdx * ca - gdy * cb;
+	const float dG_ddely = -gdy * cc - gdx * cb;
+	float dL_dG = q1.z * dL_dalpha;
+	v[0] = dL_dG * dG_ddelx * px.ddelx_dx;
+	v[1] = dL_dG * dG_ddely * px.ddely_dy;
+	v[2] = -0.5f * gdx * dx * dL_dG;
+	v[3] = -0.5f * gdx * dy * dL_dG;
+	v[4] = -0.5f * gdy * dy * dL_dG;
+	v[5] = G * dL_dalpha;
+	if (DEPTH) {   // the oracle's second pass: the same terms for dL_dalpha = T * (d_i - Rd)
+		const float dLa = T * Sd;
+		dL_dG = q1.z * dLa;
+		v[0] += dL_dG * dG_ddelx * px.ddelx_dx;
+		v[1] += dL_dG * dG_ddely * px.ddely_dy;
+		v[2] += -0.5f * gdx * dx * dL_dG;
+		v[3] += -0.5f * gdx * dy * dL_dG;
+		v[4] += -0.5f * gdy * dy * dL_dG;
+		v[5] += G * dLa;
+	}
+	const float aT = alpha * T;
+	v[6] = aT * px.dpx0;
+	v[7] = aT * px.dpx1;
+	v[8] = aT * px.dpx2;
 	v[9] = DEPTH ? aT * px.gz : 0.f;
-
-template <bool DEPTH, bool DIV, bool PAIRS, bool CHAN>
-__device__ __forceinline__ void pair_terms_contracted(PairState<DEPTH, CHAN>& st, const PixelConst& px, const float4 q0,
-                                                      const float4 q1, const float4 q2, const float dx, const float dy,
-                                                      const float G, const float alpha, float (&v)[10])
-{
-#pragma clang fp contract(fast)
-	BSR_PAIR_TERMS
 }
-template <bool DEPTH, bool DIV, bool PAIRS, bool CHAN>
-__device__ __forceinline__ void pair_terms_source_order(PairState<DEPTH, CHAN>& st, const PixelConst& px, const float4 q0,
-                                                        const float4 q1, const float4 q2, const float dx, const float dy,
-                                                        const float G, const float alpha, float (&v)[10])
-{
-	BSR_PAIR_TERMS
-}
-#undef BSR_PAIR_TERMS
 
 // DEPTH = false: the reference's backward (dL_depths ignored).  DEPTH = true: the opt-in extension
 // that also differentiates the normalised depth target (math in
 // oracle/bsr_oracle.c:bsro_render_backward_depth): a tenth partial sum dL/dz per instance and one more
 // term in dL/dalpha.  out_depth is the forward's depth image (its zeros are the acc <= 0.5 gate).
-// STRICT (BSR_FLAG_EXACT_GRAD): every arithmetic shortcut off, see the switches above.
-template <bool DEPTH, bool STRICT>
-__global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, int W, int H,
-                                                          const uint32_t* __restrict__ tile_start,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const float4* __restrict__ rec,
-                                                          const uint32_t* __restrict__ wg_base,
-                                                          const float* __restrict__ bg_color,
-                                                          const float* __restrict__ final_Ts,
-                                                          const uint32_t* __restrict__ n_contrib,
-                                                          const float* __restrict__ dL_dpixels,
-                                                          const float* __restrict__ out_depth,   // DEPTH only
-                                                          const float* __restrict__ dL_depths,   // DEPTH only
-                                                          float4* __restrict__ slab)        // [R][9 or 10 floats]
+template <bool DEPTH>
+__global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd_strict(int n_tiles, int gx, int W, int H,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ point_list,
+                                                                 const float4* __restrict__ rec,
+                                                                 const uint32_t* __restrict__ wg_base,
+                                                                 const float* __restrict__ bg_color,
+                                                                 const float* __restrict__ final_Ts,
+                                                                 const uint32_t* __restrict__ n_contrib,
+                                                                 const float* __restrict__ dL_dpixels,
+                                                                 const float* __restrict__ out_depth,   // DEPTH only
+                                                                 const float* __restrict__ dL_depths,   // DEPTH only
+                                                                 const int* __restrict__ masks_flag,    // forward's hand-over word
+                                                                 float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
-	constexpr bool X_EXP = STRICT || BSR_A_EXP, X_DIV = STRICT || BSR_A_DIV, X_NOCONTRACT = STRICT || BSR_A_NOCONTRACT,
-	               X_PAIRS = STRICT || BSR_A_PAIRS, X_CHAN = STRICT || BSR_A_CHAN;
 	__shared__ BwdShared<NV> sh;
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
-#ifdef BSR_WALK_STATS
-	unsigned long long wstat[BSR_NSTAT] = {};
-	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
 	const int tx = tile % gx, ty = tile / gx;
 	const int px = tx * BSR_TILE + ((wave & 1) << 3) + (lane & 7);
 	const int py = ty * BSR_TILE + ((wave >> 1) << 3) + (lane >> 3);
@@ -368,9 +264,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
+	// (the forward may have left its box tests in the top byte of the point_list words: k_render_bwd_t; unused here)
+	const uint32_t id_mask = __builtin_amdgcn_readfirstlane(*masks_flag) != 0 ? 0x00ffffffu : 0xffffffffu;
 
 	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
-	PairState<DEPTH, X_CHAN> pst = {};
+	PairState pst = {};
 	pst.T = T_final;
 	const uint32_t last_contributor = inside ? n_contrib[pix_id] : 0u;
 	PixelConst pc = {};
@@ -416,89 +314,19 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
 		const bool valid = tid < cnt;
 		uint32_t my_row = 0;
-#if defined(BSR_BWD_WAVE_STAGING) && BSR_BWD_BATCH == 128
-		// Round 4 experiment (opt-in: measured +6 % on the dense scene, noise at C5 -- this walk is bound by its vector
-		// instructions at 6 waves per SIMD, not by its staging; docs/EXPERIMENTS.md).  As in k_render_bwd_t: EVERY wave
-		// looks at the batch itself -- lane j at entries j and j + 64, the same
-		// 64-B lines four times, three of them from the L1 / L2 -- and tests them against ITS OWN quadrant: two box tests
-		// per wave instead of four on each of two waves, its list straight from its own two ballots (no count table, one
-		// barrier instead of two).  Waves 0 and 1 also write the records to LDS (entry tid) and keep the rows.
-		// (the trailing barrier of the previous iteration fenced the staging buffers)
-		unsigned long long hits2[2];
-#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int j = lane + 64 * h;
-			bool hit = false;
-			if (j < cnt) {
-				const uint32_t id = point_list[start + (uint32_t)(top - j)];
-				const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
-				const float4 r0 = r[0], r1 = r[1];
-				if (wave == h) {   // this wave's lanes own entries 64 h .. 64 h + 63 = tid
-					float4 r2 = r[2];
-					my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-					r2.w = r1.y + 2.2e-3f;   // staged q2.w (the mask half is used up): just above the decision band, -ln(255 o) + 1.2e-3
-					sh.st.q0[j] = r0;
-					sh.st.q1[j] = r1;
-					sh.st.q2[j] = r2;
-				}
-				const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
-				const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
-				hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, tile_x0 + (float)((wave & 1) << 3),
-				                        tile_y0 + (float)((wave >> 1) << 3));
-			}
-			hits2[h] = wave_ballot(hit);
-			const int before = h == 0 ? 0 : (int)__popcll(hits2[0]);
-			if (hit) sh.st.list[wave][before + (int)__popcll(hits2[h] & ((1ull << lane) - 1ull))] = (unsigned int)(j << 4);
-		}
-		const int n_u = __builtin_amdgcn_readfirstlane((int)(__popcll(hits2[0]) + __popcll(hits2[1])));
-		__syncthreads();
-#else
 		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
 		if (valid) {
 			const uint32_t my_slot = start + (uint32_t)(top - tid);
-			const uint32_t id = point_list[my_slot];
+			const uint32_t id = point_list[my_slot] & id_mask;
 			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
 			r0 = r[0];
 			r1 = r[1];
 			r2 = r[2];
 			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-			r2.w = r1.y + 2.2e-3f;   // staged q2.w (the mask half is used up): just above the decision band, -ln(255 o) + 1.2e-3
 		}
 		// (the trailing barrier of the previous iteration fenced the staging buffers)
 		const int n_mine = stage_and_compact(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
-
 		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
-#endif
-#ifdef BSR_WALK_STATS
-		{
-			// what-if: per-wave lists split into the two 8x4 halves of the quadrant (rows 0-3 / 4-7), or its four 8x2
-			// strips: how many (entry, half / strip) pairs are there, and how long would the longest list of a wave be?
-			// every thread tests its own staged entry against the strips of THIS wave's quadrant
-			int n_half[2] = {0, 0}, n_strip[4] = {0, 0, 0, 0};
-			for (int e0 = 0; e0 < cnt; e0 += 64) {
-				const int e = e0 + lane;
-				bool hh[2] = {false, false}, hs[4] = {false, false, false, false};
-				if (e < cnt) {
-					const float4 a0 = sh.st.q0[e], a1 = sh.st.q1[e];
-					const float ca = -2.0f * a0.z, cb = -a0.w, cc = -2.0f * a1.x;
-					const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
-					const float rb_c = -cb / cc, rb_a = -cb / ca;
-					const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
-					for (int h = 0; h < 2; h++) hh[h] = box_may_hit<7, 3>(a0.x, a0.y, ca, cb, cc, a1.y, rb_c, rb_a, pd, qx, qy + 4.0f * h);
-					for (int h = 0; h < 4; h++) hs[h] = box_may_hit<7, 1>(a0.x, a0.y, ca, cb, cc, a1.y, rb_c, rb_a, pd, qx, qy + 2.0f * h);
-				}
-				for (int h = 0; h < 2; h++) n_half[h] += __popcll(wave_ballot(hh[h]));
-				for (int h = 0; h < 4; h++) n_strip[h] += __popcll(wave_ballot(hs[h]));
-			}
-			STAT_ADD(16, n_half[0] + n_half[1]);                                        // (entry, half) pairs
-			STAT_ADD(17, max(n_half[0], n_half[1]));                                    // iterations with 2 halves per visit
-			STAT_ADD(18, n_strip[0] + n_strip[1] + n_strip[2] + n_strip[3]);            // (entry, strip) pairs
-			STAT_ADD(19, max(max(n_strip[0], n_strip[1]), max(n_strip[2], n_strip[3]))); // iterations with 4 strips per visit
-			STAT_ADD(20, n_u);                                                          // iterations now (per-quadrant list)
-		}
-#endif
-		STAT_ADD(6, 1);        // batches (per wave)
-		STAT_ADD(7, cnt);      // staged entries (per wave: every wave sees the batch)
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
 		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
 		const int joff_min = (top - (int)last_contributor) * 16;
@@ -510,61 +338,21 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 			const float dy = q0.y - pixfy;
 			const float power = (q0.z * dx * dx + q1.x * dy * dy) + q0.w * dx * dy;   // pre-scaled conic (common.h): the forward's bits
 			const bool cand = ((int)joff > joff_min) && !(power > 0.0f) && !(power < q1.y);
-			const uint64_t cand_mask = wave_ballot((int)joff > joff_min) & wave_ballot(!(power > 0.0f)) & wave_ballot(!(power < q1.y));
-			STAT_ADD(0, 1);                                  // visits
-			if (cand_mask == 0ull) return;   // wave-uniform
-			STAT_ADD(1, 1);                                  // ... with a candidate lane
-			STAT_ADD(4, __popcll(wave_ballot(cand)));        // candidate lanes
-
-			// slow path: fully predicated
+			if (wave_ballot(cand) == 0ull) return;   // wave-uniform
 			const float4 q2 = rec_q2<BSR_BWD_BATCH>(rec);
-			// The forward decided `alpha >= 1/255` on alpha = min(0.99, o * E(power)) with the pinned exp E
-			// (bsr_expf); the backward must take the same decision on every pair (the T chain divides by the
-			// same factors the forward multiplied).  power_cut = -ln(255 o) - 1e-3 proves alpha < 1/255 below it;
-			// symmetrically, power >= power_cut + 2e-3 proves alpha >= 1/255 (E is within 1 ulp of exp, logf within
-			// 2 ulp: margins of 1e-3 in the exponent = 0.1 % of alpha against 1e-6 of rounding).  Only a wave with a
-			// candidate inside that 2e-3 wide band evaluates E to decide; everywhere else the VALUE of exp(power) is
-			// all that is needed, and gradients are compared with a tolerance (the reference's sums are unordered),
-			// so it comes from v_exp_f32: 2 issue slots instead of 13.
-			// The wave votes on `candidate && !(power >= hi)`, hi = power_cut + 2.2e-3 staged in q2.w: a superset of the lanes
-			// the forward's test |power - centre| < 1.1e-3 (centre = power_cut + 1e-3) puts inside the band, assembled on the
-			// scalar side from ballots of SINGLE compares (a ballot of an AND of lane masks makes hipcc materialise the
-			// mask in a VGPR and compare it again, two VALU slots per visit).  With a NaN hi (opacity <= 0 or NaN, whose
-			// NaN power_cut also lets every lane through `cand`) or a NaN power the vote fires, so those pairs get the
-			// alpha < 1/255 test below, which skipped them in the forward (alpha < 0) -- the fast path would blend them.
-			// Inside the rare branch each lane picks its exp with the FORWARD's expression (render_fwd.hip): per lane the
-			// same exp the forward's default mode used on this pair, so alpha is the forward's alpha bit for bit.
-			// X_EXP (strict gradients / attribution build): the pinned exp on every visit.
-			const bool in_band = X_EXP ? true : (wave_ballot(!(power >= q2.w)) & cand_mask) != 0ull;   // rare: ~1 % of the visits
-			float Gx = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
-			if (in_band) {
-				const bool lane_in_band = X_EXP ? true : !(fabsf(power - (q1.y + 1.0e-3f)) >= 1.1e-3f);
-				const float Ge = bsr_expf_walk(power);
-				Gx = lane_in_band ? Ge : Gx;
-			}
-			// Lanes that must not blend carry G = 0, hence alpha = 0: every recurrence below then leaves their state
-			// unchanged (T / 1 = T, Srec + 0 * S = Srec) and all nine contributions are exactly 0 (G * dL_dalpha and
-			// alpha * T; dL_dalpha itself is finite there).
-			float G = cand ? Gx : 0.f;
+			// The forward decided `alpha >= 1/255` on alpha = min(0.99, o * E(power)) with the pinned exp E (bsr_expf) --
+			// in its default mode only inside the decision band, outside of which every exp within ulps decides alike
+			// (render_fwd.hip) -- and the backward must take the same decision on every pair (the T chain divides by the
+			// same factors the forward multiplied).  Lanes that must not blend carry G = 0, hence alpha = 0: every
+			// recurrence then leaves their state unchanged (T / 1 = T) and all nine contributions are exactly 0.
+			float G = cand ? bsr_expf_walk(power) : 0.f;
 			float alpha = fminf(0.99f, q1.z * G);
-			if (in_band) {
-				STAT_ADD(2, 1);                                 // ... decided by the pinned exp
-				const bool active = !(alpha < 1.0f / 255.0f);
-				if (wave_ballot(active) == 0ull) return;
-				G = active ? G : 0.f;
-				alpha = active ? alpha : 0.f;
-			}
-#ifdef BSR_WALK_STATS
-			{
-				const int live = __popcll(wave_ballot(G != 0.f));
-				STAT_ADD(3, 1);                                 // visits that reach the reduction
-				STAT_ADD(5, live);                              // lanes that blend
-				STAT_ADD(8 + ((live - 1) >> 3), 1);             // histogram of live lanes: 1-8, 9-16, ..., 57-64
-			}
-#endif
+			const bool active = !(alpha < 1.0f / 255.0f);
+			if (wave_ballot(active) == 0ull) return;
+			G = active ? G : 0.f;
+			alpha = active ? alpha : 0.f;
 			float v[10];
-			if constexpr (X_NOCONTRACT) pair_terms_source_order<DEPTH, X_DIV, X_PAIRS, X_CHAN>(pst, pc, q0, q1, q2, dx, dy, G, alpha, v);
-			else pair_terms_contracted<DEPTH, X_DIV, X_PAIRS, X_CHAN>(pst, pc, q0, q1, q2, dx, dy, G, alpha, v);
+			pair_terms_reference<DEPTH>(pst, pc, q0, q1, q2, dx, dy, G, alpha, v);
 			const float tot = wave_sums_masked<DEPTH>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
 			if (stores) *reinterpret_cast<float*>(reinterpret_cast<char*>(part_mine) + (joff >> 2)) = tot;   // part_mine[j]
 		};
@@ -588,32 +376,19 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 				sh.part[2][k][tid] = 0.f;
 				sh.part[3][k][tid] = 0.f;
 			}
-			// moments -> the reference's sums (see the walk); this thread staged entry `tid` itself
-			const float4 e0 = sh.st.q0[tid], e1 = sh.st.q1[tid];   // (x, y, -a/2, -b), (-c/2, cut, o, depth)
-			const float ca = -2.0f * e0.z, cb = -e0.w, cc = -2.0f * e1.x;
-			const float no = -e1.z;
-			const float h = 0.5f * no;
 			float* const row = reinterpret_cast<float*>(slab) + (size_t)my_row * slab_row_floats(DEPTH);
-			if constexpr (X_PAIRS) {
-				*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{a9[0], a9[1], a9[2], a9[3]};
-				*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{a9[4], a9[5], a9[6], a9[7]};
-			} else {
-				*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{no * pc.ddelx_dx * (ca * a9[0] + cb * a9[1]),
-				                                                   no * pc.ddely_dy * (cc * a9[1] + cb * a9[0]), h * a9[2], h * a9[3]};
-				*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{h * a9[4], a9[5], a9[6], a9[7]};
-			}
+			*reinterpret_cast<bsr_f32x4_a4*>(row) = bsr_f32x4{a9[0], a9[1], a9[2], a9[3]};
+			*reinterpret_cast<bsr_f32x4_a4*>(row + 4) = bsr_f32x4{a9[4], a9[5], a9[6], a9[7]};
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
-#if !(defined(BSR_BWD_WAVE_STAGING) && BSR_BWD_BATCH == 128)
 		__syncthreads();
-#endif
 	}
 
 	// entries no pixel of the tile reached: zero rows, but they still need their map entry
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
-		const uint32_t id = point_list[slot];
+		const uint32_t id = point_list[slot] & id_mask;
 		float* const row = reinterpret_cast<float*>(slab) +
 		                   (size_t)instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3],
 		                                          tx, ty) * slab_row_floats(DEPTH);
@@ -623,77 +398,49 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd(int n_tiles, int gx, i
 		if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{0.f, 0.f};
 		else row[8] = 0.f;
 	}
-#ifdef BSR_WALK_STATS
-	if (lane == 0) {
-		for (int i = 0; i < BSR_NSTAT; i++)
-			if (wstat[i]) atomicAdd(&g_walk_stats[i], wstat[i]);
-		if (wave == 0 && blockIdx.x < 70000) {
-			unsigned long long* t = g_wg_times + 4 * (size_t)blockIdx.x;
-			t[0] = t_start;
-			t[1] = __builtin_amdgcn_s_memrealtime();
-			uint32_t xcc, hwid;
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-			t[2] = (unsigned long long)xcc | ((unsigned long long)hwid << 32);
-			t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
-		}
-	}
-#endif
 }
 
 // =====================================================================================================================
-// k_render_bwd_t: the default backward walk (round 4).  Same staging, lists, decisions and per-pixel chain as
-// k_render_bwd above, but the cross-lane reduction is TRANSPOSED through LDS:
+// k_render_bwd_t: the default backward walk.  Per-pixel decisions as the reference; the cross-lane reduction of the
+// entry's nine (ten) sums is TRANSPOSED through LDS and runs at full lane utilisation:
 //
-//   phase 1 (per visit; lane = pixel of the wave's 8x8 quadrant): power, candidate votes, exp, alpha, the T chain, Srec,
-//            dL_dalpha -- and then only the TWO numbers every one of the entry's sums is linear in,
+//   staging  (64-entry batches; lane j <-> entry j): the waves take their lists -- one per 8 x 4 HALF of the wave's
+//            quadrant with NS = 2 -- from the half masks the forward left in the entries' point_list words (top byte;
+//            render_fwd.hip), by two ballots and prefix popcounts; only wave 0 gathers the records (one 64-B line each),
+//            writes them to LDS and keeps the entries' slab rows.  One barrier.  (No masks -- more than 2^24 Gaussians,
+//            a single-list forward, the "no_half_masks" hook --: every wave gathers the records and tests them itself.)
+//   phase 1  (per visit; lane = pixel of the wave's 8x8 quadrant; the wave's two halves walk their own lists side by
+//            side, so a visit works on two different entries and the wave needs max(upper, lower) visits instead of
+//            their union): power, candidate votes, exp, alpha, the T chain, Srec, dL_dalpha -- and then only the TWO
+//            numbers every one of the entry's sums is linear in,
 //                gd = G dL_dalpha      (mean2D / conic / opacity sums = sum over pixels of gd x (1, dx, dy, dx dx, dx dy, dy dy))
 //                aT = alpha T          (colour sums = sum over pixels of aT x dL_dpixel[ch])
-//            written as one 8-byte LDS store to the visit's SLOT of the wave's private buffer.  No cross-lane instruction,
-//            no per-pair products.
-//   phase 2 (once per CHUNK of 8 visits; lane = (slot e = lane >> 3, pixel row r = lane & 7)): the lane reads its row's
-//            8 x (gd, aT) with four 16-byte LDS reads and accumulates, serially in registers, the row's moments of gd
-//            about the TILE centre (pixel-column coordinates are compile-time constants: sum g, sum g x, sum g x^2 by
-//            the symmetric pairing x_c = -x_(7-c); the row coordinate y is a per-lane constant) and the three colour
-//            sums against dL_dpixel of its own 8 pixels (per-lane constants for the whole kernel).  The 8 rows of a slot
-//            are then added by a 3-step butterfly over the 8 lanes (19 DPP adds for 9 values, amortised over 8 visits)
-//            and stored to the wave's partial-sum slots part[wave][k][entry].
-//   epilogue (per batch, as before): the four quadrants' partial sums are added in a fixed order; the moments about the
-//            tile centre are shifted ONCE to the Gaussian's centre (d = centre - pixel: sum g dx = Dx M00 - M10, sum g dx^2
-//            = Dx^2 M00 - 2 Dx M10 + M20, ...) and the row is assembled as before.
+//            written as one 8-byte LDS store to the visit's SLOT of the wave's private buffer.  No cross-lane
+//            instruction, no per-pair products.
+//   phase 2  (once per CHUNK of 8 visits; lane = (slot e = lane >> 3, pixel row r = lane & 7)): the lane reads its row's
+//            8 x (gd, aT) with four 16-byte LDS reads and forms the row's moments of gd about ITS entry's centre (the
+//            reference's d = centre - pixel: dy one number per row, dx_c = dx_0 - c; moments about the tile centre
+//            shifted afterwards cancel 50-100x on small splats) and the three colour sums against dL_dpixel of its own 8
+//            pixels (register constants).  NS = 2: a slot's rows 0-3 and 4-7 belong to two entries, so the rows are added
+//            over the quad (18 DPP adds) and the quad's four lanes ADD their shares to part[wave][k][entry] -- upper
+//            halves first, lower halves behind them, plain read-add-write (an entry in both lists gets two
+//            contributions; 0 + a + b does not depend on their order).  NS = 1: 19 DPP adds over the 8-lane group, plain
+//            stores.
+//   epilogue (per batch): wave 0 adds the four quadrants' parts in a fixed order and writes the entry's 36-byte row of
+//            the Gaussian-major slab, while the other waves already stage the next batch.
 //
-// Why: the predecessor spent 24 DPP / permlane instructions (the most expensive issue slots of the walk, 4.3 cycles each)
-// plus 8 per-pair products on EVERY visit, at 22 useful lanes of 64 (the reduction alone was 0.18-0.20 ms of
-// 0.62 at C3).  Here every visit pays one LDS store, and the reduction work runs at full lane utilisation:
-// ~75 instructions per 8 visits.  Sums are still formed in a fixed order (bit-reproducible); no atomics.
-// LDS: 64-entry batches (the partial-sum slots shrink with the batch) + 4 x 4.1 KB of transposition buffers = 30.6 KB
-// per workgroup, 5 workgroups per CU.
-//
-// NS = 2 (the default instantiation; round 4, second half): one list per 8 x 4 HALF of the quadrant instead of one per
-// quadrant, as in the forward walk (tile_common.h).  A third of the quadrant visits touch one half only; with a list per
-// half the wave's two halves walk different entries side by side and the wave needs max(upper, lower) visits instead of
-// their union: 12-15 % fewer phase-1 visits and phase-2 chunks.  What round 2 could not afford in the per-visit network
-// walk (the two halves' sums of one entry had to meet in LDS on EVERY visit) costs little here: a slot of the
-// transposition buffer simply holds two entries (rows 0-3 | rows 4-7), phase 2 sums over the quad instead of the
-// 8-lane group (18 DPP adds instead of 19) and ADDS the quad's totals to the entry's partial sums -- upper halves
-// first, lower halves behind them, plain read-add-write (see reduce_chunk).  A/B on one box: render_bwd -4..-5 % at
-// C3, -4 % at 2 M Gaussians, -5 % with scales x 0.6 and with cycling cameras, -2 % at 300 k and scales x 1.5, +1 % at
-// scales x 2 (profiles/r04_v3/ab_bwd_split_lists_*.txt); with plain stores in place of the adds (wrong sums) -10.6 %:
-// the two-pass accumulation is what is left on the table.  The depth-gradient instantiation (ten sums per entry) keeps
-// NS = 1: with split lists it spills and loses 8 %.
+// Sums are formed in a fixed order (bit-reproducible); no atomics.  LDS 31.0 KB -> 5 workgroups per CU (the limit is
+// 32 000 B each); amdgpu_waves_per_eu(5,5) holds the kernel at 96 VGPRs.  History, A/B tables and rejected variants
+// (scalar-cache records, LDS atomics, sums filed by list position, pair-padded lists, blocks of four entries, shared
+// staging, a trailing barrier, list words prefetched a batch ahead, ...): docs/EXPERIMENTS.md.
+// The depth-gradient instantiation (ten sums per entry) keeps NS = 1: with split lists it spills.
 #ifndef BSR_BWT_BATCH
 #define BSR_BWT_BATCH 64
 #endif
 #define BSR_BWT_CHUNK 8
-#ifndef BSR_BWT_ILP
-#define BSR_BWT_ILP 2   // list entries per straight-line block of phase 1 (2 or 4): A/B on one box, 5 waves per SIMD: 2 is
-                        // 1 % faster than 4 and needs no spill; at 4 waves per SIMD the block of 4 was worth 8 %
-#endif
-#ifndef BSR_BWT_PAD
-#define BSR_BWT_PAD 4   // the lists are sentinel-padded to whole TRIPS of four; a chunk is one or two trips.  (Padding to
-                        // blocks of two, the second block of a trip skipped past the end: -2 % in one four-round A/B, +6 % on
-                        // six other boxes -- the branch between a trip's blocks costs more than the sentinel visits; docs/EXPERIMENTS.md)
-#endif
+#define BSR_BWT_ILP 2   // list entries per straight-line block of phase 1 (blocks of four: +1 %, docs/EXPERIMENTS.md)
+#define BSR_BWT_PAD 4   // the lists are sentinel-padded to whole TRIPS of four; a chunk is one or two trips (pairs / eights:
+                        // docs/EXPERIMENTS.md)
 // A slot = 8 pixel rows x 64 B.  Phase-1 store: ds_write_b64 is served in groups of 16 consecutive lanes = 2 rows = 32
 // consecutive dwords: conflict-free.  Phase-2 read: ds_read_b128 is served in four groups of 16 lanes that mix slots
 // (e, e+1, e+2, e+3) x 4 rows each; rows 16 dwords apart cover all 64 banks once per FOUR rows, so slot e is rotated by
@@ -817,6 +564,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
                                                             const float* __restrict__ dL_dpixels,
                                                             const float* __restrict__ out_depth,   // DEPTH only
                                                             const float* __restrict__ dL_depths,   // DEPTH only
+                                                            const int* __restrict__ masks_flag,    // forward's hand-over word
                                                             float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
@@ -839,6 +587,11 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 
 	const uint32_t start = tile_start[tile];
 	const int n = (int)(tile_start[tile + 1] - start);
+	// The forward's split-list staging left its eight per-half box tests in the top byte of every point_list word it
+	// staged (render_fwd.hip; a word the forward never staged lies beyond every pixel's last contributor): the waves then
+	// take their lists from that byte and only wave 0 gathers records.  0: plain ids, every wave tests for itself.
+	const bool has_masks = __builtin_amdgcn_readfirstlane(*masks_flag) != 0;
+	const uint32_t id_mask = has_masks ? 0x00ffffffu : 0xffffffffu;
 
 	const float T_final = inside ? final_Ts[pix_id] : 0.0f;
 	float T = T_final, Srec = 0.f;
@@ -914,7 +667,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	for (int base = 0; base < n_walk; base += B) {
 		const int cnt = min(B, n_walk - base);
 		const int top = n_walk - 1 - base;   // list position of batch entry j is top - j
-#ifndef BSR_BWT_SHARED_STAGING
 		// ---- staging: EVERY wave looks at the batch's 64 entries itself (lane j <-> entry j: the same 64-B lines four
 		// times, three of them from the L1/L2) and tests them against ITS OWN quadrant: one box test per wave instead of
 		// four on one wave, its list straight from its own ballot -- no count table, one barrier instead of two.  Wave 0
@@ -925,25 +677,39 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		bool hit = false;
 		bool hit_lo = false;   // NS = 2: rows 4-7 of the quadrant (`hit`: rows 0-3)
 		if (valid) {
-			const uint32_t id = point_list[start + (uint32_t)(top - lane)];
-			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
-			const float4 r0 = r[0], r1 = r[1];
-			if (wave == 0) {
-				float4 r2 = r[2];
-				my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-				r2.w = r1.y + 2.2e-3f;   // staged q2.w: just above the decision band, -ln(255 o) + 1.2e-3
-				sh.st.q0[lane] = r0;
-				sh.st.q1[lane] = r1;
-				sh.st.q2[lane] = r2;
+			const uint32_t word = point_list[start + (uint32_t)(top - lane)];
+			const uint32_t id = word & id_mask;
+			if (wave == 0 || !has_masks) {
+				const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
+				const float4 r0 = r[0], r1 = r[1];
+				if (wave == 0) {
+					float4 r2 = r[2];
+					my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
+					r2.w = r1.y + 2.2e-3f;   // staged q2.w: just above the decision band, -ln(255 o) + 1.2e-3
+					sh.st.q0[lane] = r0;
+					sh.st.q1[lane] = r1;
+					sh.st.q2[lane] = r2;
+				}
+				if (!has_masks) {
+					const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
+					const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
+					const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
+					if (NS == 2) {
+						hit = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
+						hit_lo = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy + 4.0f);
+					} else {
+						hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
+					}
+				}
 			}
-			const float ca = -2.0f * r0.z, cb = -r0.w, cc = -2.0f * r1.x;   // the record holds (-a/2, -b, -c/2)
-			const bool pd = (ca > 0.0f) && (cc > 0.0f) && (ca * cc - cb * cb > 0.0f);
-			const float qx = tile_x0 + (float)((wave & 1) << 3), qy = tile_y0 + (float)((wave >> 1) << 3);
-			if (NS == 2) {
-				hit = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
-				hit_lo = box_may_hit<7, 3>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy + 4.0f);
-			} else {
-				hit = box_may_hit<7, 7>(r0.x, r0.y, ca, cb, cc, r1.y, -cb / cc, -cb / ca, pd, qx, qy);
+			if (has_masks) {   // the forward's tests of this entry against the two halves of this wave's quadrant
+				const uint32_t two = (word >> (24 + 2 * wave)) & 3u;
+				if (NS == 2) {
+					hit = (two & 1u) != 0u;
+					hit_lo = (two & 2u) != 0u;
+				} else {
+					hit = two != 0u;
+				}
 			}
 		}
 		int n_u;   // visits the wave needs for this batch (wave-uniform)
@@ -967,24 +733,6 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			if (lane < BSR_BWT_PAD - 1) sh.st.list[wave][n_u + lane] = (unsigned int)(B << 4);   // pad to whole blocks
 		}
 		__syncthreads();
-#else
-		const bool valid = tid < cnt;
-		float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-		uint32_t my_row = 0;
-		if (valid) {
-			const uint32_t my_slot = start + (uint32_t)(top - tid);
-			const uint32_t id = point_list[my_slot];
-			const float4* r = rec + (size_t)id * BSR_REC;   // one 64-B line: record + rect + instance offset
-			r0 = r[0];
-			r1 = r[1];
-			r2 = r[2];
-			my_row = instance_index(wg_base, id, r2, r[3], tx, ty);   // the entry's row in the Gaussian-major slab
-			r2.w = r1.y + 2.2e-3f;   // staged q2.w: just above the decision band, -ln(255 o) + 1.2e-3
-		}
-		// (the trailing barrier of the previous iteration fenced the staging buffers)
-		const int n_mine = stage_and_compact_s(sh.st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
-		const int n_u = __builtin_amdgcn_readfirstlane(n_mine);
-#endif
 		// entry j of the batch sits at list position top - j; this pixel blended positions < last_contributor
 		// (reference :498-500): j > top - last_contributor, compared on the pre-scaled list offsets
 		const int joff_min = (top - (int)last_contributor) * 16;
@@ -1069,14 +817,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			for (int k = 0; k < NE; k++) chain(e[k], g[k], a[k], slot0 + k);
 		};
 		auto trip = [&](const uint4 l, const int slot0) {
-#if BSR_BWT_ILP == 4
-			const unsigned int q[4] = {l.x, l.y, l.z, l.w};
-			block(q, slot0);
-#else
 			const unsigned int q0[2] = {l.x, l.y}, q1[2] = {l.z, l.w};
 			block(q0, slot0);
 			block(q1, slot0 + 2);
-#endif
 		};
 
 		// ---- phase 2: the chunk's slots, transposed: lane (e2, r2) sums row r2 of slot e2 about the ENTRY's centre
@@ -1163,7 +906,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			const uint4 la = *reinterpret_cast<const uint4*>(my_list + i);
 			const uint4 lb = *reinterpret_cast<const uint4*>(my_list + i + 4);   // (past the padding: inside the struct, not used)
 			trip(la, 0);
-			if (BSR_BWT_PAD == 8 || i + 4 < n_pad) trip(lb, 4);
+			if (i + 4 < n_pad) trip(lb, 4);
 #ifdef BSR_BWT_KO_PHASE2   // knock-out build (timing only): phase 1 without the transposed reduction
 			continue;
 #endif
@@ -1200,7 +943,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
-#if defined(BSR_BWT_SHARED_STAGING) || defined(BSR_BWT_TRAILING_BARRIER)
+#ifdef BSR_BWT_TRAILING_BARRIER   // debug build only (see the invariants below): results must not change with it
 		__syncthreads();
 #endif
 		// (no barrier here: while wave 0 adds up the batch, the other waves already fetch and test the next one -- they
@@ -1211,7 +954,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	// entries no pixel of the tile reached: zero rows, but they still need their map entry
 	for (int pos = n_walk + tid; pos < n; pos += BSR_BLOCK) {
 		const uint32_t slot = start + (uint32_t)pos;
-		const uint32_t id = point_list[slot];
+		const uint32_t id = point_list[slot] & id_mask;
 		float* const row = reinterpret_cast<float*>(slab) +
 		                   (size_t)instance_index(wg_base, id, rec[(size_t)id * BSR_REC + 2], rec[(size_t)id * BSR_REC + 3],
 		                                          tx, ty) * slab_row_floats(DEPTH);
@@ -1226,67 +969,38 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       float4* slab, bool strict, int num_rendered, hipStream_t s)
+                       const int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_BWD");
 	const bool depth = out_depth && dL_depths;
-#define BSR_LAUNCH_BWD(D_, S_)                                                                                          \
-	hipLaunchKernelGGL((k_render_bwd<D_, S_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
+#define BSR_LAUNCH_STRICT(D_)                                                                                            \
+	hipLaunchKernelGGL((k_render_bwd_strict<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
-	                   depth ? dL_depths : nullptr, slab)
-#ifndef BSR_BWT_DEFAULT_NS
-#define BSR_BWT_DEFAULT_NS 2   // lists per quadrant of the default instantiation (A/B hook: make variant DEFS=-DBSR_BWT_DEFAULT_NS=1)
-#endif
+	                   depth ? dL_depths : nullptr, masks_flag, slab)
 #define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
 	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
-	                   depth ? dL_depths : nullptr, slab)
-	// Default: the transposed-reduction walk.  BSR_FLAG_EXACT_GRAD (and the attribution / diagnostic builds, which are
-	// variants of the per-visit network walk): k_render_bwd.  Frames whose tiles hold very long lists also take
-	// k_render_bwd: the transposed walk moves work from the vector ALU to the LDS (27 instead of 20 LDS cycles per visit)
-	// and stages 64 entries per batch instead of 128, which costs more than it saves once a tile's life is dominated by
-	// staging (5 M Gaussians: 2700 entries per tile, 1.1 visits per staged entry) or by visits alone (scales x 3).
-	// A/B on one box, k_render_bwd -> k_render_bwd_t, by reference instances per tile: 160: -5 %, 540 (C3): -20 %, 1000
-	// -1300: -6..-9 %, 1600 (3 M Gaussians): -3 %, 2200 (scales x 3): +4 %, 2700 (C5): +3 %.  Both walks take every
-	// decision alike; their sums differ in the order of the additions only (gradients carry a tolerance either way).
-#if defined(BSR_BWD_NETWORK_WALK) || defined(BSR_WALK_STATS)
-	const bool network = true;
-#else
-#ifndef BSR_BWT_MAX_PER_TILE
-#define BSR_BWT_MAX_PER_TILE 1900ll   // (A/B hook: make variant DEFS=-DBSR_BWT_MAX_PER_TILE=100000000ll)
-#endif
-	const bool network = strict || (long long)num_rendered > BSR_BWT_MAX_PER_TILE * n_tiles;
-#endif
-	if (network) {
-		if (depth && strict) BSR_LAUNCH_BWD(true, true);
-		else if (depth) BSR_LAUNCH_BWD(true, false);
-		else if (strict) BSR_LAUNCH_BWD(false, true);
-		else BSR_LAUNCH_BWD(false, false);
+	                   depth ? dL_depths : nullptr, masks_flag, slab)
+	// Default: the transposed-reduction walk, for every frame.  (Until round 5 frames with > 1900 reference instances
+	// per tile -- C5, scales x 3 -- kept round 3's per-visit network walk, 0-4 % faster there; with the forward's half
+	// masks handed over, k_render_bwd_t is 5 % faster at C5 and within 1.5 % on the dense scene: docs/EXPERIMENTS.md.)
+	// BSR_FLAG_EXACT_GRAD: k_render_bwd_strict.
+	(void)num_rendered;
+	if (strict) {
+		if (depth) BSR_LAUNCH_STRICT(true);
+		else BSR_LAUNCH_STRICT(false);
 	} else if (depth) {
-		BSR_LAUNCH_BWT(true, 1);    // (ten sums per entry: with split lists the kernel spills and loses 8 %)
+#ifndef BSR_BWT_DEPTH_NS
+#define BSR_BWT_DEPTH_NS 1
+#endif
+		BSR_LAUNCH_BWT(true, BSR_BWT_DEPTH_NS);    // (ten sums per entry: with split lists the kernel spills and loses 8 %)
 	} else {
-		BSR_LAUNCH_BWT(false, BSR_BWT_DEFAULT_NS);
+		BSR_LAUNCH_BWT(false, 2);
 	}
+#undef BSR_LAUNCH_STRICT
 #undef BSR_LAUNCH_BWT
-#undef BSR_LAUNCH_BWD
 }
 
 }  // namespace bsr
-
-#ifdef BSR_WALK_STATS
-// Diagnostic build only: copies (and clears) the counters / the timeline.  which = 0: g_walk_stats, 1: g_wg_times.
-extern "C" int bsr_debug_walk_stats(int which, void* out, size_t bytes)
-{
-	hipError_t e = hipDeviceSynchronize();
-	if (e == hipSuccess)
-		e = which == 0 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_walk_stats), bytes)
-		               : hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_wg_times), bytes);
-	if (e == hipSuccess && which == 0) {
-		static unsigned long long zeros[BSR_NSTAT];
-		e = hipMemcpyToSymbol(HIP_SYMBOL(bsr::g_walk_stats), zeros, sizeof(zeros));
-	}
-	return e == hipSuccess ? 0 : 1;
-}
-#endif

@@ -47,7 +47,7 @@ template <int NS, int FB, bool EXACT>
 __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
-                                                          const uint32_t* __restrict__ point_list,
+                                                          uint32_t* point_list, int* __restrict__ masks_flag,
                                                           const float4* __restrict__ rec,
                                                           const float* __restrict__ bg_color,
                                                           float* __restrict__ final_T,
@@ -67,6 +67,12 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 	if (n_instances > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave-uniform: kept on the scalar side)
+	// Hand-over to the backward walk (masks_flag != nullptr: one view, ids below 2^24): the NS = 2 staging below has the
+	// eight per-half box tests of every entry it stages in one byte; written into the top byte of the entry's point_list
+	// word, the backward's waves take their lists from it instead of gathering and testing the records again (the tests
+	// are a pure function of the sorted list: built once, here).  *masks_flag says whether THIS run did so.
+	const bool hand_over = (NS == 2) && masks_flag != nullptr;
+	if (masks_flag != nullptr && tile == 0 && tid == 0) *masks_flag = hand_over ? 1 : 0;
 #ifdef BSR_WALK_STATS
 	unsigned long long wstat[BSR_NSTAT_F] = {};
 	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -284,15 +290,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 			const int cnt = min(FB, n - base);
 			const bool valid = tid < cnt;
 			float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+			uint32_t id = 0;
 			if (valid) {
-				const uint32_t id = point_list[start + base + tid];
+				id = point_list[start + base + tid];
 				const float4* r = rec + (size_t)id * BSR_REC;
 				r0 = r[0];
 				r1 = r[1];
 				r2 = r[2];
 				r2.w = r1.y + 1.0e-3f;   // staged q2.w (in HBM: half of the kept-tile mask, backward only): centre of the decision band, -ln(255 o)
 			}
-			n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0);
+			unsigned int hits;   // bit 2 q + h: the entry may touch rows 4 h .. 4 h + 3 of quadrant q
+			n_mine = stage_and_compact_s(st, tid, valid, r0, r1, r2, tile_x0, tile_y0, hits);
+			if (hand_over && valid) point_list[start + base + tid] = id | (hits << 24);
 			pos_bias = (uint32_t)(base + 1) << 4;
 			FSTAT_ADD(6, 1);      // batches (per wave)
 			FSTAT_ADD(7, cnt);    // staged entries (every wave sees the batch)
@@ -332,7 +341,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 }
 
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
-                       const uint32_t* point_list,
+                       uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, bool exact, hipStream_t s)
 {
@@ -345,7 +354,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	const bool split = (long long)capacity >= 48ll * n_tiles;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
 	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_FWD_BATCH, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
-	                   n_ptr, capacity, tile_start, point_list, rec, bg, final_T, n_contrib, out_color, out_depth)
+	                   n_ptr, capacity, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth)
 	if (split && exact) BSR_LAUNCH_FWD(2, true);
 	else if (split) BSR_LAUNCH_FWD(2, false);
 	else if (exact) BSR_LAUNCH_FWD(1, true);

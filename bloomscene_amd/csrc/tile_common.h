@@ -154,12 +154,13 @@ __device__ __forceinline__ int my_list_index(int wave, int lane) { return wave *
 // its NS lists); st.list[l][0 .. that, rounded up to 4) is valid for each of its lists.
 template <int BATCH, int NS, typename LT, int PAD>
 __device__ __forceinline__ int stage_and_compact_s(TileStageS<BATCH, NS, LT, PAD>& st, int tid, bool valid, const float4 r0,
-                                                   const float4 r1, const float4 r2, float tile_x0, float tile_y0)
+                                                   const float4 r1, const float4 r2, float tile_x0, float tile_y0,
+                                                   unsigned int& hits)
 {
 	constexpr int NL = 4 * NS;
 	constexpr int SH = 8 / NS;   // strip height in pixels
 	const int wave = tid >> 6, lane = tid & 63;
-	unsigned int hits = 0;       // bit l: this thread's entry may touch strip l (one VGPR, not NL flags and masks)
+	hits = 0;                    // bit l: this thread's entry may touch strip l (one VGPR, not NL flags and masks)
 	if (valid) {
 		st.q0[tid] = r0;
 		st.q1[tid] = r1;

@@ -375,7 +375,12 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     out.kept = int(out.tile_start[T]) if R > 0 else 0
     if R > 0:
         b = bin_t.cpu().numpy()
-        out.point_list = b[0:out.kept * 4].view(np.uint32)   # point_list is the first section
+        words = b[0:out.kept * 4].view(np.uint32)   # point_list is the first section
+        # one view of at most 2^24 Gaussians: the forward leaves its eight per-half box tests in the top byte of every
+        # word it staged (csrc/render_fwd.hip -> render_bwd.hip); zero where it did not
+        packed = P <= (1 << 24)
+        out.half_masks = (words >> 24).astype(np.uint8) if packed else np.zeros(words.shape, np.uint8)
+        out.point_list = (words & 0xffffff) if packed else words
     else:
         out.point_list = np.zeros(0, dtype=np.uint32)
     return out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # BASELINE config C5, "LDS-tile occupancy + rocprof HBM-GB/s sweep": the two tile renderers at 5 M Gaussians with
-#   * the backward's LDS batch at 64 / 128 / 256 staged entries (make -C bloomscene_amd/csrc batch BATCH=64|256), and
+#   * (until round 5 also the network walk at 64 / 128 / 256 staged entries: profiles/r02-r04), and
 #   * the workgroups a CU can hold capped by unused dynamic LDS (BSR_SWEEP_LDS_PAD_FWD / _BWD, read only by the sweep
 #     build libbsr_rast_sweep.so: make -C bloomscene_amd/csrc sweep; tile_common.h),
 # each point: bench.py --config c5 (stage times from hipEvents) + rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
@@ -32,9 +32,6 @@ POINTS=(
  "fwd_wg6           libbsr_rast_sweep.so  10800 0"
  "fwd_wg4           libbsr_rast_sweep.so  24000 0"
  "fwd_wg2           libbsr_rast_sweep.so  65000 0"
- "bwd_batch64       libbsr_batch64.so     0     0"
- "bwd_batch64_wg6   libbsr_batch64.so     0     13700"
- "bwd_batch256      libbsr_batch256.so    0     0"
 )
 fi
 for p in "${POINTS[@]}"; do

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Lane utilisation and load balance of the backward tile walk (k_render_bwd), from the diagnostic build
+"""Lane utilisation and load balance of the FORWARD tile walk (k_render_fwd), from the diagnostic build
 `make -C bloomscene_amd/csrc stats` (libbsr_rast_stats.so: per-wave counters + a per-workgroup timeline; the product
-library carries neither).  Run on the GPU box:
+library carries neither).  (Until round 5 also of the backward's per-visit network walk, which is now the strict-gradient
+path only; its tables: profiles/r03_*, r04_*/walk_stats_*.json.)  Run on the GPU box:
 
     python tools/walk_stats.py [--lib bloomscene_amd/libbsr_rast_stats.so] [--config c3] [--scale-mul 1.0]
 
@@ -34,10 +35,7 @@ def main():
     _capi.use_library(args.lib)
     from bloomscene_amd.synthetic import scene_a, upstream_grads
     lib = _capi.lib()
-    fn = lib.bsr_debug_walk_stats   # AttributeError here = not the diagnostic build
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
-    fnf = lib.bsr_debug_walk_stats_fwd
+    fnf = lib.bsr_debug_walk_stats_fwd   # AttributeError here = not the diagnostic build
     fnf.restype = C.c_int
     fnf.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
     P, W, H, deg = CONFIGS[args.config]
@@ -54,7 +52,6 @@ def main():
         leaves["scales"].mul_(args.scale_mul)
     gC, gD = upstream_grads(W, H, seed=1)
     gC, gD = gC.to(dev), gD.to(dev)
-    stats = np.zeros(24, dtype=np.uint64)
     fstats = np.zeros(24, dtype=np.uint64)
     for it in range(3):
         if it == 2:
@@ -63,39 +60,12 @@ def main():
         m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
         color, radii, depth = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"],
                                    shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
-        if it == 2:
-            torch.cuda.synchronize()
-            assert fn(0, stats.ctypes.data, stats.nbytes) == 0   # clears what the warm-up launches counted
         torch.autograd.backward((color, depth), (gC, gD))
     torch.cuda.synchronize()
-    assert fn(0, stats.ctypes.data, stats.nbytes) == 0
     assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0
     T = ((W + 15) // 16) * ((H + 15) // 16)
     nblk = (T + 7) // 8 * 8
-    tl = np.zeros(4 * 70000, dtype=np.uint64)
-    assert fn(1, tl.ctypes.data, tl.nbytes) == 0
-    tl = tl.reshape(-1, 4)[:nblk]
-    tl = tl[tl[:, 1] > 0]
-    s = stats.astype(np.float64)
-    visits, pass1, band, reduce_, cand_l, live_l, batches, staged = s[:8]
-    hist = s[8:16]
-    out = {
-        "config": args.config, "scale_mul": args.scale_mul, "tiles": T,
-        "entries_staged_per_tile": staged / 4 / T,            # every wave counts the batch
-        "visits_per_staged_entry": visits / (staged / 4),     # = quadrants kept by the conservative box test
-        "share_of_visits_with_a_candidate": pass1 / visits,
-        "share_of_visits_decided_by_pinned_exp": band / visits,
-        "share_of_visits_reducing": reduce_ / visits,
-        "candidate_lanes_per_candidate_visit": cand_l / max(pass1, 1),
-        "live_lanes_per_reducing_visit": live_l / max(reduce_, 1),
-        "live_lane_histogram_1-8_..._57-64": (hist / max(reduce_, 1)).round(4).tolist(),
-        "reducing_visits_per_kept_instance": reduce_ / (staged / 4),
-        # what-if counts (conservative box test per 8x4 half / 8x2 strip of each quadrant)
-        "what_if": {"iterations_now": s[20], "entry_half_pairs": s[16], "iterations_two_halves_per_visit": s[17],
-                    "entry_strip_pairs": s[18], "iterations_four_strips_per_visit": s[19],
-                    "ratio_two_halves": s[17] / max(s[20], 1), "ratio_four_strips": s[19] / max(s[20], 1)},
-    }
-    out["backward_timeline"] = timeline(tl)
+    out = {"config": args.config, "scale_mul": args.scale_mul, "tiles": T}
     ftl = np.zeros(4 * 70000, dtype=np.uint64)
     assert fnf(3, ftl.ctypes.data, ftl.nbytes) == 0
     ftl = ftl.reshape(-1, 4)[:nblk]
