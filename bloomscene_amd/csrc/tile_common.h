@@ -21,12 +21,15 @@ static inline constexpr unsigned occupancy_sweep_lds_pad(const char*) { return 0
 #endif
 
 // Can the splat reach alpha >= 1/255 at ANY point of an axis-aligned box of pixel centres
-// [bx, bx+EXT] x [by, by+EXT]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
+// [bx, bx+EXT] x [by, by+EXTY]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
 // d = centre - pixel.  For a positive-definite conic q is convex, so its minimum over the box is 0
-// if the centre lies inside and otherwise sits on one of the four edges, where it is a clamped 1-D
-// parabola minimum.  The splat is kept iff  -qmin >= power_cut - slack  (power_cut already carries
-// a margin; the extra slack covers the rounding of this test).  Anything not provably a miss --
-// non-PD conics, NaNs -- is kept, so the per-pixel decisions downstream stay exact.
+// if the centre lies inside; otherwise it sits on an edge that FACES the centre (the level ellipse that first touches
+// the box touches it at a point the centre sees): the vertical edge on the centre's side if the centre is outside the
+// box's x-range, the horizontal one on its side if outside the y-range -- at most two clamped 1-D parabola minima
+// (until round 5 all four edges were evaluated: the other two can never hold the minimum).  The splat is kept iff
+// -qmin >= power_cut - slack  (power_cut already carries a margin; the extra slack covers the rounding of this test).
+// Anything not provably a miss -- non-PD conics, NaN conics / cuts -- is kept, so the per-pixel decisions downstream
+// stay exact.
 template <int EXT, int EXTY = EXT>   // box of pixel centres [bx, bx+EXT] x [by, by+EXTY]: EXT = 7 (quadrant) or 15 (tile)
 __device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
                                             float rb_a, bool pd, float bx, float by)
@@ -35,20 +38,16 @@ __device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, 
 	const float dy_lo = Y - (by + (float)EXTY), dy_hi = Y - by;
 	const bool in_x = (dx_lo <= 0.0f) && (dx_hi >= 0.0f);
 	const bool in_y = (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
-	float qmin = 0.0f;
-	if (!(in_x && in_y)) {
-		// edges dx = const
-		float dy0 = fminf(fmaxf(rb_c * dx_lo, dy_lo), dy_hi);
-		float q0 = 0.5f * (a * dx_lo * dx_lo + c * dy0 * dy0) + b * dx_lo * dy0;
-		float dy1 = fminf(fmaxf(rb_c * dx_hi, dy_lo), dy_hi);
-		float q1 = 0.5f * (a * dx_hi * dx_hi + c * dy1 * dy1) + b * dx_hi * dy1;
-		// edges dy = const
-		float dx2 = fminf(fmaxf(rb_a * dy_lo, dx_lo), dx_hi);
-		float q2 = 0.5f * (a * dx2 * dx2 + c * dy_lo * dy_lo) + b * dx2 * dy_lo;
-		float dx3 = fminf(fmaxf(rb_a * dy_hi, dx_lo), dx_hi);
-		float q3 = 0.5f * (a * dx3 * dx3 + c * dy_hi * dy_hi) + b * dx3 * dy_hi;
-		qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-	}
+	// the edge dx = const on the centre's side (centre right of the box: dx_lo > 0, the edge at pixel x = bx + EXT)
+	const float dxe = dx_lo > 0.0f ? dx_lo : dx_hi;
+	const float dy0 = fminf(fmaxf(rb_c * dxe, dy_lo), dy_hi);
+	const float q0 = 0.5f * (a * dxe * dxe + c * dy0 * dy0) + b * dxe * dy0;
+	// the edge dy = const on the centre's side
+	const float dye = dy_lo > 0.0f ? dy_lo : dy_hi;
+	const float dx1 = fminf(fmaxf(rb_a * dye, dx_lo), dx_hi);
+	const float q1 = 0.5f * (a * dx1 * dx1 + c * dye * dye) + b * dx1 * dye;
+	// centre inside the x-range: only the horizontal edge faces it (and inside both: q = 0 at the centre itself)
+	const float qmin = in_x ? (in_y ? 0.0f : q1) : (in_y ? q0 : fminf(q0, q1));
 	const float slack = 1.0e-3f + 1.0e-4f * fabsf(cut);
 	const bool miss = pd && (-qmin < cut - slack);
 	return !miss;
