@@ -465,6 +465,19 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     alg_bytes = n_views * ((187 + 12 * M) * P + 24 * W * H) + 48 * R_all
     out["num_rendered_all_views"] = int(R_all)
     out["algorithmic_bytes_all_views"] = int(alg_bytes)
+    # ... and what a sweep that renders every 16-view batch from the rows its own filter kept actually submits: per batch
+    # the filter's read of positions, scales and rotations (40 B x P), the gather (236-byte rows read and written) and the
+    # per-view term on the batch's rows only.  (Round 4 charged the compacted sweeps with all P rows per view: a
+    # "fraction" above 1.)
+    row_bytes_all = (3 + 3 + 4 + 1 + 3 * M) * 4
+    batches16 = [mine[b0:b0 + 16] for b0 in range(0, len(mine), 16)]
+    rows16 = [int(x) for x in views.group_visibility(pack, bufs["means3D"], bufs["scales"], bufs["rotations"], batches16,
+                                                     return_counts=True)[1].tolist()] if batches16 else []
+    alg_mine_compacted = sum(40 * P + 2 * row_bytes_all * r + len(b) * (187 + 12 * M) * r for b, r in zip(batches16, rows16)) \
+        + len(mine) * 24 * W * H + 48 * R_mine
+    alg_bytes_compacted = sum(D.gather_ints(alg_mine_compacted))
+    out["rows_submitted_per_16_view_batch_rank0"] = rows16
+    out["algorithmic_bytes_all_views_compacted"] = int(alg_bytes_compacted)
     for batch, compact in ((1, False), (16, False), (16, True)):
         def sweep():
             return views.render_views_sharded(cams if batch == 1 else pack, bufs, bg, deg, rank=D.rank, world=D.world,
@@ -484,19 +497,35 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
             "sweep_ms": round(t * 1e3, 3), "ms_per_view_per_rank": round(t / max(len(mine), 1) * 1e3, 4),
             "value": round(n_views * P / t / 1e6, 1),
             "value_including_broadcast": round(n_views * P / (t + bcast_s) / 1e6, 1),
-            "roofline_frac_algorithmic": round(alg_bytes / t / 1e9 / (HBM_PEAK_GBS * D.world), 5)}
+            # bytes of the rows this form of the sweep SUBMITS (all P per view, or each batch's kept rows) / time / peak
+            "roofline_frac_algorithmic": round((alg_bytes_compacted if compact else alg_bytes) / t / 1e9
+                                               / (HBM_PEAK_GBS * D.world), 5)}
     # ---- the MI355X-native distribution: every rank gets ONLY what its block of neighbouring views can see, over its
     # own xGMI link (views.scatter_visible_gaussians), instead of the 236 B/Gaussian broadcast on every link ----
-    for _ in range(2):   # first pass: code-object load of the group filter, allocator growth; second: measured
-        D.fence()
-        t0 = time.perf_counter()
-        local, my_views, info = views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0,
-                                                                assignment="contiguous", device=dev)
-        D.fence()
-        dist_s = D.max_over_ranks(time.perf_counter() - t0)
-    sc_out = {"assignment": "contiguous blocks of views", "rows_per_rank": info["counts"],
+    def distribute(form):
+        fn = {"batched": lambda: views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0,
+                                                                 assignment="contiguous", device=dev, pipelined=False),
+              "pipelined": lambda: views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0,
+                                                                   assignment="contiguous", device=dev, pipelined=True),
+              "blockwise": lambda: views.scatter_visible_gaussians_blockwise(bufs if D.rank == 0 else None, pack, src=0,
+                                                                             device=dev)}[form]
+        for _ in range(2):   # first pass: code-object loads, allocator growth, RCCL's peer connections; second: measured
+            D.fence()
+            t0 = time.perf_counter()
+            res = fn()
+            D.fence()
+            dt = D.max_over_ranks(time.perf_counter() - t0)
+        return res, dt
+    (local, my_views, info), dist_s = distribute("batched")
+    sc_out = {"assignment": "contiguous blocks of views", "form": "batched: one filter, one pack, all sends posted as one group",
+              "rows_per_rank": info["counts"],
               "bytes_per_rank": info["bytes"], "filter_ms": round(info["filter_ms"], 3), "pack_ms": round(info["pack_ms"], 3),
               "comm_ms": round(D.max_over_ranks(info["comm_ms"]), 3), "distribution_ms": round(dist_s * 1e3, 3)}
+    if D.multi:
+        # the two pipelined forms beside it (DESIGN.md "Multi-GPU"): which one a node prefers is for this record to say
+        for form in ("pipelined", "blockwise"):
+            (_, _, inf2), d2 = distribute(form)
+            sc_out["distribution_ms_" + form] = round(d2 * 1e3, 3)
 
     def sweep_local():
         return views.render_views_sharded(pack, local, bg, deg, rank=D.rank, world=D.world, batch=16, views=my_views)
@@ -509,10 +538,13 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
         D.fence()
         times.append(D.max_over_ranks(time.perf_counter() - t0))
     t = sorted(times)[len(times) // 2]
+    rows_local = int(local["means3D"].shape[0])
+    alg_local = sum(D.gather_ints(len(my_views) * ((187 + 12 * M) * rows_local + 24 * W * H))) + 48 * R_all
     sc_out["views_per_call_16"] = {"sweep_ms": round(t * 1e3, 3),
                                    "ms_per_view_per_rank": round(t / max(len(my_views), 1) * 1e3, 4),
                                    "value": round(n_views * P / t / 1e6, 1),
-                                   "value_including_distribution": round(n_views * P / (t + dist_s) / 1e6, 1)}
+                                   "value_including_distribution": round(n_views * P / (t + dist_s) / 1e6, 1),
+                                   "roofline_frac_algorithmic": round(alg_local / t / 1e9 / (HBM_PEAK_GBS * D.world), 5)}
     out["scatter_visible"] = sc_out
     # ---- stated model for the first SCALE record to be checked against (views.modelled_scatter_sweep): the source filters,
     # then packs and sends rank by rank (remote ranks first, own block last); every rank renders from its arrival on.
@@ -533,14 +565,30 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                 "ms_per_view_broadcast_path": per_view_bcast_ms, "filter_ms": round(info["filter_ms"], 4),
                 "pack_ms_per_million_rows": round(pack_per_row * 1e6, 4)}
         t1 = n_views * per_view_ms
+
+        def filter_block_ms(block):
+            """one launch of the visibility filter for ONE view block (what the blockwise source runs per rank), GPU time"""
+            if not block:
+                return 0.0
+            views.group_visibility(pack, bufs["means3D"], bufs["scales"], bufs["rotations"], [block])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                views.group_visibility(pack, bufs["means3D"], bufs["scales"], bufs["rotations"], [block])
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / 3
         for w in (1, 2, 4, 8):
             def model(sizes, pipelined=True):
                 rr = views.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", sizes=sizes)[w]
+                fb = [filter_block_ms(views.assign_views(n_views, r, w, "contiguous", sizes=sizes)) for r in range(w)] \
+                    if pipelined == "blocks" else None
                 return rr, views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
-                                                        per_view_ms, LINK_GBS, pipelined=pipelined)
+                                                        per_view_ms, LINK_GBS, pipelined=pipelined, filter_block_ms=fb)
             even_sizes = views.staggered_block_sizes(n_views, w)
             rows_even, even = model(even_sizes)
             _, batched = model(even_sizes, pipelined=False)
+            _, blocks = model(even_sizes, pipelined="blocks") if w > 1 else (None, even)
             # uneven blocks: a rank whose rows leave late gets fewer views (views.balanced_block_sizes).  A block's rows
             # (hence its pack and wire time) depend on its size, so the split is iterated: leave times from the previous
             # split's rows -> new split, three rounds.
@@ -560,6 +608,9 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                 "sweep_ms_scatter": round(even["sweep_ms"], 3), "speedup_scatter": round(t1 / even["sweep_ms"], 2),
                 "critical_rank": even["critical_rank"],
                 "sweep_ms_scatter_unpipelined": round(batched["sweep_ms"], 3),
+                # the source pipelined block by block (scatter_visible_gaussians_blockwise), even blocks
+                "sweep_ms_scatter_blockwise": round(blocks["sweep_ms"], 3),
+                "speedup_scatter_blockwise": round(t1 / blocks["sweep_ms"], 2),
                 # uneven contiguous blocks (scatter_visible_gaussians(sizes=...)): ranks served late render fewer views
                 "balanced": {"views_per_rank": sizes, "rows_per_rank": rows_b, "sweep_ms_scatter": round(bal["sweep_ms"], 3),
                              "speedup_scatter": round(t1 / bal["sweep_ms"], 2), "critical_rank": bal["critical_rank"],
@@ -572,6 +623,18 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                 # ceil(views / N) views per rank, no exchange at all
                 "sweep_ms_resident": round(t_render, 3),
                 "speedup_resident": round(n_views * per_view_ms / t_render, 2)}
+        # Is north_star's >= 6x at 8 GPUs reachable COLD (Gaussians on one rank when the clock starts) for this preset?
+        # No schedule can beat: one block's filter launch + its pack + its wire time + an eighth of the rendering.
+        p8 = pred["8"]
+        rows8 = p8["balanced"]["rows_per_rank"]
+        fb_min = filter_block_ms(views.assign_views(n_views, 1, 8, "contiguous"))
+        floor8 = fb_min + min(rows8[1:]) * (pack_per_row + row_bytes / (LINK_GBS * 1e6)) + n_views / 8 * per_view_ms
+        best8 = min(p8["sweep_ms_scatter"], p8["balanced"]["sweep_ms_scatter"], p8["sweep_ms_scatter_blockwise"])
+        pred["cold_6x_at_8_gpus"] = {
+            "needed_sweep_ms": round(t1 / 6, 3), "modelled_best_ms": round(best8, 3), "modelled_best_speedup": round(t1 / best8, 2),
+            "floor_ms": round(floor8, 3), "floor_speedup": round(t1 / floor8, 2), "reachable": bool(t1 / floor8 >= 6.0),
+            "why": ("rendering an eighth of the views takes %.3f ms of the %.3f ms a 6x sweep may take; one block's filter + pack "
+                    "+ wire alone need %.3f ms" % (n_views / 8 * per_view_ms, t1 / 6, floor8 - n_views / 8 * per_view_ms))}
         out["predicted"] = pred
     del bufs, local
     torch.cuda.empty_cache()
@@ -665,6 +728,10 @@ def main():
         keep = ("workload", "views", "views_per_rank", "broadcast_ms", "views_per_call_16", "views_per_call_16_compacted",
                 "scatter_visible", "predicted")
         c4["preset_180_views"] = c4_180 if "error" in c4_180 else {k: c4_180[k] for k in keep if k in c4_180}
+        # the camera path the reference SHIPS and render_video loads (cameras/rotate360.json via utils/camera.py:23-51,
+        # bloomscene.py:181): 720 frames, half a degree apart
+        c4_720 = guarded(c4_sweep, D, args, n_views=720, repeats=2)
+        c4["preset_720_views"] = c4_720 if "error" in c4_720 else {k: c4_720[k] for k in keep if k in c4_720}
     secondary = None
     if D.world == 1 and headline and not args.no_secondary:
         sec_steps = max(20, args.steps // 2)

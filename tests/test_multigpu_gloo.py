@@ -131,6 +131,65 @@ def test_pipelined_scatter_world4_and_the_batched_form():
         assert sorted(results) == [(r, True) for r in range(world)], (world, pipelined, src_fewer, results)
 
 
+def _blockwise_worker(rank, world, port, q, src_fewer, with_layout):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, M = 3000, 4
+        g = torch.Generator().manual_seed(4321)
+        src = {"means3D": torch.randn(P, 3, generator=g), "scales": torch.rand(P, 3, generator=g),
+               "rotations": torch.randn(P, 4, generator=g), "opacities": torch.rand(P, 1, generator=g),
+               "shs": torch.randn(P, M, 3, generator=g)}
+        masks = torch.rand(world, P, generator=g) < torch.tensor([[0.1], [0.3], [0.0], [0.2]])[:world]   # rank 2: nothing visible
+        cams = [helpers.scene_b(1, 64, 48, 0, n_views=10).cameras[i] for i in range(10)]
+        layout = {k: tuple(v.shape[1:]) for k, v in src.items()} if with_layout else None
+        local, mine, info = views.scatter_visible_gaussians_blockwise(
+            src if rank == 0 else None, cams, src=0, masks=masks if rank == 0 else None, src_fewer=src_fewer, layout=layout)
+        ok = mine == views.assign_views(10, rank, world, "contiguous", 0, src_fewer)
+        if rank == 0:   # every peer gets its header (also the one that sees nothing), in rank order; own block last
+            ok = ok and info["send_order"] == list(range(1, world)) and info["counts"] == [int(m.sum()) for m in masks]
+        else:
+            ok = ok and info["counts"][rank] == int(masks[rank].sum())
+        ok = ok and info["pipelined"] == "blocks"
+        for k, v in src.items():
+            ok = ok and torch.equal(local[k], v[masks[rank]]) and local[k].is_contiguous()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_blockwise_scatter_world4():
+    """scatter_visible_gaussians_blockwise (the source filters, packs and sends ONE view block at a time, an 8-byte
+    header ahead of every peer's rows) over gloo with four ranks: the same rows on every rank as the batched form, with
+    and without the static layout handed to the peers (no collective in front of the sends), even and uneven blocks."""
+    for world, src_fewer, with_layout in ((4, 0, False), (4, 2, True), (2, 1, True)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_blockwise_worker, args=(r, world, port, q, src_fewer, with_layout)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(results) == [(r, True) for r in range(world)], (world, src_fewer, with_layout, results)
+
+
+def test_modelled_blockwise_sweep():
+    """The stated critical path of the blockwise pipeline: F(1) F(2) P(1) F(3) P(2) ... on the source's stream."""
+    rows, sizes = [100, 200, 300], [2, 3, 3]
+    m = views.modelled_scatter_sweep(8, 3, rows, sizes, filter_ms=9.0, pack_ms_per_row=0.01, row_bytes=100, per_view_ms=1.0,
+                                     link_GBs=0.1, pipelined="blocks", filter_block_ms=[0.5, 0.25, 0.125])
+    # order 1, 2, 0: t = F1 + F2 = 0.375; + P1 = 2.375 -> rank 1 leaves; + F0 = 2.875; + P2 = 5.875 -> rank 2 leaves; + P0 = 6.875
+    wire = [r * 100 / (0.1 * 1e6) for r in rows]
+    assert abs(m["finish_ms"][1] - (2.375 + wire[1] + 3.0)) < 1e-9
+    assert abs(m["finish_ms"][2] - (5.875 + wire[2] + 3.0)) < 1e-9
+    assert abs(m["finish_ms"][0] - (6.875 + 2.0)) < 1e-9
+    assert m["critical_rank"] == max(range(3), key=lambda r: m["finish_ms"][r])
+
+
 def test_view_assignments():
     # uneven contiguous blocks: the distributing rank takes fewer views, its peers share them out; still a partition
     assert views.staggered_block_sizes(64, 8, 0, 0) == [8] * 8
