@@ -276,8 +276,11 @@ def timed_steps(D, step, steps, warmup, stage_events=True, dominant=None, prewar
 
 
 def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0, cycle_views=1, steps=None, warmup=None,
-                    label="c3", allreduce=False, depth_gradient=False):
-    """fwd(+bwd) steps of the rasterizer on scene A; returns the measurements of this rank (rank 0's are printed)."""
+                    label="c3", allreduce=False, depth_gradient=False, mode="default"):
+    """fwd(+bwd) steps of the rasterizer on scene A; returns the measurements of this rank (rank 0's are printed).
+    ``mode``: "default" (the reference's call: the forward blocks on the read-back of num_rendered); "capacity"
+    (GaussianRasterizer(capacity=1.25 R + 4096): BSR_FLAG_NO_READBACK, the host never waits); "graph" (the capacity-mode
+    step captured once into a HIP graph and replayed).  Secondary legs only: the metric is quoted on "default"."""
     from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer
     from bloomscene_amd.synthetic import scene_a, upstream_grads
     from bloomscene_amd.views import allreduce_gradients, broadcast_gaussians, yawed_camera
@@ -314,6 +317,16 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
         rasterizers.append(GaussianRasterizer(st, depth_gradient=depth_gradient))
     leaves = {k: v.requires_grad_(do_bwd) for k, v in bufs.items()}
     state = {"i": 0}
+    if mode != "default":
+        from bloomscene_amd.rasterizer import _rasterize_gaussians_native as _fwd0
+        e0 = torch.Tensor([])
+        s00 = rasterizers[0].raster_settings
+        with torch.no_grad():
+            R0 = _fwd0(s00.bg, bufs["means3D"], bufs["shs"] if precomp else e0, bufs["opacities"], bufs["scales"],
+                       bufs["rotations"], 1.0, e0, s00.viewmatrix, s00.projmatrix, s00.tanfovx, s00.tanfovy, H, W,
+                       e0 if precomp else bufs["shs"], deg, s00.campos, False, False)[0]
+        for r_ in rasterizers:
+            r_.capacity = int(1.25 * R0) + 4096
 
     def step():
         rasterizer = rasterizers[state["i"] % len(rasterizers)]
@@ -333,8 +346,28 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
 
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
+    if mode == "graph":
+        # the capacity-mode step holds no host wait and no call that is illegal during capture: warm it up on a side
+        # stream (allocator, pinned buffer, events), capture it once, replay it
+        from bloomscene_amd.rasterizer import check_deferred
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        check_deferred()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        eager_step, step = step, graph.replay
     tm = timed_steps(D, step, steps, warmup, dominant="render_bwd" if do_bwd else "render_fwd",
-                     prewarm_ms=args.prewarm_ms if label == args.config else 0.0)
+                     prewarm_ms=args.prewarm_ms if label == args.config else 0.0,
+                     stage_events=mode != "graph")
+    if mode == "capacity":
+        from bloomscene_amd.rasterizer import check_deferred
+        check_deferred()   # (raises if a frame of the timed region overflowed its capacity)
     # instances of this rank's first view, for the algorithmic byte count
     from bloomscene_amd.rasterizer import _rasterize_gaussians_native
     e = torch.Tensor([])
@@ -365,7 +398,9 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
                        f"{'fwd+bwd colour+depth targets' if do_bwd else 'fwd only'}"
                        f"{' WITH depth gradient (extension)' if depth_gradient and do_bwd else ''}, synthetic scene A seed 0"
                        + (f", all scales x{scale_mul:g}" if scale_mul != 1.0 else "")
-                       + (f", camera changes every step ({cycle_views} views, 1 degree apart)" if cycle_views > 1 else "")}
+                       + (f", camera changes every step ({cycle_views} views, 1 degree apart)" if cycle_views > 1 else "")
+                       + ({"default": "", "capacity": "; capacity mode (BSR_FLAG_NO_READBACK: no host wait)",
+                           "graph": "; the capacity-mode step replayed from a HIP graph"}[mode])}
     del leaves, bufs, rasterizers
     torch.cuda.empty_cache()
     return res
@@ -376,13 +411,15 @@ def secondary_line(r):
     whole = r["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9
     return {"workload": r["workload"], "value": round(r["value"], 2), "unit": "Msplats/s",
             "ms_per_step": round(r["ms_per_step"], 4), "ms_per_step_median": round(r["ms_per_step_median"], 4),
+            "step_ms_first": round(r["step_ms_first"], 4), "step_ms_max": round(r["step_ms_max"], 4),
+            "steps_over_1p15x_median": r["steps_over_1p15x_median"], "host_max_ms_per_step": round(r["max_host_ms"], 3),
             "steps": r["steps"], "num_rendered": r["R"], "instances_per_gaussian": round(r["R"] / max(r["visible"], 1), 2),
             "roofline_step_frac": round(whole / HBM_PEAK_GBS, 5),
             "stage_ms": {k: round(v, 4) for k, v in r["stages"].items()},
             "device_allocs_in_timed_region": r["device_allocs"]}
 
 
-def bloomscene_shape_workload(D, args, n_anchor=100_000, n_offsets=10, W=512, H=512):
+def bloomscene_shape_workload(D, args, n_anchor=100_000, n_offsets=10, W=512, H=512, mode="default"):
     """BloomScene's real call shape (arguments.py:8,102; gaussian_renderer/__init__.py:165-203,244-262): anchors x 10
     candidate Gaussians through the fused anchor expansion into the rasterizer with colors_precomp and sh_degree = 1,
     512 x 512, forward + backward w.r.t. all six head outputs.  Msplats/s counts the SELECTED Gaussians."""
@@ -397,20 +434,57 @@ def bloomscene_shape_workload(D, args, n_anchor=100_000, n_offsets=10, W=512, H=
     gC, gD = gC.to(dev), gD.to(dev)
     bg = torch.zeros(3, device=dev)
     state = {}
+    # "capacity": static shapes, no host wait (neural_gaussians.render_anchors(capacity=...): every per-Gaussian output
+    # has n_anchor * n_offsets rows, the selection count stays on the device); "graph": that step replayed from a HIP graph
+    settings = views.make_settings(cam, bg, 1)
+    capacity = None
+    if mode != "default":
+        # the capacity a training loop would carry along: 1.25 x the instance count of a previous frame (here: probed once)
+        from bloomscene_amd.neural_gaussians import expand_anchors
+        from bloomscene_amd.rasterizer import _rasterize_gaussians_native
+        with torch.no_grad():
+            xyz, rgb, opac, scal, rot, _ = expand_anchors(*[leaves[k].detach() for k in names])
+            e = torch.Tensor([])
+            R0 = _rasterize_gaussians_native(settings.bg, xyz, rgb, opac, scal, rot, 1.0, e, settings.viewmatrix,
+                                             settings.projmatrix, settings.tanfovx, settings.tanfovy, H, W, e, 1, settings.campos,
+                                             False, False)[0]
+        capacity = int(1.25 * R0) + 4096
+        del xyz, rgb, opac, scal, rot
 
     def step():
         for v in leaves.values():
             v.grad = None
-        res = views.render_neural(cam, *[leaves[k] for k in names], bg)
+        res = views.render_neural(cam, *[leaves[k] for k in names], bg, capacity=capacity, settings=settings)
         torch.autograd.backward((res["render"], res["depth"]), (gC, gD))
         state["radii"] = res["radii"]
+        state["mask"] = res["selection_mask"]
 
     steps = max(20, args.steps // 2)
-    tm = timed_steps(D, step, steps, max(3, args.warmup // 2))
-    S = int(state["radii"].numel())
+    if mode == "graph":
+        from bloomscene_amd.rasterizer import check_deferred
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        check_deferred()
+        state.clear()          # (no output of an earlier iteration may outlive into the capture: torch's AccumulateGrad rule)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        step = graph.replay
+    tm = timed_steps(D, step, steps, max(3, args.warmup // 2), stage_events=mode != "graph")
+    if mode == "capacity":
+        from bloomscene_amd.rasterizer import check_deferred
+        check_deferred()
+    S = int(state["mask"].sum().item())
     ms = tm["seconds"] / steps * 1e3
     return {"workload": f"bloomscene-shaped: {n_anchor} anchors x {n_offsets} offsets -> {S} selected Gaussians, fused "
-                        f"expansion + rasterizer (colors_precomp, sh_degree 1), {W}x{H}, fwd+bwd to the six head outputs",
+                        f"expansion + rasterizer (colors_precomp, sh_degree 1), {W}x{H}, fwd+bwd to the six head outputs"
+                        + {"default": "", "capacity": "; static shapes, no host wait (BSR_FLAG_NO_READBACK)",
+                           "graph": "; the static-shape step replayed from a HIP graph"}[mode],
             "value": round(S * steps / tm["seconds"] / 1e6, 2), "unit": "Msplats/s (selected Gaussians)",
             "ms_per_step": round(ms, 4), "ms_per_step_median": round(tm["median_ms"], 4), "steps": steps,
             "visible": int((state["radii"] > 0).sum().item()),
@@ -741,6 +815,22 @@ def main():
             "c3_camera_changes_every_step": secondary_line(raster_workload(D, args, P, W, H, deg, True, cycle_views=8,
                                                                            steps=sec_steps, label="c3-cycling")),
             "bloomscene_shape": bloomscene_shape_workload(D, args),
+            "bloomscene_shape_no_host_wait": bloomscene_shape_workload(D, args, mode="capacity"),
+            "bloomscene_shape_hip_graph": bloomscene_shape_workload(D, args, mode="graph"),
+            # the forward without its host wait (include/bloomscene_rast.h BSR_FLAG_NO_READBACK), and the whole step as a
+            # HIP graph: the headline workload, and the rasterizer alone at BloomScene's call shape (500 k selected
+            # Gaussians, colors_precomp, sh_degree 1, 512 x 512) where launch gaps and the wait are a larger share
+            # (the headline workload once more, in the same place of the process as the two legs below: legs late in the
+            # run are ~4 % slower than the first one on every box -- compare the three with each other)
+            "c3_default_again": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
+                                                               label="c3-again")),
+            "c3_capacity_mode": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
+                                                               label="c3-capacity", mode="capacity")),
+            "c3_hip_graph_replay": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
+                                                                  label="c3-graph", mode="graph")),
+            "raster_512_precomp": {m: secondary_line(raster_workload(D, args, 500_000, 512, 512, 1, True, precomp=True,
+                                                                     steps=sec_steps, label="512-" + m, mode=m))
+                                   for m in ("default", "capacity", "graph")},
         }
 
     if D.rank == 0:

@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _F = C.c_void_p  # device pointer
+ABI_VERSION = 3  # BSR_VERSION of include/bloomscene_rast.h this binding was written against
 
 
 class StageProfile(C.Structure):
@@ -65,6 +66,8 @@ SIGNATURES = {
     "bsr_backward_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _F, C.c_int, C.c_int, _F, _F, _F, _F, C.c_float,
                                   _F, _F, _F, _F, _F, C.c_float, C.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F,
                                   _F, _F, _F, _F, _F, _F, C.c_int, C.c_void_p, C.c_uint]),
+    "bsr_read_counts": (C.c_int, [_F, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bsr_check_deferred": (C.c_int, []),
     "bsr_geometry_bytes": (C.c_size_t, [C.c_int]),
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -109,6 +112,12 @@ def lib():
                 f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
                 "bloomscene_amd has no CPU fallback.")
         handle = C.CDLL(LIB_PATH)
+        # a stale build of another ABI version would shift arguments silently (several entry points changed their
+        # parameter lists in place between versions): refuse it before binding anything
+        handle.bsr_version.restype = C.c_int
+        if handle.bsr_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is ABI version {handle.bsr_version()}, this binding needs {ABI_VERSION}: "
+                               f"rebuild it (make -C {CSRC})")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

@@ -386,6 +386,24 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected, c
 //   rot[S,4] 0 | xyz[S,3] 4S | color[S,3] 7S | scaling[S,3] 10S | opacity[S] 13S | radii[S] 14S          (15 S words)
 // and of the gradient scratch the backward fills:
 //   dL_drot[S,4] 0 | dL_dxyz[S,3] 4S | dL_dcolor[S,3] 7S | dL_dscaling[S,3] 10S | dL_dopacity[S] 13S | dL_dmean2D[S,3] 14S   (17 S)
+// BSR_FLAG_NO_READBACK: the packed buffer holds n_cand rows per section whatever the selection; rows [S, n_cand) (S on
+// the device: the scan's grand total) become Gaussians no view can see -- centre AT the camera (view-space z = 0: behind
+// the near plane, auxiliary.h:154), opacity 0 -- so the rasterizer culls them in its first test and their gradient rows
+// are zeros.
+__global__ void __launch_bounds__(256) k_anchor_pad(int n_cand, const uint32_t* __restrict__ total, const float* __restrict__ cam_pos,
+                                                    float* __restrict__ xyz, float* __restrict__ rgb, float* __restrict__ opacity,
+                                                    float* __restrict__ scaling, float* __restrict__ rot)
+{
+	const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_cand || i < (long long)*total) return;
+	const float cx = cam_pos[0], cy = cam_pos[1], cz = cam_pos[2];
+	xyz[3 * i] = cx; xyz[3 * i + 1] = cy; xyz[3 * i + 2] = cz;
+	rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = 0.f;
+	scaling[3 * i] = scaling[3 * i + 1] = scaling[3 * i + 2] = 0.f;
+	opacity[i] = 0.f;
+	rot[4 * i] = 1.f; rot[4 * i + 1] = rot[4 * i + 2] = rot[4 * i + 3] = 0.f;
+}
+
 size_t bsr_anchor_gaussian_bytes(int num_selected) { return (size_t)(num_selected > 0 ? num_selected : 0) * 15 * sizeof(float); }
 size_t bsr_anchor_gradient_bytes(int num_selected) { return (size_t)(num_selected > 0 ? num_selected : 0) * 17 * sizeof(float); }
 
@@ -400,8 +418,41 @@ int bsr_anchor_render_forward(int n_anchors, int n_offsets, const float* anchor,
                               int* num_selected, int* num_rendered, unsigned flags)
 {
 	if (!num_selected || !num_rendered) return fail("bsr_anchor_render_forward: num_selected / num_rendered is NULL");
-	*num_rendered = 0;
 	if (!gaussianBuffer) return fail("bsr_anchor_render_forward: gaussianBuffer callback is NULL");
+	if (flags & BSR_FLAG_NO_READBACK) {
+		// Static shapes, no host wait at all (include/bloomscene_anchors.h): every section of the packed buffer has
+		// n_anchors * n_offsets rows, the selection stays on the device, the rows behind it are padded with invisible
+		// Gaussians, and the rasterizer runs in its capacity mode on all of them.
+		Partition p;
+		if (!make_partition(n_anchors, n_offsets, &p))
+			return fail("bsr_anchor_render_forward: need 0 < n_offsets <= %d and n_anchors * n_offsets < 2^31", BSR_ANCHOR_BLOCK);
+		if (p.n_cand == 0) return fail("bsr_anchor_render_forward: BSR_FLAG_NO_READBACK needs at least one candidate");
+		if (!neural_opacity || !mask || !anchor_scratch || !cam_pos) return fail("bsr_anchor_render_forward: NULL buffer");
+		const int S_cap = (int)p.n_cand;
+		float* g = (float*)gaussianBuffer(gaussian_user, bsr_anchor_gaussian_bytes(S_cap));
+		if (!g) return fail("bsr_anchor_render_forward: gaussianBuffer returned null");
+		if (((uintptr_t)g & 15) != 0) return fail("bsr_anchor_render_forward: gaussianBuffer must be 16-byte aligned");
+		hipStream_t st = (hipStream_t)stream;
+		uint32_t* wg = (uint32_t*)anchor_scratch;
+		hipLaunchKernelGGL(k_anchor_select, dim3(p.n_wg), dim3(BSR_ANCHOR_BLOCK), 0, st, (int)p.n_cand, p.per_wg,
+		                   neural_opacity, mask, wg);
+		hipLaunchKernelGGL(k_anchor_scan, dim3(1), dim3(1024), 0, st, p.n_wg, wg);
+		const size_t sc = (size_t)S_cap;
+		float* rot = g, *xyz = g + 4 * sc, *rgb = g + 7 * sc, *scaling = g + 10 * sc, *opacity = g + 13 * sc;
+		int* radii = (int*)(g + 14 * sc);
+		if (bsr_anchor_expand(n_anchors, n_offsets, S_cap, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot,
+		                      anchor_scratch, xyz, rgb, opacity, scaling, rot, stream))
+			return 1;
+		hipLaunchKernelGGL(k_anchor_pad, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, st, S_cap, wg + p.n_wg, cam_pos, xyz, rgb,
+		                   opacity, scaling, rot);
+		if (hipGetLastError() != hipSuccess) return fail("bsr_anchor_render_forward: launch failed");
+		*num_selected = S_cap;   // rows of every section = what the backward must be handed as num_selected
+		return bsr_forward_ex(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, S_cap, 1, 0,
+		                      background, width, height, xyz, nullptr, rgb, opacity, scaling, scale_modifier, rot, nullptr,
+		                      viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, radii, debug, stream,
+		                      num_rendered, flags);
+	}
+	*num_rendered = 0;
 	// While the GPU counts, ask for the S-sized buffer with a GUESS (the calling thread's previous selection of this
 	// shape + 25 %, as the forward sizes its binning scratch): the callback -- interpreter time on the python host --
 	// then runs beside the selection kernels instead of behind the blocking read.  A guess that turns out short costs

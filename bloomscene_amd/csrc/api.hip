@@ -106,9 +106,12 @@ struct SyncCache {
 	                             // [5] = error flag a prefiltered bsr_visible_filter kernel writes straight into host memory
 	int* pinned_dev = nullptr;   // the same buffer as the device addresses it
 	hipEvent_t copied = nullptr;
+	hipEvent_t deferred = nullptr;   // behind the counters' copy of a BSR_FLAG_NO_READBACK forward (waited for by the NEXT call)
 	int device = -1;
 	int last_P = -1, last_W = -1, last_H = -1, last_V = -1;
 	uint32_t last_R = 0;
+	bool pending = false;        // a BSR_FLAG_NO_READBACK forward's copy of the counters is in flight / unchecked
+	size_t pending_capacity = 0;
 };
 static SyncCache* sync_cache()
 {
@@ -117,7 +120,9 @@ static SyncCache* sync_cache()
 	if (hipGetDevice(&dev) != hipSuccess) { fail("hipGetDevice failed"); return nullptr; }
 	if (c.device != dev) {   // first use on this thread, or the thread moved to another GPU
 		if (c.copied) (void)hipEventDestroy(c.copied);
-		c.copied = nullptr;
+		if (c.deferred) (void)hipEventDestroy(c.deferred);
+		c.copied = c.deferred = nullptr;
+		c.pending = false;
 		if (!c.pinned && hipHostMalloc((void**)&c.pinned, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) {
 			c.pinned = nullptr;
 			fail("hipHostMalloc failed");
@@ -128,8 +133,9 @@ static SyncCache* sync_cache()
 			fail("hipHostGetDevicePointer failed");
 			return nullptr;
 		}
-		if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess) {
-			c.copied = nullptr;
+		if (hipEventCreateWithFlags(&c.copied, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&c.deferred, hipEventDisableTiming) != hipSuccess) {
+			c.copied = c.deferred = nullptr;
 			fail("hipEventCreate failed");
 			return nullptr;
 		}
@@ -153,6 +159,21 @@ int read_u32_blocking(const uint32_t* dev, uint32_t* out, hipStream_t s)
 	return 0;
 }
 
+// Deferred overflow check of the calling thread's last BSR_FLAG_NO_READBACK forward (include/bloomscene_rast.h).
+static int check_deferred(SyncCache* sc)
+{
+	if (!sc->pending) return 0;
+	sc->pending = false;
+	if (hipEventSynchronize(sc->deferred) != hipSuccess)
+		return fail("waiting for the counters of the previous no-readback forward failed: %s", hipGetErrorString(hipGetLastError()));
+	const uint32_t kept = (uint32_t)sc->pinned[2];
+	if ((size_t)kept > sc->pending_capacity)
+		return fail("the previous BSR_FLAG_NO_READBACK forward of this thread kept %u tile instances but was given a capacity "
+		            "of %zu: that frame was not rendered (NaN outputs); its num_rendered was %u",
+		            kept, sc->pending_capacity, (uint32_t)sc->pinned[3]);
+	return 0;
+}
+
 // ---------------------------------------------------------------- kernels (other translation units)
 void launch_preprocess(const PreArgs& a, bool filter_only, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
@@ -173,7 +194,7 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, bool exact_exp, hipStream_t s);
+                       float* out_depth, bool exact_exp, bool nan_on_overflow, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
@@ -333,10 +354,26 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
-	if (num_rendered) *num_rendered = 0;
 	// (BSR_FLAG_EXACT_GRAD concerns the backward alone: accepted here so that a caller can hand one word to both)
-	if (flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD))
-		return fail("forward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD));
+	if (flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD | BSR_FLAG_NO_READBACK)) {
+		if (num_rendered) *num_rendered = 0;
+		return fail("forward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD | BSR_FLAG_NO_READBACK));
+	}
+	const bool no_readback = (flags & BSR_FLAG_NO_READBACK) != 0;
+	const long long given_capacity = (no_readback && num_rendered) ? (long long)*num_rendered : 0;
+	if (num_rendered) *num_rendered = 0;
+	if (no_readback) {
+		if (V != 1) return fail("BSR_FLAG_NO_READBACK is for single-view calls");
+		if (prefiltered) return fail("BSR_FLAG_NO_READBACK cannot be combined with prefiltered (its violation flag is part of the read-back)");
+		if (!num_rendered || given_capacity <= 0)
+			return fail("BSR_FLAG_NO_READBACK: *num_rendered must hold the capacity (tile instances, > 0) on entry");
+	}
+	{   // the deferred status of this thread's previous no-readback forward comes first
+		SyncCache* sc0 = sync_cache();
+		if (!sc0) return 1;
+		if (check_deferred(sc0)) return 1;
+	}
+	if (no_readback) *num_rendered = (int)given_capacity;   // what the backward must be handed as R (same carve)
 	if (P == 0) {   // reference rasterize_points.cu:68-82: zero images, no scratch, num_rendered = 0
 		if (width <= 0 || height <= 0 || !out_color || !out_depth) return fail("invalid image outputs");
 		HIP_TRY(hipMemsetAsync(out_color, 0, (size_t)V * 3 * width * height * sizeof(float), s));
@@ -453,10 +490,26 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			                            ? img.flags + 6 : nullptr;
 			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, masks_flag, geom.rec,
 			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
-			                  (flags & BSR_FLAG_EXACT_EXP) != 0, s);
+			                  (flags & BSR_FLAG_EXACT_EXP) != 0, no_readback, s);
 		}
 		return 0;
 	};
+	if (no_readback) {
+		// The caller's capacity sizes the scratch; nothing is waited for.  The counters still travel to the pinned buffer
+		// (checked by this thread's next forward / bsr_check_deferred) unless the stream is capturing: an event recorded
+		// into a graph cannot be waited for on the host.
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+		if (cs == hipStreamCaptureStatusNone) {
+			HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+			HIP_TRY(hipEventRecord(sc->deferred, s));
+			sc->pending = true;
+			sc->pending_capacity = (size_t)given_capacity;
+		}
+		if (run_tail((size_t)given_capacity, false)) return 1;
+		STAGE_CHECK("render_fwd", debug, s);
+		return 0;
+	}
 	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
 	HIP_TRY(hipEventRecord(sc->copied, s));
 	if (guess) {
@@ -510,6 +563,28 @@ size_t bsr_image_bytes(int W, int H)
 {
 	const size_t gx = (W + BSR_TILE - 1) / BSR_TILE, gy = (H + BSR_TILE - 1) / BSR_TILE;
 	return ImgState::bytes((size_t)W * H, gx * gy);
+}
+
+int bsr_check_deferred(void)
+{
+	g_err[0] = 0;
+	SyncCache* sc = sync_cache();
+	if (!sc) return 1;
+	return check_deferred(sc);
+}
+
+int bsr_read_counts(const char* image_buffer, int width, int height, void* stream, int* kept, int* num_rendered)
+{
+	g_err[0] = 0;
+	if (!image_buffer || width <= 0 || height <= 0) return fail("bsr_read_counts: invalid image buffer / size");
+	const size_t gx = (width + BSR_TILE - 1) / BSR_TILE, gy = (height + BSR_TILE - 1) / BSR_TILE;
+	ImgState img = ImgState::carve(const_cast<char*>(image_buffer), (size_t)width * height, gx * gy);
+	uint32_t k = 0, r = 0;
+	if (read_u32_blocking((const uint32_t*)(img.flags + 2), &k, (hipStream_t)stream)) return 1;
+	if (read_u32_blocking((const uint32_t*)(img.flags + 3), &r, (hipStream_t)stream)) return 1;
+	if (kept) *kept = (int)k;
+	if (num_rendered) *num_rendered = (int)r;
+	return 0;
 }
 
 int bsr_set_option(const char* name, int value)
@@ -803,8 +878,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 {
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
-	if (flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP))
-		return fail("backward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP));
+	// (the forward's flags are accepted and ignored, so that a caller can hand one word to both calls)
+	if (flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK))
+		return fail("backward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK));
 	if (P == 0) return 0;
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
 	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("scratch buffer is null");

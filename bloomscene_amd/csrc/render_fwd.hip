@@ -45,7 +45,7 @@ __device__ unsigned long long g_fwd_times[4 * 70000];
 #endif
 template <int NS, int FB, bool EXACT>
 __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
-                                                          const int* __restrict__ n_ptr, int capacity,
+                                                          const int* __restrict__ n_ptr, int capacity, int nan_on_overflow,
                                                           const uint32_t* __restrict__ tile_start,
                                                           uint32_t* point_list, int* __restrict__ masks_flag,
                                                           const float4* __restrict__ rec,
@@ -64,7 +64,23 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 	const int n_instances = *n_ptr;
 	const uint32_t start = tile_start[tile];
 	const uint32_t end = tile_start[tile + 1];
-	if (n_instances > capacity) return;   // launched ahead of the host's read-back with too small a scratch: re-run follows
+	if (n_instances > capacity) {
+		// launched ahead of the host's read-back with too small a scratch: the default path re-runs the tail.  A
+		// BSR_FLAG_NO_READBACK call has no re-run: its frame says so itself (NaN), never a stale or half-written image
+		if (nan_on_overflow) {
+			const int tx = tile % gx, ty = tile / gx;   // (single-view calls only)
+			const int px = tx * BSR_TILE + (threadIdx.x & 15), py = ty * BSR_TILE + (threadIdx.x >> 4);
+			if (px < W && py < H) {
+				const size_t plane = (size_t)H * W, pix_id = (size_t)W * py + px;
+				const float nan = __builtin_nanf("");
+				out_color[pix_id] = nan;
+				out_color[plane + pix_id] = nan;
+				out_color[2 * plane + pix_id] = nan;
+				out_depth[pix_id] = nan;
+			}
+		}
+		return;
+	}
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave-uniform: kept on the scalar side)
 	// Hand-over to the backward walk (masks_flag != nullptr: one view, ids below 2^24): the NS = 2 staging below has the
@@ -343,7 +359,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, bool exact, hipStream_t s)
+                       float* out_depth, bool exact, bool nan_on_overflow, hipStream_t s)
 {
 	const int n_tiles = gx * gy * n_views;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
@@ -354,7 +370,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	const bool split = (long long)capacity >= 48ll * n_tiles;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
 	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_FWD_BATCH, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
-	                   n_ptr, capacity, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth)
+	                   n_ptr, capacity, nan_on_overflow ? 1 : 0, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth)
 	if (split && exact) BSR_LAUNCH_FWD(2, true);
 	else if (split) BSR_LAUNCH_FWD(2, false);
 	else if (exact) BSR_LAUNCH_FWD(1, true);

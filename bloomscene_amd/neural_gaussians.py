@@ -131,7 +131,7 @@ class _NeuralRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                depth_gradient, flags=0):
+                depth_gradient, flags=0, capacity=None):
         from .rasterizer import _Scratch, _dev_f32
         _need_gpu(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot)
         lib = _capi.lib()
@@ -168,7 +168,13 @@ class _NeuralRender(torch.autograd.Function):
 
         gauss_cb = _capi.ALLOC_FN(_alloc_gaussians)
         geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
-        S, R = C.c_int(0), C.c_int(0)
+        # capacity: BSR_FLAG_NO_READBACK -- static shapes (every output has N * K rows, the unselected tail padded with
+        # invisible Gaussians), no host wait for the selection count or for num_rendered
+        if capacity is not None:
+            if int(capacity) <= 0 or N * K == 0:
+                raise RuntimeError("capacity mode needs a positive capacity and at least one candidate")
+            flags = int(flags) | 4
+        S, R = C.c_int(0), C.c_int(int(capacity) if capacity is not None else 0)
         with torch.cuda.device(dev):
             rc = lib.bsr_anchor_render_forward(
                 N, K, _ptr(a), _ptr(gs), _ptr(go), _ptr(no), _ptr(co), _ptr(sr), _ptr(mask), _ptr(scratch),
@@ -241,15 +247,20 @@ class _NeuralRender(torch.autograd.Function):
         ctx.viewspace.grad = grads[14 * S:17 * S].view(S, 3)
         sh = ctx.shapes
         return (d_anchor.view(sh[0]), d_gs.view(sh[1]), d_go.view(sh[2]), d_no.view(sh[3]), d_co.view(sh[4]),
-                d_sr.view(sh[5]), None, None, None)
+                d_sr.view(sh[5]), None, None, None, None)
 
 
 def render_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                   depth_gradient=False, flags=None):
+                   depth_gradient=False, flags=None, capacity=None):
     """-> (image [3,H,W], depth [1,H,W], radii int32 [S], mask bool [N*K], xyz, color, opacity, scaling, rot,
     viewspace_points [S,3]) -- expand_anchors followed by GaussianRasterizer(raster_settings)(colors_precomp=color, ...)
     in one native call each way; after backward ``viewspace_points.grad`` holds the screen-space gradient.
-    ``flags``: BSR_FLAG_* of the call; None = the calling thread's ``numerics(...)`` context."""
+    ``flags``: BSR_FLAG_* of the call; None = the calling thread's ``numerics(...)`` context.
+    ``capacity`` (tile instances; extension): STATIC SHAPES and no host wait (include/bloomscene_anchors.h,
+    BSR_FLAG_NO_READBACK) -- every per-Gaussian output then has N * K rows: the S selected Gaussians first, in the usual
+    order, then padding rows no camera sees (radii 0, zero gradients); S = mask.sum() stays on the device.  The image,
+    the depth and the gradients of the six inputs are bit-identical to the default mode's; a warmed-up forward +
+    backward can be captured into a HIP graph."""
     from .numerics import resolve_flags
     return _NeuralRender.apply(anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, raster_settings,
-                               bool(depth_gradient), resolve_flags() if flags is None else int(flags))
+                               bool(depth_gradient), resolve_flags() if flags is None else int(flags), capacity)

@@ -18,6 +18,8 @@ import torch.nn as nn
 from . import _capi
 from .numerics import FLAG_EXACT_EXP, FLAG_EXACT_GRAD, numerics, resolve_flags  # noqa: F401  (re-exported)
 
+FLAG_NO_READBACK = 4   # BSR_FLAG_NO_READBACK (include/bloomscene_rast.h)
+
 
 def cpu_deep_copy_tuple(input_tuple):  # PYW:17-19
     copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
@@ -86,10 +88,16 @@ def _check_means3D(means3D):
 # ------------------------------------------------------------------ native entry points
 def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                                campos, prefiltered, debug, flags=None):
+                                campos, prefiltered, debug, flags=None, capacity=None):
     """Counterpart of `_C.rasterize_gaussians` = RasterizeGaussiansCUDA (RP:35-117).  ``flags``: the call's numerics
-    (BSR_FLAG_* of include/bloomscene_rast.h); None = the calling thread's `numerics` context (default 0, the fast path)."""
+    (BSR_FLAG_* of include/bloomscene_rast.h); None = the calling thread's `numerics` context (default 0, the fast path).
+    ``capacity`` (tile instances): BSR_FLAG_NO_READBACK -- the caller sizes the binning scratch, the call never waits
+    for the GPU and the returned num_rendered IS the capacity (what the backward must be handed)."""
     flags = resolve_flags() if flags is None else int(flags)
+    if capacity is not None:
+        if int(capacity) <= 0:
+            raise RuntimeError("capacity must be a positive number of tile instances")
+        flags |= FLAG_NO_READBACK
     _check_means3D(means3D)
     if not means3D.is_cuda:
         raise RuntimeError("means3D must be a GPU tensor; bloomscene_amd has no CPU path")
@@ -106,7 +114,7 @@ def _rasterize_gaussians_native(bg, means3D, colors, opacity, scales, rotations,
              cov3D=_dev_f32(cov3D_precomp, "cov3D_precomp", dev), view=_dev_f32(viewmatrix, "viewmatrix", dev),
              proj=_dev_f32(projmatrix, "projmatrix", dev), sh=_dev_f32(sh, "shs", dev),
              campos=_dev_f32(campos, "campos", dev))
-    num_rendered = C.c_int(0)
+    num_rendered = C.c_int(int(capacity) if capacity is not None else 0)
     with torch.cuda.device(dev):
         rc = _capi.lib().bsr_forward_ex(
             geom.callback, None, binning.callback, None, img.callback, None,
@@ -394,13 +402,31 @@ def _pack_rows_native(tensors, idx, idx_stride=1, rows=None, debug=False):
     return _gather_rows_native(tensors, idx, idx_stride, rows, True, debug)
 
 
+def read_counts(image_buffer, image_height, image_width):
+    """(kept, num_rendered) of the forward call that filled ``image_buffer`` (the third scratch tensor the native forward
+    returns / an autograd node saves): bsr_read_counts, blocks on the current stream.  For capacity-mode callers."""
+    kept, R = C.c_int(0), C.c_int(0)
+    dev = image_buffer.device
+    with torch.cuda.device(dev):
+        rc = _capi.lib().bsr_read_counts(image_buffer.data_ptr(), int(image_width), int(image_height), _stream_handle(dev),
+                                         C.byref(kept), C.byref(R))
+    _capi.check(rc, "bsr_read_counts")
+    return kept.value, R.value
+
+
+def check_deferred():
+    """Raises if the calling thread's last capacity-mode forward overflowed its capacity (bsr_check_deferred)."""
+    _capi.check(_capi.lib().bsr_check_deferred(), "deferred check of the previous no-readback forward")
+
+
 # ------------------------------------------------------------------ autograd (PYW:21-156)
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, depth_gradient=False, return_final_T=False, flags=None):
-    """``flags``: BSR_FLAG_* word of this call; None = the calling thread's `numerics(...)` context (default 0)."""
+                        raster_settings, depth_gradient=False, return_final_T=False, flags=None, capacity=None):
+    """``flags``: BSR_FLAG_* word of this call; None = the calling thread's `numerics(...)` context (default 0).
+    ``capacity``: see GaussianRasterizer."""
     out = _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                     cov3Ds_precomp, raster_settings, depth_gradient, return_final_T,
-                                    resolve_flags() if flags is None else int(flags))
+                                    resolve_flags() if flags is None else int(flags), capacity)
     return out if return_final_T else out[:3]
 
 
@@ -408,7 +434,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, depth_gradient=False, return_final_T=False, flags=0):
+                raster_settings, depth_gradient=False, return_final_T=False, flags=0, capacity=None):
         # same argument order as the reference hands to its C++ lib (PYW:60-80)
         args = (
             raster_settings.bg, means3D, colors_precomp, opacities, scales, rotations,
@@ -421,14 +447,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted (PYW:84)
             try:
                 num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
-                    _rasterize_gaussians_native(*args, flags=flags)
+                    _rasterize_gaussians_native(*args, flags=flags, capacity=capacity)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
             num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = \
-                _rasterize_gaussians_native(*args, flags=flags)
+                _rasterize_gaussians_native(*args, flags=flags, capacity=capacity)
 
         # accumulated opacity of the call (extension, GaussianRasterizer.forward(return_alpha=True)): final_T lives in the
         # image buffer, where the library says it is; the view is handed out as a fourth, non-differentiable output
@@ -509,12 +535,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             None,
             None,
             None,
+            None,
         )
         return grads
 
 
 class GaussianRasterizer(nn.Module):  # PYW:172-249
-    def __init__(self, raster_settings, depth_gradient=False, exact_exp=None, strict_gradients=None):
+    def __init__(self, raster_settings, depth_gradient=False, exact_exp=None, strict_gradients=None, capacity=None):
         """``depth_gradient`` (extension, default off = the reference's behaviour): also backpropagate the
         gradient of the depth output.  The reference accepts grad_depth and drops it (backward.cu:457-463,
         539-554), so depth losses never move the Gaussians there; see include/bloomscene_rast.h
@@ -525,8 +552,16 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
         ``exact_exp=True`` -- the pinned exp on every evaluation of the forward blend (bit-equal to the CPU oracle);
         ``strict_gradients=True`` -- the backward tile walk performs the reference's per-pair operations
         (backward.cu:521,527-536,557,561-583), which meets SURVEY.md 8(d)'s elementwise gradient bar at ~1.8x the
-        cost of that kernel."""
+        cost of that kernel.
+
+        ``capacity`` (extension, default None = the reference's behaviour): a number of tile instances.  The reference
+        blocks the host in every forward on the read-back of num_rendered (rasterizer_impl.cu:282) and so does the
+        default path; with a capacity the forward never waits for the GPU (BSR_FLAG_NO_READBACK): the binning scratch is
+        sized for ``capacity``, a frame that needs more comes back as NaN and the NEXT forward of the thread raises
+        (``read_counts(...)`` tells how much was needed).  A warmed-up forward + backward in this mode can be captured
+        into a HIP graph (torch.cuda.graph)."""
         super().__init__()
+        self.capacity = None if capacity is None else int(capacity)
         self.raster_settings = raster_settings
         self.depth_gradient = bool(depth_gradient)
         self.exact_exp = exact_exp
@@ -569,11 +604,12 @@ class GaussianRasterizer(nn.Module):  # PYW:172-249
 
         if not return_alpha:
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                       cov3D_precomp, raster_settings, self.depth_gradient, flags=self._flags())
+                                       cov3D_precomp, raster_settings, self.depth_gradient, flags=self._flags(),
+                                       capacity=self.capacity)
         color, radii, depth, final_T = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
                                                            rotations, cov3D_precomp, raster_settings,
                                                            self.depth_gradient, return_final_T=True,
-                                                           flags=self._flags())
+                                                           flags=self._flags(), capacity=self.capacity)
         return color, radii, depth, (1.0 - final_T).detach()
 
     def visible_filter_indices(self, means3D, scales=None, rotations=None, cov3D_precomp=None):

@@ -551,7 +551,8 @@ def render_view(cam: MiniCam, gaussians: dict, bg_color, sh_degree=0, scaling_mo
 
 
 def render_neural(cam: MiniCam, anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot, bg_color,
-                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False, fused=True):
+                  scaling_modifier=1.0, retain_grad=False, debug=False, depth_gradient=False, fused=True, capacity=None,
+                  settings=None):
     """gaussian_renderer.render for BloomScene's anchor representation (GR:211-291) from the point
     where the MLP heads have produced their outputs: fused anchor expansion (GR:165-203,
     ``neural_gaussians.expand_anchors``) -> rasterizer with ``colors_precomp`` and ``sh_degree=1``
@@ -565,9 +566,11 @@ def render_neural(cam: MiniCam, anchor, grid_scaling, grid_offsets, neural_opaci
     if fused and not debug:
         # one native call for selection + expansion + rasterizer (and one for their backward): no interpreter time
         # between the blocking read of the selection count and the rasterizer's first launch
+        # capacity (extension): static shapes + no host wait, see neural_gaussians.render_anchors; settings: a prebuilt
+        # GaussianRasterizationSettings (a captured step must not build device tensors)
         image, depth, radii, mask, xyz, rgb, opacity, scaling, rot, viewspace = render_anchors(
             anchor, grid_scaling, grid_offsets, neural_opacity, color, scale_rot,
-            make_settings(cam, bg_color, 1, scaling_modifier, debug), depth_gradient)
+            settings or make_settings(cam, bg_color, 1, scaling_modifier, debug), depth_gradient, capacity=capacity)
         return {"render": image, "viewspace_points": viewspace, "visibility_filter": radii > 0, "radii": radii,
                 "depth": depth, "selection_mask": mask, "neural_opacity": neural_opacity, "scaling": scaling}
     # the same as two autograd nodes (what fused=True is tested against, bit for bit).  Everything that does not depend

@@ -85,7 +85,16 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected,
  * selected Gaussians out in it as fp32 words  rot[S,4] at 0 | xyz[S,3] at 4S | color[S,3] at 7S | scaling[S,3] at 10S |
  * opacity[S] at 13S | radii[S] (int32) at 14S,  i.e. the outputs of bsr_anchor_expand and the radii of bsr_forward.
  * The rasterizer call is the reference's: colors_precomp = color, sh_degree 1, prefiltered False (GR:244-262).
- * Everything else as bsr_anchor_select / bsr_anchor_expand / bsr_forward. */
+ * Everything else as bsr_anchor_select / bsr_anchor_expand / bsr_forward.
+ *
+ * flags & BSR_FLAG_NO_READBACK (include/bloomscene_rast.h): STATIC SHAPES, no host wait anywhere -- neither for S nor for
+ * num_rendered.  gaussianBuffer is asked once for bsr_anchor_gaussian_bytes(N * K); every section has N * K rows
+ * (layout above with S = N * K); the S selected Gaussians fill the first rows of each section in the usual order and the
+ * rows behind them are padded with Gaussians no camera can see (centre at cam_pos, opacity 0: culled by the rasterizer's
+ * near-plane test, radii 0, zero gradient rows).  S itself stays on the device (word n_wg of anchor_scratch; the mask
+ * holds the selection).  On entry *num_rendered = the rasterizer's capacity (tile instances); on return *num_selected
+ * = N * K and *num_rendered = that capacity: hand both to bsr_anchor_render_backward.  The frame and every gradient of
+ * the selected rows are bit-identical to the default path's.  Capturable into a hipGraph (after one warm-up call). */
 size_t bsr_anchor_gaussian_bytes(int num_selected);
 int bsr_anchor_render_forward(int n_anchors, int n_offsets,
                               const float* anchor, const float* grid_scaling, const float* grid_offsets,

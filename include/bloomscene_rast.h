@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BSR_VERSION 2
+#define BSR_VERSION 3
 
 /* ---- per-call numerics flags (bsr_forward_ex, bsr_backward_ex, bsr_forward_views, the fused anchor front end) ------
  * BSR_FLAG_EXACT_EXP   forward: 0 (default) = the blend takes exp(power) from the hardware's v_exp_f32 (1 ulp) wherever
@@ -56,6 +56,19 @@ extern "C" {
  *                      and ignored by the forward. */
 #define BSR_FLAG_EXACT_EXP  1u
 #define BSR_FLAG_EXACT_GRAD 2u
+/* BSR_FLAG_NO_READBACK  forward (bsr_forward_ex): the call NEVER waits for the GPU.  The reference blocks on a 4-byte
+ *   device-to-host copy of num_rendered to size its binning buffer (rasterizer_impl.cu:282), and so does the default
+ *   path here (a 16-byte one, overlapped with the rest of the forward).  With this flag the CALLER states the size:
+ *   on entry *num_rendered holds a CAPACITY (tile instances, > 0) -- the binning buffer is sized for it, every kernel
+ *   takes the real count from device memory, and the call returns once everything is enqueued (nothing in it is illegal
+ *   during hipStreamBeginCapture: a warmed-up forward + backward pair can be captured into a hipGraph and replayed).
+ *   *num_rendered is left at the capacity: hand THAT to bsr_backward* as R (same scratch carve).
+ *   Overflow (more instances kept than the capacity) is never silent: the frame's out_color / out_depth are filled with
+ *   NaN by the tile kernel instead of being rendered, bsr_read_counts reports kept > capacity, and -- unless the stream
+ *   was capturing -- the next bsr_forward* call of the same host thread (or bsr_check_deferred) returns an error naming
+ *   both numbers.  The real counts of any forward, on demand (blocks): bsr_read_counts.
+ *   Not for prefiltered calls (their violation flag is part of the read-back). */
+#define BSR_FLAG_NO_READBACK 4u
 
 /* Resize callback for an opaque scratch buffer: must return a device pointer to at least
  * `bytes` bytes (256-byte aligned) that stays valid until the matching backward call.
@@ -150,6 +163,19 @@ int bsr_forward_ex(bsr_alloc_fn geometryBuffer, void* geometry_user,
                    void* stream,
                    int* num_rendered,
                    unsigned flags);
+
+/* The counts of the forward call that filled `image_buffer` (for `width` x `height`), read back from it now: *kept =
+ * tile instances after the exact tile cull (what the binning scratch must hold), *num_rendered = the reference's
+ * num_rendered (sum of tile-rect areas).  Blocks until `stream` has reached the copy.  For BSR_FLAG_NO_READBACK callers:
+ * kept > the capacity they passed means that frame was NOT rendered (NaN outputs); num_rendered sizes the next capacity.
+ * No reference counterpart (the reference returns num_rendered from forward, rasterizer_impl.cu:282,339). */
+int bsr_read_counts(const char* image_buffer, int width, int height, void* stream, int* kept, int* num_rendered);
+
+/* Deferred status of the calling thread's last BSR_FLAG_NO_READBACK forward: 0 if it fit its capacity (or there was
+ * none, or its stream was capturing), 1 + bsr_last_error() if it overflowed.  Waits for that forward's 16-byte copy
+ * (long done once the frame has been consumed); clears the pending state.  Every bsr_forward* call makes this check
+ * first. */
+int bsr_check_deferred(void);
 
 /* radii[P] of the Gaussians as the forward pass would compute them (0 = culled); nothing else.
  * Needs no scratch (the reference allocates and discards full state, rasterizer_impl.cu:361-375).

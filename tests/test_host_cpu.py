@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bloomscene_rast.h but not exported"
     assert declared == set(_capi.SIGNATURES), "ctypes table and header disagree"
-    assert lib.bsr_version() == 2
+    assert lib.bsr_version() == 3
     assert lib.bsr_last_error() == b""
     # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
     assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)

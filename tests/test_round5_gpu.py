@@ -99,3 +99,185 @@ def test_half_masks_cover_every_pixel_that_can_blend(name):
                 assert not (need & ~have).any(), (tile, q, h)
                 checked += int(need.sum())
     assert checked > 0
+
+
+# ------------------------------------------------------------------ BSR_FLAG_NO_READBACK (capacity mode)
+def _leaves(c, dev):
+    keys = ("means3D", "opacities", "shs", "scales", "rotations")
+    return {k: getattr(c, k).to(dev).clone().requires_grad_(True) for k in keys}
+
+
+def _step(c, dev, capacity=None, leaves=None, gC=None, gD=None, rast=None):
+    from bloomscene_amd import GaussianRasterizer
+    leaves = leaves or _leaves(c, dev)
+    rast = rast or GaussianRasterizer(Hh.hip_settings(c, dev), capacity=capacity)
+    m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, depth = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], shs=leaves["shs"],
+                               scales=leaves["scales"], rotations=leaves["rotations"])
+    for v in leaves.values():
+        v.grad = None
+    torch.autograd.backward((color, depth), (c.gC.to(dev) if gC is None else gC, c.gD.to(dev) if gD is None else gD))
+    return color, depth, radii, {k: v.grad for k, v in leaves.items()}, m2d.grad
+
+
+@pytest.mark.parametrize("name", ["sh3", "sh1_near_ragged", "lists_gt_1024", "c2_100k_800x800"])
+def test_capacity_mode_renders_the_same_bits_without_waiting(name, exp_mode):
+    """GaussianRasterizer(capacity=...) = BSR_FLAG_NO_READBACK: scratch sized by the caller, no host wait; colour, depth,
+    radii and every gradient bit-identical to the default path, for a capacity just above the kept count and for a
+    generous one."""
+    from bloomscene_amd.rasterizer import check_deferred
+    dev = _dev()
+    c = Hh.make_case(**CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    ref = _step(c, dev)
+    for cap in (int(st.num_rendered) + 1, 3 * int(st.num_rendered) + 5000):
+        got = _step(c, dev, capacity=cap)
+        check_deferred()   # (fits: no error)
+        for a, b in zip(ref[:3], got[:3]):
+            assert torch.equal(a.view(torch.int32) if a.is_floating_point() else a, b.view(torch.int32) if b.is_floating_point() else b)
+        for k in ref[3]:
+            assert torch.equal(ref[3][k].view(torch.int32), got[3][k].view(torch.int32)), k
+        assert torch.equal(ref[4].view(torch.int32), got[4].view(torch.int32))
+
+
+def test_capacity_overflow_is_never_silent():
+    """Too small a capacity: the frame comes back as NaN (not stale, not half rendered), bsr_read_counts says how many
+    instances were kept, and the thread's NEXT forward raises naming both numbers -- after which the library works on."""
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    c = Hh.make_case(**CASES["sh3"])
+    rs, t, R, color, depth, radii, gb, bb, ib = _native_forward(c)
+    kept, R2 = RZ.read_counts(ib, c.H, c.W)
+    assert R2 == R and 0 < kept <= R
+    cap = max(1, kept // 2)
+    e = torch.Tensor([])
+    args = (rs.bg, t["means3D"], e, t["opac"], t["scales"], t["rot"], rs.scale_modifier, e, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, c.H, c.W, t["shs"], c.deg, rs.campos, False, False)
+    Rc, color2, depth2, radii2, gb2, bb2, ib2 = RZ._rasterize_gaussians_native(*args, capacity=cap)
+    torch.cuda.synchronize()
+    assert Rc == cap
+    assert torch.isnan(color2).all() and torch.isnan(depth2).all()
+    assert torch.equal(radii2, radii)                       # (preprocess ran: radii are those of the frame)
+    assert RZ.read_counts(ib2, c.H, c.W) == (kept, R)
+    with pytest.raises(RuntimeError, match=f"kept {kept} tile instances but was given a capacity of {cap}"):
+        RZ._rasterize_gaussians_native(*args)
+    R3, color3, depth3, _, _, _, _ = RZ._rasterize_gaussians_native(*args)   # the error was reported once; back to normal
+    assert R3 == R and torch.equal(color3.view(torch.int32), color.view(torch.int32))
+    # and through bsr_check_deferred
+    RZ._rasterize_gaussians_native(*args, capacity=cap)
+    with pytest.raises(RuntimeError, match="was not rendered"):
+        RZ.check_deferred()
+    RZ.check_deferred()
+
+
+@pytest.mark.fast_exp
+def test_capacity_mode_forward_backward_replays_from_a_hip_graph():
+    """A warmed-up forward + backward in capacity mode holds no host wait and no illegal call: captured into a HIP graph
+    (torch.cuda.graph) and replayed on new input values, it produces the bits of the eager default path."""
+    from bloomscene_amd.rasterizer import check_deferred
+    dev = _dev()
+    c = Hh.make_case(P=20000, W=320, H=200, deg=3, seed=3, scale_mul=2.0)
+    st, _ = Hh.run_oracle(c, backward=False)
+    cap = 2 * int(st.num_rendered) + 4096
+    from bloomscene_amd import GaussianRasterizer
+    leaves = _leaves(c, dev)
+    gC, gD = c.gC.to(dev), c.gD.to(dev)
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev), capacity=cap)   # (camera tensors uploaded before the capture)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up on a side stream: allocator, pinned buffer, events, code objects
+        for _ in range(3):
+            _step(c, dev, leaves=leaves, gC=gC, gD=gD, rast=rast)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    check_deferred()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        color, depth, radii, grads, g2d = _step(c, dev, leaves=leaves, gC=gC, gD=gD, rast=rast)
+    # new values in the captured input tensors (same shapes): move every Gaussian a little, change the upstream gradients
+    with torch.no_grad():
+        leaves["means3D"].add_(0.01 * torch.randn_like(leaves["means3D"]))
+        gC.mul_(0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    c2 = Hh.make_case(P=20000, W=320, H=200, deg=3, seed=3, scale_mul=2.0)
+    c2.means3D = leaves["means3D"].detach().cpu()
+    c2.gC = gC.cpu()
+    ref = _step(c2, dev)
+    assert torch.equal(ref[0].view(torch.int32), color.view(torch.int32))
+    assert torch.equal(ref[1].view(torch.int32), depth.view(torch.int32))
+    assert torch.equal(ref[2], radii)
+    for k in ref[3]:
+        assert torch.equal(ref[3][k].view(torch.int32), grads[k].view(torch.int32)), k
+
+
+# ------------------------------------------------------------------ the fused anchor front end without a host wait
+def _anchor_step(sc, dev, leaves, gC, gD, capacity=None, settings=None):
+    from bloomscene_amd import views
+    names = ("anchor", "grid_scaling", "grid_offsets", "neural_opacity", "color", "scale_rot")
+    for v in leaves.values():
+        v.grad = None
+    res = views.render_neural(sc.camera_dev, *[leaves[k] for k in names], sc.bg_dev, capacity=capacity, settings=settings)
+    torch.autograd.backward((res["render"], res["depth"]), (gC, gD))
+    return res, {k: v.grad for k, v in leaves.items()}
+
+
+@pytest.mark.fast_exp
+def test_static_shape_anchor_render_equals_the_default_and_replays_from_a_hip_graph():
+    """render_anchors(capacity=...) = bsr_anchor_render_forward with BSR_FLAG_NO_READBACK: neither the selection count
+    nor num_rendered is read back; every per-Gaussian output has N * K rows, the selected ones first, the rest padding
+    no camera sees.  Image, depth and the gradients of the six inputs are the default path's bits; radii / viewspace
+    gradients agree on the first S rows and are zero behind them.  The step replays from a HIP graph."""
+    from bloomscene_amd import views
+    from bloomscene_amd.rasterizer import check_deferred
+    from bloomscene_amd.synthetic import anchor_scene, upstream_grads
+    dev = _dev()
+    N, K, W, H = 20000, 10, 256, 192
+    sc = anchor_scene(N, K, W, H, seed=3)
+    sc.camera_dev = sc.camera.to(dev)
+    sc.bg_dev = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    names = ("anchor", "grid_scaling", "grid_offsets", "neural_opacity", "color", "scale_rot")
+    leaves = {k: getattr(sc, k).to(dev).requires_grad_(True) for k in names}
+    gC, gD = [t.to(dev) for t in upstream_grads(W, H, seed=1)]
+    ref, ref_g = _anchor_step(sc, dev, leaves, gC, gD)
+    ref_view_grad = ref["viewspace_points"].grad.clone()
+    S = int(ref["radii"].numel())
+    assert 0 < S < N * K
+    cap = 40 * S
+    got, got_g = _anchor_step(sc, dev, leaves, gC, gD, capacity=cap)
+    check_deferred()
+    assert got["radii"].numel() == N * K
+    assert torch.equal(got["render"].view(torch.int32), ref["render"].view(torch.int32))
+    assert torch.equal(got["depth"].view(torch.int32), ref["depth"].view(torch.int32))
+    assert torch.equal(got["radii"][:S], ref["radii"]) and not got["radii"][S:].any()
+    assert torch.equal(got["selection_mask"], ref["selection_mask"])
+    assert torch.equal(got["viewspace_points"].grad[:S], ref_view_grad) and not got["viewspace_points"].grad[S:].any()
+    for k in names:
+        assert torch.equal(got_g[k].view(torch.int32), ref_g[k].view(torch.int32)), k
+    # ---- replay from a graph, on changed input values.  (No output of an earlier iteration may stay alive: it would keep
+    # that iteration's AccumulateGrad nodes, bound to the default stream, in the captured backward -- a torch rule for
+    # whole-step capture, not a property of this library.)
+    del ref, got, ref_g, got_g, ref_view_grad
+    settings = views.make_settings(sc.camera_dev, sc.bg_dev, 1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            _anchor_step(sc, dev, leaves, gC, gD, capacity=cap, settings=settings)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    check_deferred()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        res, grads = _anchor_step(sc, dev, leaves, gC, gD, capacity=cap, settings=settings)
+    with torch.no_grad():
+        leaves["color"].mul_(0.9)
+        leaves["neural_opacity"].add_(0.02 * torch.randn_like(leaves["neural_opacity"]))   # (changes the SELECTION too)
+    g.replay()
+    torch.cuda.synchronize()
+    ref2, ref2_g = _anchor_step(sc, dev, leaves, gC, gD)
+    assert int(ref2["radii"].numel()) != S
+    assert torch.equal(res["render"].view(torch.int32), ref2["render"].view(torch.int32))
+    assert torch.equal(res["depth"].view(torch.int32), ref2["depth"].view(torch.int32))
+    for k in names:
+        assert torch.equal(grads[k].view(torch.int32), ref2_g[k].view(torch.int32)), k
