@@ -137,7 +137,7 @@ def use_library(path: str):
 
 
 def set_option(name: str, value) -> None:
-    """bsr_set_option (include/bloomscene_rast.h): the test hooks "sort_force_int", "no_half_masks".  Numerics are per call:
+    """bsr_set_option (include/bloomscene_rast.h): the test hooks "sort_force_int", "sort_small_grids", "no_half_masks".  Numerics are per call:
     bloomscene_amd.numerics / GaussianRasterizer(exact_exp=, strict_gradients=)."""
     check(lib().bsr_set_option(name.encode(), int(bool(value))), "bsr_set_option")
 

@@ -205,13 +205,16 @@ void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 // Numerics are per call (the `flags` of bsr_forward_ex / bsr_backward_ex); the one process-wide switch left is a test
 // hook that changes no result.
 static std::atomic<int> g_opt_sort_force_int{0};
+static std::atomic<int> g_opt_sort_small_grids{0};  // the wide sort classes on grids of 2 / 1 / 1 workgroups (their striding loops)
 static std::atomic<int> g_opt_no_half_masks{0};   // the forward keeps its per-half box tests to itself: the backward tests again
 int opt_sort_force_int() { return g_opt_sort_force_int.load(std::memory_order_relaxed); }
+int opt_sort_small_grids() { return g_opt_sort_small_grids.load(std::memory_order_relaxed); }
 static std::atomic<int>* find_option(const char* name)
 {
 	if (!name) return nullptr;
 	if (!strcmp(name, "sort_force_int")) return &g_opt_sort_force_int;
 	if (!strcmp(name, "no_half_masks")) return &g_opt_no_half_masks;
+	if (!strcmp(name, "sort_small_grids")) return &g_opt_sort_small_grids;
 	return nullptr;
 }
 

@@ -1152,8 +1152,12 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
 	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
 	// (upper bounds of the list lengths, capped: the kernels stride over their lists)
-	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), 2560), g4 = min(min(T, n_bound / 4097), 512),
-	          g8 = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), 512);
+	// (test hook "sort_small_grids": caps of 2 / 1 / 1, so that ordinary test frames drive several tiles through one
+	// workgroup's striding loop -- with the product caps that takes > 2560 / 512 / 512 long tiles in one frame)
+	const bool small_grids = opt_sort_small_grids() != 0;
+	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), small_grids ? 2 : 2560),
+	          g4 = min(min(T, n_bound / 4097), small_grids ? 1 : 512),
+	          g8 = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
 	if (g1 > 0)
 		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
 		                   tile_start, big_tiles, flags, elems, point_list, force_int);

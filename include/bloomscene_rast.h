@@ -461,6 +461,9 @@ size_t bsr_transmittance_offset(const void* image_buffer);
  * bsr_set_option(name, value) -> 0, or 1 for an unknown name; bsr_get_option(name) -> value, or -1.
  *   "sort_force_int"  default 0: 1 sends every per-tile sort through the integer compare-exchange flavour
  *                     that real inputs reach only with NaN / non-positive depth bits (same order either way).
+ *   "sort_small_grids" default 0: 1 caps the grids of the three wide per-tile sort classes at 2 / 1 / 1 workgroups (product:
+ *                     2560 / 512 / 512), so that a frame with a handful of long tiles exercises the loops in which one
+ *                     workgroup sorts several tiles in turn (same order either way).
  *   "no_half_masks"   default 0: 1 makes the forward keep the per-half box tests of its tile walk to itself (by default
  *                     it leaves them in the top byte of the sorted id list -- one view of at most 2^24 Gaussians -- and
  *                     the backward's waves build their lists from that byte instead of testing every record again).

@@ -79,7 +79,7 @@ static bool write_from_device(FILE* f, const T* d, size_t n)
 int main(int argc, char** argv)
 {
 	if (argc != 3 && argc != 4) {
-		fprintf(stderr, "usage: %s inputs.bin outputs.bin [exact|strict]\n", argv[0]);
+		fprintf(stderr, "usage: %s inputs.bin outputs.bin [exact|strict|nowait]\n", argv[0]);
 		return 2;
 	}
 	// Numerics are per call.  No third argument: the reference-shaped entry points bsr_forward / bsr_backward (the
@@ -91,6 +91,9 @@ int main(int argc, char** argv)
 	if (use_ex) {
 		if (!strcmp(argv[3], "exact")) flags = BSR_FLAG_EXACT_EXP;
 		else if (!strcmp(argv[3], "strict")) flags = BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD;
+		// "nowait": exact numerics through BSR_FLAG_NO_READBACK -- the forward is handed a capacity instead of waiting for
+		// num_rendered (a first, ordinary call tells it), overflow reporting and bsr_read_counts are checked on the way
+		else if (!strcmp(argv[3], "nowait")) flags = BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK;
 		else { fprintf(stderr, "unknown mode %s\n", argv[3]); return 2; }
 	}
 	FILE* fi = fopen(argv[1], "rb");
@@ -124,6 +127,42 @@ int main(int argc, char** argv)
 	}
 	Scratch geom, binning, img;
 	int num_rendered = -1;
+	int true_num_rendered = -1;
+	if (flags & BSR_FLAG_NO_READBACK) {
+		// an ordinary forward first: its counts size the capacity.  Then a capacity that is too small: NaN frame, an
+		// error from the NEXT forward of this thread, the library usable afterwards.
+		int r0 = -1, kept = -1, r1 = -1;
+		if (bsr_forward_ex(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
+		                   use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view, d_proj,
+		                   d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &r0, BSR_FLAG_EXACT_EXP) != 0) {
+			fprintf(stderr, "probe forward: %s\n", bsr_last_error());
+			return 1;
+		}
+		if (bsr_read_counts(img.ptr, W, H, stream, &kept, &r1) != 0 || r1 != r0 || kept <= 0 || kept > r0) {
+			fprintf(stderr, "bsr_read_counts: kept %d num_rendered %d vs %d (%s)\n", kept, r1, r0, bsr_last_error());
+			return 1;
+		}
+		true_num_rendered = r0;
+		int small = kept / 2 > 0 ? kept / 2 : 1;
+		if (bsr_forward_ex(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
+		                   use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view, d_proj,
+		                   d_cam, fl[0], fl[1], 0, out_color, out_depth, radii, 0, stream, &small, flags) != 0) {
+			fprintf(stderr, "overflowing forward must be accepted: %s\n", bsr_last_error());
+			return 1;
+		}
+		float probe[2] = {0.f, 0.f};
+		HIP_OK(hipMemcpyAsync(probe, out_color, sizeof(float), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipMemcpyAsync(probe + 1, out_depth + N / 2, sizeof(float), hipMemcpyDeviceToHost, stream));
+		HIP_OK(hipStreamSynchronize(stream));
+		if (probe[0] == probe[0] || probe[1] == probe[1]) { fprintf(stderr, "overflowed frame is not NaN\n"); return 1; }
+		if (bsr_check_deferred() == 0 || !strstr(bsr_last_error(), "was not rendered")) {
+			fprintf(stderr, "overflow not reported: '%s'\n", bsr_last_error());
+			return 1;
+		}
+		if (bsr_check_deferred() != 0) { fprintf(stderr, "the deferred error must be reported once\n"); return 1; }
+		num_rendered = r0 + r0 / 4 + 64;   // the capacity of the call below (on entry), and what the backward is handed
+		printf("nowait: kept %d of %d instances; overflow at capacity %d reported\n", kept, r0, small);
+	}
 	int rc = use_ex
 	    ? bsr_forward_ex(grow, &geom, grow, &binning, grow, &img, P, D, use_sh ? M : 0, d_bg, W, H, d_means,
 	                     use_sh ? d_col : nullptr, use_sh ? nullptr : d_col, d_op, d_sc, fl[2], d_rot, nullptr, d_view,
@@ -219,6 +258,10 @@ int main(int argc, char** argv)
 
 	FILE* fo = fopen(argv[2], "wb");
 	if (!fo) { perror(argv[2]); return 2; }
+	if (flags & BSR_FLAG_NO_READBACK) {
+		if (bsr_check_deferred() != 0) { fprintf(stderr, "deferred: %s\n", bsr_last_error()); return 1; }
+		num_rendered = true_num_rendered;   // (the file carries the frame's real count, as in the other modes)
+	}
 	int32_t nr = num_rendered;
 	ok = fwrite(&nr, 4, 1, fo) == 1 && write_from_device(fo, out_color, 3 * N) && write_from_device(fo, out_depth, N) &&
 	     write_from_device(fo, radii, (size_t)P) && write_from_device(fo, g_mean3D, (size_t)3 * P) &&

@@ -25,7 +25,7 @@ def _f32(t):
                                 dict(P=2500, W=96, H=64, deg=0, seed=52, scale_mul=5.0, color_mode="precomp",
                                      free_camera=True)],
                          ids=["sh3", "precomp_free_camera"])
-@pytest.mark.parametrize("mode", ["plain", "exact", "strict"])
+@pytest.mark.parametrize("mode", ["plain", "exact", "strict", "nowait"])
 def test_forward_backward_through_a_torch_free_consumer(kw, mode, tmp_path):
     if not os.path.exists(EXE):   # normally built by __graft_entry__.build(); hipcc is on the GPU box too
         subprocess.run(["make", "-C", os.path.dirname(EXE)], capture_output=True, timeout=300)

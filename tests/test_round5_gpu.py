@@ -281,3 +281,36 @@ def test_static_shape_anchor_render_equals_the_default_and_replays_from_a_hip_gr
     assert torch.equal(res["depth"].view(torch.int32), ref2["depth"].view(torch.int32))
     for k in names:
         assert torch.equal(grads[k].view(torch.int32), ref2_g[k].view(torch.int32)), k
+
+
+# ------------------------------------------------------------------ wide sort classes: one workgroup, several tiles
+STRIDE_CASES = {
+    "lists_gt_1024": CASES["lists_gt_1024"],                                              # 9 tiles of (1024, 4096]
+    "lists_4097_8192": dict(P=24000, W=32, H=32, deg=0, seed=12, scale_mul=25.0),       # 4 tiles of (4096, 8192]
+    "lists_gt_8192": CASES["lists_gt_8192"],                                              # 4 tiles above 8192
+    "clustered_84k_list": CASES["clustered_84k_list"],                                    # all classes in one frame
+}
+
+
+@pytest.mark.parametrize("name", list(STRIDE_CASES))
+@pytest.mark.parametrize("force_int", [0, 1])
+def test_wide_sort_classes_on_capped_grids_keep_the_reference_order(name, force_int):
+    """the wide per-tile sort classes run on capped grids that stride over their work lists; with the product
+    caps (2560 / 512 / 512 workgroups) no test frame makes a workgroup sort more than one tile.  The "sort_small_grids"
+    hook caps them at 2 / 1 / 1: the lists must still be the oracle's (order-preserving sub-sequences, checked by
+    _assert_forward_bit_exact), in both compare-exchange flavours, and the image bit-equal."""
+    from test_parity_gpu import _assert_forward_bit_exact
+    c = Hh.make_case(**STRIDE_CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    T = ((c.W + 15) // 16) * ((c.H + 15) // 16)
+    sizes = np.diff(st.ranges, axis=1).reshape(-1) if st.ranges.ndim == 2 else None
+    with _option("sort_small_grids", 1), _option("sort_force_int", force_int):
+        rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+    b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    n = np.diff(b.tile_start[:T + 1].astype(np.int64))
+    if name == "lists_gt_1024":
+        assert ((n > 1024) & (n <= 4096)).sum() > 2
+    if name == "lists_4097_8192":
+        assert ((n > 4096) & (n <= 8192)).sum() > 1, n
+    if name == "lists_gt_8192":
+        assert (n > 8192).sum() > 1
