@@ -943,12 +943,15 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 			if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{a9[8], a9[9]};
 			else row[8] = a9[8];
 		}
-#ifdef BSR_BWT_TRAILING_BARRIER   // debug build only (see the invariants below): results must not change with it
+		// No barrier here: while wave 0 adds up the batch, waves 1-3 already stage the next one.  Safe ONLY while all of
+		// these hold:  (1) only wave 0 writes st.q0 / q1 / q2 and reads or zeroes part[][];  (2) a wave's lists and its
+		// tbuf are written and read by that wave alone;  (3) no wave writes part[] before the next staging barrier, which
+		// wave 0 reaches behind this epilogue.  An epilogue shared between the waves, or any wave but 0 touching the staged
+		// records ahead of the barrier, breaks them.  `make debug_variants` puts the barrier back
+		// (libbsr_trailing_barrier.so); tests/test_round5_gpu.py compares the two builds bit for bit.
+#ifdef BSR_BWT_TRAILING_BARRIER
 		__syncthreads();
 #endif
-		// (no barrier here: while wave 0 adds up the batch, the other waves already fetch and test the next one -- they
-		// write nothing but their own lists, which only they read; the records, the partial sums and their zeroing are
-		// wave 0's and the next walk starts behind the staging's barrier, which wave 0 reaches after this epilogue)
 	}
 
 	// entries no pixel of the tile reached: zero rows, but they still need their map entry

@@ -314,3 +314,25 @@ def test_wide_sort_classes_on_capped_grids_keep_the_reference_order(name, force_
         assert ((n > 4096) & (n <= 8192)).sum() > 1, n
     if name == "lists_gt_8192":
         assert (n > 8192).sum() > 1
+
+
+def test_backward_without_its_trailing_barrier_gives_the_bits_of_the_build_that_keeps_it():
+    """k_render_bwd_t has no barrier behind its per-batch epilogue (render_bwd.hip: waves 1-3 stage the next batch while
+    wave 0 adds up this one); the invariants that make this safe are written next to the #ifdef.  The debug build
+    `make debug_variants` puts the barrier back: every output of forward + backward on four scenes (with and without the
+    depth-gradient instantiation) must be the SAME BITS in both builds -- a later edit that breaks an invariant shows up
+    here as a race, not as a tolerance."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "bloomscene_amd", "libbsr_trailing_barrier.so")
+    assert os.path.exists(variant), "bloomscene_amd/libbsr_trailing_barrier.so missing: run __graft_entry__.build()"
+    tool = os.path.join(root, "tools", "gradient_digest.py")
+
+    def digest(extra):
+        r = subprocess.run([sys.executable, tool] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = digest([]), digest(["--lib", variant])
+    assert a.keys() == b.keys() and len(a) == 8
+    for case in a:
+        assert a[case] == b[case], case

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""sha256 of every output of forward + backward on a few seeded scenes, for comparing two BUILDS of the library bit for bit:
+    python tools/gradient_digest.py [--lib other_build.so]   ->  one JSON line {case: {tensor: digest}}"""
+import hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bloomscene_amd import _capi
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":
+    _capi.use_library(sys.argv[2])
+import helpers as Hh
+
+CASES = {"c3_small": dict(P=60000, W=480, H=270, deg=3, seed=0), "dense": dict(P=40000, W=160, H=96, deg=1, seed=4, scale_mul=6.0),
+         "precomp": dict(P=30000, W=200, H=120, deg=0, seed=2, color_mode="precomp", scale_mul=2.0),
+         "long_lists": dict(P=20000, W=48, H=48, deg=1, seed=7, scale_mul=12.0)}
+out = {}
+for name, kw in CASES.items():
+    c = Hh.make_case(**kw)
+    for dg in (False, True):
+        r = Hh.run_hip(c, depth_gradient=dg)
+        d = {"color": r.color, "depth": r.depth, "radii": r.radii}
+        d.update({"grad_" + k: getattr(r.grads, k) for k in Hh.GRAD_KEYS if getattr(r.grads, k) is not None})
+        out[name + ("+depth" if dg else "")] = {k: hashlib.sha256(v.tobytes()).hexdigest()[:16] for k, v in d.items()}
+print(json.dumps(out))
