@@ -321,7 +321,10 @@ struct StageTimer {
 			g_stages.push_back(StageRec{name});
 			rec = &g_stages.back();
 		}
-		if (rec->ev.size() - rec->head >= 8) drain_stage(*rec, false);
+		// (pending pairs are folded in by bsr_profile_read / _reset, outside any timed region: reading eight pairs here
+		// -- hipEventElapsedTime resolves timestamps on a slow path -- cost one step in 32 of a long bench run 3-4 ms;
+		// only a run that never reads keeps the backlog bounded this way)
+		if (rec->ev.size() - rec->head >= 4096) drain_stage(*rec, false);
 		e0 = take_event();
 		e1 = take_event();
 		if (!e0 || !e1) { rec = nullptr; return; }

@@ -112,7 +112,8 @@ def hip_settings(c, device, debug=False, prefiltered=False):
         prefiltered=prefiltered, debug=debug)
 
 
-def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False, strict_gradients=None, exact_exp=None):
+def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False, strict_gradients=None, exact_exp=None,
+            capacity=None):
     """The reference call shape (gaussian_renderer/__init__.py:224-262) against the HIP path.  Numerics: the calling
     thread's bloomscene_amd.numerics context unless given explicitly."""
     from bloomscene_amd import GaussianRasterizer
@@ -126,7 +127,7 @@ def run_hip(c, device="cuda", backward=True, debug=False, depth_gradient=False, 
     means2D = torch.zeros_like(inp.means3D, requires_grad=True) + 0
     means2D.retain_grad()
     rast = GaussianRasterizer(raster_settings=hip_settings(c, dev, debug=debug), depth_gradient=depth_gradient,
-                              exact_exp=exact_exp, strict_gradients=strict_gradients)
+                              exact_exp=exact_exp, strict_gradients=strict_gradients, capacity=capacity)
     color, radii, depth = rast(means3D=inp.means3D, means2D=means2D, opacities=inp.opacities, shs=inp.shs,
                                colors_precomp=inp.colors_precomp, scales=inp.scales, rotations=inp.rotations,
                                cov3D_precomp=inp.cov3D_precomp)

@@ -276,7 +276,19 @@ def main():
         # half with the pinned exp everywhere (images bit-equal to the oracle)
         exact = bool(rng.random() < 0.5)
         out = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact)
-        out2 = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact)
+        # the second run must reproduce the first bit for bit -- as it is, or (round 5) through another route to the same
+        # result: without the forward's half masks (every wave of the backward tests the records itself), or in capacity
+        # mode (BSR_FLAG_NO_READBACK: caller-sized scratch, no host wait), or both
+        route = int(rng.integers(0, 4))
+        cap = None if route in (0, 1) else int(st.num_rendered) + int(rng.integers(1, 5000))
+        _capi.set_option("no_half_masks", route in (1, 3))
+        try:
+            out2 = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact, capacity=cap)
+        finally:
+            _capi.set_option("no_half_masks", 0)
+        if cap is not None:
+            from bloomscene_amd.rasterizer import check_deferred
+            check_deferred()
         assert (out.radii == st.radii).all(), kw
         if exact:
             assert (out.color.view(np.uint32) == st.color.view(np.uint32)).all(), kw
@@ -310,7 +322,7 @@ def main():
                 if e > 2e-5:
                     n_img_loose += 1
                     print(f"  image outside 2e-5 of scale ({name} {e:.1e}): {kw}", flush=True)
-            assert np.array_equal(out.color, out2.color) and np.array_equal(out.depth, out2.depth), kw
+        assert np.array_equal(out.color, out2.color) and np.array_equal(out.depth, out2.depth), (kw, route)
         og = Hh.oracle_grads(c, g)
         for k in ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
             ref, got, got2 = getattr(og, k), getattr(out.grads, k), getattr(out2.grads, k)

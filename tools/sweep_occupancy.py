@@ -23,7 +23,7 @@ def main():
             pmc = json.load(open(os.path.join(d, "pmc_summary.json")))
         except (OSError, ValueError):
             continue
-        batch = 64 if "batch64" in name else 256 if "batch256" in name else 128
+        batch = 64   # (the transposed walk's batch; rounds 2-4 also swept the network walk at 64 / 128 / 256)
         pad = {"fwd": 0, "bwd": 0}
         for part in name.split("_"):
             pass

@@ -8,11 +8,12 @@
 # usage (GPU box, repo root): bash tools/sweep_occupancy.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/sweep_occ}
-CONFIG=${2:-c5}      # c5 (BASELINE's sweep: the network walk) or c3 (the transposed walk with split lists, 31.0 KB LDS: pads 5000 / 16000 / 36000 -> 4 / 3 / 2 workgroups per CU)
+CONFIG=${2:-c5}      # c5 (BASELINE's sweep) or c3
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 # name lib pad_fwd pad_bwd
-if [ "$CONFIG" = c3 ]; then
+# (round 5: every non-strict frame takes the transposed walk, 31.0 KB LDS -> the same pads at C3 and C5: 5000 / 16000 / 36000
+#  bytes leave 4 / 3 / 2 workgroups per CU; forward 20.3 KB: 6500 / 20100 / 61000 leave 6 / 4 / 2)
 POINTS=(
  "native            libbsr_rast_sweep.so  0     0"
  "bwd_wg4           libbsr_rast_sweep.so  0     5000"
@@ -22,18 +23,6 @@ POINTS=(
  "fwd_wg4           libbsr_rast_sweep.so  20100 0"
  "fwd_wg2           libbsr_rast_sweep.so  61000 0"
 )
-else
-POINTS=(
- "native            libbsr_rast_sweep.so  0     0"
- "bwd_wg5           libbsr_rast_sweep.so  0     5800"
- "bwd_wg4           libbsr_rast_sweep.so  0     14000"
- "bwd_wg3           libbsr_rast_sweep.so  0     27700"
- "bwd_wg2           libbsr_rast_sweep.so  0     55000"
- "fwd_wg6           libbsr_rast_sweep.so  10800 0"
- "fwd_wg4           libbsr_rast_sweep.so  24000 0"
- "fwd_wg2           libbsr_rast_sweep.so  65000 0"
-)
-fi
 for p in "${POINTS[@]}"; do
   set -- $p
   name=$1; lib=$2; export BSR_SWEEP_LDS_PAD_FWD=$3; export BSR_SWEEP_LDS_PAD_BWD=$4
