@@ -595,8 +595,10 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
               "rows_per_rank": info["counts"],
               "bytes_per_rank": info["bytes"], "filter_ms": round(info["filter_ms"], 3), "pack_ms": round(info["pack_ms"], 3),
               "comm_ms": round(D.max_over_ranks(info["comm_ms"]), 3), "distribution_ms": round(dist_s * 1e3, 3)}
-    if D.multi:
-        # the two pipelined forms beside it (DESIGN.md "Multi-GPU"): which one a node prefers is for this record to say
+    if D.multi and args.c4_forms == "all":
+        # the two pipelined forms beside it (DESIGN.md "Multi-GPU"): which one a node prefers is for such a record to say.
+        # Opt-in: their unbatched point-to-point sends have never run on RCCL with more than one rank, and a hang there
+        # must not cost the default invocation its line.
         for form in ("pipelined", "blockwise"):
             (_, _, inf2), d2 = distribute(form)
             sc_out["distribution_ms_" + form] = round(d2 * 1e3, 3)
@@ -739,6 +741,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 rotate360 sweep leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (N = 1) workloads")
+    ap.add_argument("--c4-forms", default="batched", choices=["batched", "all"],
+                    help="N > 1: which forms of the visible-subset distribution the C4 leg times -- 'batched' (one pack, all "
+                         "sends posted as one group: the default of views.scatter_visible_gaussians) or 'all' (also the "
+                         "rank-by-rank pipeline and the blockwise one)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="Gaussians in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--exact-exp", action="store_true",
                     help="BSR_FLAG_EXACT_EXP on every call: the pinned exp on every evaluation of the forward blend "

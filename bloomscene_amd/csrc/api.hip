@@ -932,6 +932,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	a.focal_x = width / (2.0f * tan_fovx);
 	a.geom = geom;
 	a.slab = slab; a.depth_grad = out_depth != nullptr;
+	a.kept_ptr = img.flags + 2; a.capacity = R;
 	a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor;
 	a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot;
 	{

@@ -133,6 +133,9 @@ struct BwdArgs {
 	const float4* slab;            // [R][9 floats; 10 with depth_grad] per-instance partial sums written by k_render_bwd, Gaussian-major:
 	                               //        row wg_base[g/256] + inst_offset[g] + k = k-th kept tile of Gaussian g
 	int depth_grad;                // extension: slab rows carry a tenth float, dL/d(view z), added to dL_dmean3D
+	const int* kept_ptr;           // flags[2] of the forward: kept tile instances (device)
+	int capacity;                  // the R this backward was handed.  kept > capacity <=> a BSR_FLAG_NO_READBACK forward
+	                               // overflowed: nothing behind the counters is valid, the call writes NaN gradients
 	float* dL_dmean2D;         // [P,3]  (outputs; fully written)
 	float* dL_dconic;          // [P,4]
 	float* dL_dopacity;        // [P]

@@ -165,8 +165,12 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const bool in_range = idx < a.P;
 	// (no early exit: whole waves take part in the slab gather and in the cooperative SH part)
-	const ushort4 rc = in_range ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
-	const bool visible = in_range && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
+	// More instances kept than the R this call was handed: the forward was a BSR_FLAG_NO_READBACK call whose capacity was
+	// too small.  Its binning, lists and slab do not exist -- nothing of them is read: every Gaussian is treated as
+	// culled and dL_dmean3D is filled with NaN (the frame was NaN too; the thread's next forward reports the overflow).
+	const bool overflow = __builtin_amdgcn_readfirstlane(*a.kept_ptr) > a.capacity;
+	const ushort4 rc = (in_range && !overflow) ? a.geom.rect[idx] : make_ushort4(0, 0, 0, 0);
+	const bool visible = in_range && !overflow && (a.radii ? (a.radii[idx] > 0) : (rc.z > rc.x && rc.w > rc.y));
 
 	// ---- add the per-instance partial sums of this Gaussian (adjacent slab rows) in tile (row-major) order.
 	// Replaces the reference's 9 float atomicAdds per (pixel, Gaussian) pair (backward.cu:537,574-583);
@@ -422,6 +426,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		dmean[1] += a.viewmatrix[6] * g_z;
 		dmean[2] += a.viewmatrix[10] * g_z;
 	}
+	if (overflow) dmean[0] = dmean[1] = dmean[2] = __builtin_nanf("");   // (see the top of the kernel)
 	a.dL_dmean3D[3 * idx] = dmean[0];
 	a.dL_dmean3D[3 * idx + 1] = dmean[1];
 	a.dL_dmean3D[3 * idx + 2] = dmean[2];

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd_strict(int n_tiles, in
                                                                  const float* __restrict__ dL_dpixels,
                                                                  const float* __restrict__ out_depth,   // DEPTH only
                                                                  const float* __restrict__ dL_depths,   // DEPTH only
-                                                                 const int* __restrict__ masks_flag,    // forward's hand-over word
+                                                                 const int* __restrict__ masks_flag,    // forward's hand-over word (flags[6]; flags[2] = kept instances)
+                                                                 int capacity,                          // the R the call was handed
                                                                  float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
@@ -251,6 +252,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd_strict(int n_tiles, in
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
+	// more instances kept than the R this call was handed: an overflowed BSR_FLAG_NO_READBACK forward -- no lists exist
+	// (k_preprocess_bwd writes NaN gradients, the thread's next forward reports it)
+	if (__builtin_amdgcn_readfirstlane(masks_flag[-4]) > capacity) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
@@ -564,7 +568,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
                                                             const float* __restrict__ dL_dpixels,
                                                             const float* __restrict__ out_depth,   // DEPTH only
                                                             const float* __restrict__ dL_depths,   // DEPTH only
-                                                            const int* __restrict__ masks_flag,    // forward's hand-over word
+                                                            const int* __restrict__ masks_flag,    // forward's hand-over word (flags[6]; flags[2] = kept instances)
+                                                                 int capacity,                          // the R the call was handed
                                                             float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
 	constexpr int NV = DEPTH ? 10 : 9;
@@ -574,6 +579,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 
 	const int tile = xcd_tile(blockIdx.x, n_tiles);
 	if (tile >= n_tiles) return;
+	// more instances kept than the R this call was handed: an overflowed BSR_FLAG_NO_READBACK forward -- no lists exist
+	// (k_preprocess_bwd writes NaN gradients, the thread's next forward reports it)
+	if (__builtin_amdgcn_readfirstlane(masks_flag[-4]) > capacity) return;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
@@ -981,16 +989,15 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 #define BSR_LAUNCH_STRICT(D_)                                                                                            \
 	hipLaunchKernelGGL((k_render_bwd_strict<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
-	                   depth ? dL_depths : nullptr, masks_flag, slab)
+	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 #define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
 	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
-	                   depth ? dL_depths : nullptr, masks_flag, slab)
+	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 	// Default: the transposed-reduction walk, for every frame.  (Until round 5 frames with > 1900 reference instances
 	// per tile -- C5, scales x 3 -- kept round 3's per-visit network walk, 0-4 % faster there; with the forward's half
 	// masks handed over, k_render_bwd_t is 5 % faster at C5 and within 1.5 % on the dense scene: docs/EXPERIMENTS.md.)
 	// BSR_FLAG_EXACT_GRAD: k_render_bwd_strict.
-	(void)num_rendered;
 	if (strict) {
 		if (depth) BSR_LAUNCH_STRICT(true);
 		else BSR_LAUNCH_STRICT(false);

@@ -66,7 +66,9 @@ extern "C" {
  *   Overflow (more instances kept than the capacity) is never silent: the frame's out_color / out_depth are filled with
  *   NaN by the tile kernel instead of being rendered, bsr_read_counts reports kept > capacity, and -- unless the stream
  *   was capturing -- the next bsr_forward* call of the same host thread (or bsr_check_deferred) returns an error naming
- *   both numbers.  The real counts of any forward, on demand (blocks): bsr_read_counts.
+ *   both numbers.  A backward run on such a frame (handed the capacity as R) reads none of the missing lists: every
+ *   Gaussian counts as culled and dL_dmean3D is filled with NaN.  The real counts of any forward, on demand (blocks):
+ *   bsr_read_counts.
  *   Not for prefiltered calls (their violation flag is part of the read-back). */
 #define BSR_FLAG_NO_READBACK 4u
 

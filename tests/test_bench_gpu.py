@@ -50,7 +50,10 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     ranks on the one GPU of this box over gloo (RCCL refuses two ranks on one device; the RCCL calls themselves are
     exercised by test_bench_rccl_path_on_one_rank).  A reduced Gaussian count keeps it short."""
     d = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "200000", "--allreduce-grads",
-                    "--no-cpu-baseline"], env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=2)
+                    "--no-cpu-baseline", "--c4-forms", "all"],
+                   env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=2)
+    sv = d["c4"]["scatter_visible"]
+    assert sv["distribution_ms_pipelined"] > 0 and sv["distribution_ms_blockwise"] > 0
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["config"]["visible"] > 150_000          # rank 0 rendered the broadcast scene
     assert d["config"]["broadcast_ms"] > 0 and d["config"]["allreduce_ms_per_step"] > 0

@@ -159,6 +159,12 @@ def test_capacity_overflow_is_never_silent():
     assert torch.isnan(color2).all() and torch.isnan(depth2).all()
     assert torch.equal(radii2, radii)                       # (preprocess ran: radii are those of the frame)
     assert RZ.read_counts(ib2, c.H, c.W) == (kept, R)
+    # a caller that has not looked yet runs the backward on the overflowed frame: no list, no slab exists -- the kernels
+    # must not touch them (they would read uninitialised ranges); every Gaussian is treated as culled and dL_dmean3D is NaN
+    out, _ = _raw_backward(c, rs, t, Rc, radii2, gb2, bb2, ib2, c.gC, c.gD)
+    assert np.isnan(out["mean3D"]).all()
+    for k in ("mean2D", "conic", "opacity", "cov3D", "sh", "scale", "rot"):
+        assert not out[k].any(), k
     with pytest.raises(RuntimeError, match=f"kept {kept} tile instances but was given a capacity of {cap}"):
         RZ._rasterize_gaussians_native(*args)
     R3, color3, depth3, _, _, _, _ = RZ._rasterize_gaussians_native(*args)   # the error was reported once; back to normal

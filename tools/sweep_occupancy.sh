@@ -36,6 +36,6 @@ for p in "${POINTS[@]}"; do
   done
   python "$ROOT/tools/pmc_summary.py" "$d" > "$d/pmc_summary.json"
   find "$d" -name "*.csv" -delete
-  echo "$name done"
+  echo "$name done" >&2
 done
 python "$ROOT/tools/sweep_occupancy.py" "$ROOT/$OUT"
