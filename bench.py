@@ -363,7 +363,8 @@ def raster_workload(D, args, P, W, H, deg, do_bwd, precomp=False, scale_mul=1.0,
             step()
         eager_step, step = step, graph.replay
     tm = timed_steps(D, step, steps, warmup, dominant="render_bwd" if do_bwd else "render_fwd",
-                     prewarm_ms=args.prewarm_ms if label == args.config else 0.0,
+                     prewarm_ms=args.prewarm_ms,   # every leg: the GPU idles while the host builds the leg's scene, and a
+                                                   # leg timed on clocks still ramping reads 4-5 % slow (docs/EXPERIMENTS.md)
                      stage_events=mode != "graph")
     if mode == "capacity":
         from bloomscene_amd.rasterizer import check_deferred
@@ -475,7 +476,7 @@ def bloomscene_shape_workload(D, args, n_anchor=100_000, n_offsets=10, W=512, H=
         with torch.cuda.graph(graph):
             step()
         step = graph.replay
-    tm = timed_steps(D, step, steps, max(3, args.warmup // 2), stage_events=mode != "graph")
+    tm = timed_steps(D, step, steps, max(3, args.warmup // 2), stage_events=mode != "graph", prewarm_ms=args.prewarm_ms)
     if mode == "capacity":
         from bloomscene_amd.rasterizer import check_deferred
         check_deferred()
@@ -826,8 +827,7 @@ def main():
             # the forward without its host wait (include/bloomscene_rast.h BSR_FLAG_NO_READBACK), and the whole step as a
             # HIP graph: the headline workload, and the rasterizer alone at BloomScene's call shape (500 k selected
             # Gaussians, colors_precomp, sh_degree 1, 512 x 512) where launch gaps and the wait are a larger share
-            # (the headline workload once more, in the same place of the process as the two legs below: legs late in the
-            # run are ~4 % slower than the first one on every box -- compare the three with each other)
+            # (the headline workload once more, in the same place of the process as the two legs below)
             "c3_default_again": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
                                                                label="c3-again")),
             "c3_capacity_mode": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,

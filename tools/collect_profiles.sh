@@ -24,9 +24,11 @@ python tools/bench_anchors.py 2>/dev/null | tail -1 > "$OUT/bench_anchors.json"
 python tools/sweep_c5.py 2>/dev/null > "$OUT/sweep_c5.jsonl"
 python tools/parity_report.py c1 c2 c3 c5 dense free_camera precomp lists > "$OUT/parity_report.jsonl" 2>/dev/null
 # the BloomScene-shaped step: kernel trace -> idle intervals (tools/trace_gaps.py)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_bloomscene_shape" -- python3 "$ROOT/tools/profile_bloomscene_shape.py" --steps 200 > "$OUT/bloomscene_shape_under_rocprof.log" 2>&1 )
-python tools/trace_gaps.py "$OUT/kt_bloomscene_shape" > "$OUT/bloomscene_shape_gaps.txt" 2>&1
-python tools/profile_bloomscene_shape.py --steps 200 2>/dev/null | tail -1 > "$OUT/bench_bloomscene_shape.json"
+for m in default capacity graph; do
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_bloomscene_shape_$m" -- python3 "$ROOT/tools/profile_bloomscene_shape.py" --steps 200 --mode $m > "$OUT/bloomscene_shape_${m}_under_rocprof.log" 2>&1 )
+python tools/trace_gaps.py "$OUT/kt_bloomscene_shape_$m" > "$OUT/bloomscene_shape_gaps_$m.txt" 2>&1
+python tools/profile_bloomscene_shape.py --steps 200 --mode $m 2>/dev/null | tail -1 > "$OUT/bench_bloomscene_shape_$m.json"
+done
 fi
 if [ "$PART" != "a" ]; then
 if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then

@@ -17,10 +17,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="default", choices=["default", "capacity", "graph"],
+                    help="default: the reference's call shape; capacity: static shapes, no host wait; graph: that step "
+                         "replayed from a HIP graph (bench.bloomscene_shape_workload)")
     a = ap.parse_args()
-    args = argparse.Namespace(steps=a.steps, warmup=a.warmup)
+    args = argparse.Namespace(steps=a.steps, warmup=a.warmup, prewarm_ms=300.0)
     D = bench.Dist(1)
-    print(json.dumps(bench.bloomscene_shape_workload(D, args)))
+    print(json.dumps(bench.bloomscene_shape_workload(D, args, mode=a.mode)))
     D.close()
 
 
