@@ -739,6 +739,8 @@ def main():
                          "is quoted without it (the reference ignores grad_depth)")
     ap.add_argument("--lib", default="", help="measurement only: time another build of the same C ABI (A/B runs, the "
                                                 "diagnostic builds of csrc/Makefile) instead of the in-tree product library")
+    ap.add_argument("--lib-older-abi", action="store_true",
+                    help="with --lib: accept a build of an earlier ABI version (A/B runs against an earlier round's library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the C4 rotate360 sweep leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (N = 1) workloads")
@@ -762,7 +764,7 @@ def main():
 
     from bloomscene_amd import _capi
     if args.lib:
-        _capi.use_library(args.lib)
+        _capi.use_library(args.lib, allow_older_abi=args.lib_older_abi)
     if args.exact_exp or args.strict_gradients:
         # per-call flags, taken by every rasterizer call of this (main) thread from its numerics context
         from bloomscene_amd import numerics

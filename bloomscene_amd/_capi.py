@@ -94,6 +94,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_allow_older_abi = False   # use_library(..., allow_older_abi=True): A/B runs against a library of an earlier round
 
 
 def build(force: bool = False) -> str:
@@ -115,10 +116,13 @@ def lib():
         # a stale build of another ABI version would shift arguments silently (several entry points changed their
         # parameter lists in place between versions): refuse it before binding anything
         handle.bsr_version.restype = C.c_int
-        if handle.bsr_version() != ABI_VERSION:
+        older = handle.bsr_version() < ABI_VERSION and _allow_older_abi
+        if handle.bsr_version() != ABI_VERSION and not older:
             raise RuntimeError(f"{LIB_PATH} is ABI version {handle.bsr_version()}, this binding needs {ABI_VERSION}: "
                                f"rebuild it (make -C {CSRC})")
         for name, (res, args) in SIGNATURES.items():
+            if older and not hasattr(handle, name):
+                continue   # (an entry point the older library does not have: calling it raises AttributeError)
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
@@ -126,14 +130,18 @@ def lib():
     return _lib
 
 
-def use_library(path: str):
+def use_library(path: str, allow_older_abi: bool = False):
     """Measurement tools only (A/B runs of two builds on one GPU box, the diagnostic builds of csrc/Makefile): load
     another build of the SAME C ABI instead of the in-tree product library.  Must precede the first native call of
-    the process; the product never calls this and reads no environment variable to find its library."""
-    global LIB_PATH
+    the process; the product never calls this and reads no environment variable to find its library.
+    ``allow_older_abi``: accept a library of an EARLIER ABI version whose entry points kept their parameter lists
+    (version 2 -> 3 added symbols and flags only: INTEGRATION.md "ABI versions") -- for A/B runs against an earlier
+    round's build; entry points it lacks are simply not bound."""
+    global LIB_PATH, _allow_older_abi
     if _lib is not None:
         raise RuntimeError("use_library() must be called before the library is first used")
     LIB_PATH = os.path.abspath(path)
+    _allow_older_abi = bool(allow_older_abi)
 
 
 def set_option(name: str, value) -> None:
