@@ -355,15 +355,26 @@ def scatter_visible_gaussians_blockwise(bufs, cams, src: int = 0, masks=None, sc
         trail = {k: tuple(bufs[k].shape[1:]) for k in keys}
 
         def enqueue_filter(r):
-            """(mask bool [P], count tensor [1]) of rank r's block; on the GPU nothing is waited for here"""
+            """(mask bool [P], count landing in host memory, event behind the count's copy) of rank r's block; nothing is
+            waited for here.  The count travels to PINNED memory behind its own event, so that reading count i waits for
+            filter i alone -- a plain .item() would wait for everything enqueued since, the next filter included."""
             if masks is not None:
                 m = masks[r].to(dev)
-                return m, m.sum().reshape(1)
-            if not blocks[r]:
-                return torch.zeros(bufs[keys[0]].shape[0], dtype=torch.bool, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
-            m, c = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], [blocks[r]], scaling_modifier,
-                                    return_counts=True)
-            return m[0], c
+                c = m.sum().reshape(1)
+            elif not blocks[r]:
+                m = torch.zeros(bufs[keys[0]].shape[0], dtype=torch.bool, device=dev)
+                c = torch.zeros(1, dtype=torch.int32, device=dev)
+            else:
+                mm, c = group_visibility(cams, bufs["means3D"], bufs["scales"], bufs["rotations"], [blocks[r]],
+                                         scaling_modifier, return_counts=True)
+                m = mm[0]
+            if dev.type != "cuda":
+                return m, c, None
+            landing = torch.empty(1, dtype=c.dtype, pin_memory=True)
+            landing.copy_(c, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return m, landing, ev
         ahead = [enqueue_filter(r) for r in order[:2]]          # two filters in flight before the host looks at anything
         if layout is None:
             dist.broadcast_object_list([{"keys": keys, "trail": trail}], src=src)
@@ -371,8 +382,10 @@ def scatter_visible_gaussians_blockwise(bufs, cams, src: int = 0, masks=None, sc
         counts, keep, pending, sent = [0] * world, [], [], []
         mine = None
         for i, r in enumerate(order):
-            m, c = ahead[i]
-            n = int(c.item())                                  # waits for filter i only; filter i + 1 is already enqueued
+            m, c, ev = ahead[i]
+            if ev is not None:
+                ev.synchronize()                               # waits for filter i only; filter i + 1 is already enqueued
+            n = int(c.item())
             if i + 2 < len(order):
                 ahead.append(enqueue_filter(order[i + 2]))
             counts[r] = n
@@ -576,8 +589,8 @@ def render_neural(cam: MiniCam, anchor, grid_scaling, grid_offsets, neural_opaci
     # the same as two autograd nodes (what fused=True is tested against, bit for bit).  Everything that does not depend
     # on the number of selected Gaussians first: expand_anchors blocks the host on that count, and whatever python runs
     # between its return and the rasterizer's first launch is GPU idle time
-    rasterizer = GaussianRasterizer(raster_settings=make_settings(cam, bg_color, 1, scaling_modifier, debug),
-                                    depth_gradient=depth_gradient)
+    rasterizer = GaussianRasterizer(raster_settings=settings or make_settings(cam, bg_color, 1, scaling_modifier, debug),
+                                    depth_gradient=depth_gradient, capacity=capacity)   # (capacity: the rasterizer half only)
     xyz, rgb, opacity, scaling, rot, mask = expand_anchors(anchor, grid_scaling, grid_offsets, neural_opacity, color,
                                                            scale_rot)
     # GR:224-229 builds `zeros_like(xyz, requires_grad=True) + 0` and calls retain_grad(): a leaf receives .grad as well,
