@@ -24,30 +24,29 @@ static inline constexpr unsigned occupancy_sweep_lds_pad(const char*) { return 0
 // [bx, bx+EXT] x [by, by+EXTY]?  power(d) = -q(d), q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy with
 // d = centre - pixel.  For a positive-definite conic q is convex, so its minimum over the box is 0
 // if the centre lies inside; otherwise it sits on an edge that FACES the centre (the level ellipse that first touches
-// the box touches it at a point the centre sees): the vertical edge on the centre's side if the centre is outside the
-// box's x-range, the horizontal one on its side if outside the y-range -- at most two clamped 1-D parabola minima
-// (until round 5 all four edges were evaluated: the other two can never hold the minimum).  The splat is kept iff
-// -qmin >= power_cut - slack  (power_cut already carries a margin; the extra slack covers the rounding of this test).
-// Anything not provably a miss -- non-PD conics, NaN conics / cuts -- is kept, so the per-pixel decisions downstream
-// stay exact.
+// the box touches it at a point the centre sees).  Two clamped 1-D parabola minima cover every case without a branch
+// or a select: on the line dx = dxe := clamp(0, dx_lo, dx_hi) -- the facing vertical edge if the centre is outside
+// the box's x-range, the vertical line THROUGH the centre if it is inside -- and on dy = dye := clamp(0, dy_lo, dy_hi)
+// likewise.  Centre inside both ranges: both lines pass through it, q = 0.  Inside the x-range only: the minimum over
+// the box lies on the facing horizontal edge, which the second parabola finds; the first (a line through the box that
+// ends on that edge) can only be larger.  Outside both: the two facing edges.  (Until round 5: all four edges, then
+// the two facing ones chosen by compares and selects -- six of each per pair of tests, each at twice the issue cost
+// of an arithmetic instruction; clamp = v_med3_f32.)  The splat is kept iff  -qmin >= power_cut - slack
+// (power_cut already carries a margin; the extra slack covers the rounding of this test).  Anything not provably a
+// miss -- non-PD conics, NaN conics / cuts -- is kept, so the per-pixel decisions downstream stay exact.
 template <int EXT, int EXTY = EXT>   // box of pixel centres [bx, bx+EXT] x [by, by+EXTY]: EXT = 7 (quadrant) or 15 (tile)
 __device__ __forceinline__ bool box_may_hit(float X, float Y, float a, float b, float c, float cut, float rb_c,
                                             float rb_a, bool pd, float bx, float by)
 {
 	const float dx_lo = X - (bx + (float)EXT), dx_hi = X - bx;
 	const float dy_lo = Y - (by + (float)EXTY), dy_hi = Y - by;
-	const bool in_x = (dx_lo <= 0.0f) && (dx_hi >= 0.0f);
-	const bool in_y = (dy_lo <= 0.0f) && (dy_hi >= 0.0f);
-	// the edge dx = const on the centre's side (centre right of the box: dx_lo > 0, the edge at pixel x = bx + EXT)
-	const float dxe = dx_lo > 0.0f ? dx_lo : dx_hi;
-	const float dy0 = fminf(fmaxf(rb_c * dxe, dy_lo), dy_hi);
+	const float dxe = __builtin_amdgcn_fmed3f(0.0f, dx_lo, dx_hi);
+	const float dy0 = __builtin_amdgcn_fmed3f(rb_c * dxe, dy_lo, dy_hi);
 	const float q0 = 0.5f * (a * dxe * dxe + c * dy0 * dy0) + b * dxe * dy0;
-	// the edge dy = const on the centre's side
-	const float dye = dy_lo > 0.0f ? dy_lo : dy_hi;
-	const float dx1 = fminf(fmaxf(rb_a * dye, dx_lo), dx_hi);
+	const float dye = __builtin_amdgcn_fmed3f(0.0f, dy_lo, dy_hi);
+	const float dx1 = __builtin_amdgcn_fmed3f(rb_a * dye, dx_lo, dx_hi);
 	const float q1 = 0.5f * (a * dx1 * dx1 + c * dye * dye) + b * dx1 * dye;
-	// centre inside the x-range: only the horizontal edge faces it (and inside both: q = 0 at the centre itself)
-	const float qmin = in_x ? (in_y ? 0.0f : q1) : (in_y ? q0 : fminf(q0, q1));
+	const float qmin = fminf(q0, q1);
 	const float slack = 1.0e-3f + 1.0e-4f * fabsf(cut);
 	const bool miss = pd && (-qmin < cut - slack);
 	return !miss;

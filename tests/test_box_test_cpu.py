@@ -1,5 +1,5 @@
 """The tile walks' conservative ellipse-vs-box test (csrc/tile_common.h: box_may_hit) evaluates only the box edges that
-FACE the splat's centre (round 5; all four before).  Restated in float64: the facing-edges minimum of
+FACE the splat's centre (round 5; all four before), in a branch-free clamp form.  Restated in float64: the facing-edges minimum of
 q(d) = 0.5 (a dx^2 + c dy^2) + b dx dy over the box equals the four-edges minimum and is a lower bound of q at every
 pixel centre of the box -- so a pair the test drops can never reach the cut."""
 import numpy as np
@@ -20,7 +20,9 @@ def _edges(X, Y, a, b, c, bx, by, E, EY):
     four = np.where(in_x & in_y, 0.0, np.minimum(np.minimum(e_x(dx_lo), e_x(dx_hi)), np.minimum(e_y(dy_lo), e_y(dy_hi))))
     q0, q1 = e_x(np.where(dx_lo > 0, dx_lo, dx_hi)), e_y(np.where(dy_lo > 0, dy_lo, dy_hi))
     two = np.where(in_x, np.where(in_y, 0.0, q1), np.where(in_y, q0, np.minimum(q0, q1)))
-    return four, two
+    # the kernels' branch-free form: the lines dx = clamp(0, dx_lo, dx_hi) and dy = clamp(0, dy_lo, dy_hi)
+    clamped = np.minimum(e_x(np.clip(0.0, dx_lo, dx_hi)), e_y(np.clip(0.0, dy_lo, dy_hi)))
+    return four, two, clamped
 
 
 def test_facing_edges_minimum_equals_four_edges_minimum_and_bounds_every_pixel():
@@ -34,10 +36,13 @@ def test_facing_edges_minimum_equals_four_edges_minimum_and_bounds_every_pixel()
     b = ca * sa * (1 / s1 ** 2 - 1 / s2 ** 2)
     for E, EY in ((7, 7), (7, 3), (15, 15), (7, 1)):
         bx, by = rng.integers(0, 3, n) * 8.0, rng.integers(0, 3, n) * 8.0
-        four, two = _edges(X, Y, a, b, c, bx, by, E, EY)
+        four, two, clamped = _edges(X, Y, a, b, c, bx, by, E, EY)
         np.testing.assert_array_equal(four, two)
+        # (equal up to the rounding of a parabola evaluated at its own minimum: the clamp form may take the minimum of
+        # two expressions of the same point)
+        assert (np.abs(clamped - two) <= 1e-12 * np.maximum(np.abs(two), 1e-300) + 1e-300).all()
         for px in range(E + 1):
             for py in range(EY + 1):
                 dx, dy = X - (bx + px), Y - (by + py)
                 q = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy
-                assert (q >= two * (1 - 1e-9) - 1e-12).all()
+                assert (q >= two * (1 - 1e-9) - 1e-12).all() and (q >= clamped * (1 - 1e-9) - 1e-12).all()
