@@ -548,6 +548,10 @@ __device__ __forceinline__ void row4_sums(float& x0, float& x1, float& x2, float
 #undef BSR_QSTEP
 }
 
+#ifdef BSR_WALK_TIMELINE
+// (make timeline: per-workgroup start / end stamps of the default backward walk; tools/walk_stats.py --timeline)
+__device__ unsigned long long g_bwd_times[4 * 70000];
+#endif
 template <bool DEPTH, int NS>
 // Occupancy target handed to the register allocator.  The kernel's LDS allows 5 workgroups per CU = 5 waves per SIMD = 96
 // VGPRs; left alone the allocator takes 113 (4 waves).  A/B on one box: 5 waves -7.5 % (the walk waits on LDS round trips
@@ -582,6 +586,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	// more instances kept than the R this call was handed: an overflowed BSR_FLAG_NO_READBACK forward -- no lists exist
 	// (k_preprocess_bwd writes NaN gradients, the thread's next forward reports it)
 	if (__builtin_amdgcn_readfirstlane(masks_flag[-4]) > capacity) return;
+#ifdef BSR_WALK_TIMELINE
+	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
 	const int tx = tile % gx, ty = tile / gx;
@@ -975,6 +982,18 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		if (DEPTH) *reinterpret_cast<bsr_f32x2_a4*>(row + 8) = bsr_f32x2{0.f, 0.f};
 		else row[8] = 0.f;
 	}
+#ifdef BSR_WALK_TIMELINE
+	if (tid == 0 && blockIdx.x < 70000) {   // (wave 0 leaves last or nearly so: it owns every batch's epilogue)
+		unsigned long long* t = g_bwd_times + 4 * (size_t)blockIdx.x;
+		uint32_t xcc, hwid;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+		t[0] = t_start;
+		t[1] = __builtin_amdgcn_s_memrealtime();
+		t[2] = (unsigned long long)(xcc & 0xfu) | ((unsigned long long)blockIdx.x << 4) | ((unsigned long long)hwid << 32);
+		t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
+	}
+#endif
 }
 
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
@@ -1014,3 +1033,12 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 }
 
 }  // namespace bsr
+
+#ifdef BSR_WALK_TIMELINE
+extern "C" int bsr_debug_walk_timeline_bwd(void* out, size_t bytes)
+{
+	hipError_t e = hipDeviceSynchronize();
+	if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_bwd_times), bytes);
+	return e == hipSuccess ? 0 : 1;
+}
+#endif

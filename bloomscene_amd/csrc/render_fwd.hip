@@ -27,10 +27,14 @@ namespace bsr {
 #ifdef BSR_WALK_STATS
 #define BSR_NSTAT_F 24
 __device__ unsigned long long g_fwd_stats[BSR_NSTAT_F];
-__device__ unsigned long long g_fwd_times[4 * 70000];
 #define FSTAT_ADD(i, v) (wstat[i] += (unsigned long long)(v))
 #else
 #define FSTAT_ADD(i, v) ((void)0)
+#endif
+// (make timeline: the per-workgroup start / end stamps alone -- two clock reads and one 32-byte store per workgroup, the
+// walk itself as shipped; the counters above slow the kernel ~10x and distort the stamps)
+#if defined(BSR_WALK_STATS) || defined(BSR_WALK_TIMELINE)
+__device__ unsigned long long g_fwd_times[4 * 70000];
 #endif
 
 // View-batched calls (bsr_forward_views) stack their views into one virtual image of n_views * gy tile rows: tile
@@ -91,6 +95,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 	if (masks_flag != nullptr && tile == 0 && tid == 0) *masks_flag = hand_over ? 1 : 0;
 #ifdef BSR_WALK_STATS
 	unsigned long long wstat[BSR_NSTAT_F] = {};
+#endif
+#if defined(BSR_WALK_STATS) || defined(BSR_WALK_TIMELINE)
 	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
 	// the sentinel record, written by EVERY wave (the same three values): a wave that stages a small tile for itself
@@ -339,19 +345,20 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 		out_depth[img + pix_id] = (acc > 0.5f) ? D / acc : 0.0f;
 	}
 #ifdef BSR_WALK_STATS
-	if (lane == 0) {
+	if (lane == 0)
 		for (int i = 0; i < BSR_NSTAT_F; i++)
 			if (wstat[i]) atomicAdd(&g_fwd_stats[i], wstat[i]);
-		if (wave == 0 && blockIdx.x < 70000) {
-			unsigned long long* t = g_fwd_times + 4 * (size_t)blockIdx.x;
-			uint32_t xcc, hwid;
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-			t[0] = t_start;
-			t[1] = __builtin_amdgcn_s_memrealtime();
-			t[2] = (unsigned long long)xcc | ((unsigned long long)hwid << 32);
-			t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
-		}
+#endif
+#if defined(BSR_WALK_STATS) || defined(BSR_WALK_TIMELINE)
+	if (lane == 0 && wave == 0 && blockIdx.x < 70000) {
+		unsigned long long* t = g_fwd_times + 4 * (size_t)blockIdx.x;
+		uint32_t xcc, hwid;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+		t[0] = t_start;
+		t[1] = __builtin_amdgcn_s_memrealtime();
+		t[2] = (unsigned long long)(xcc & 0xfu) | ((unsigned long long)blockIdx.x << 4) | ((unsigned long long)hwid << 32);
+		t[3] = (unsigned long long)tile | ((unsigned long long)n << 32);
 	}
 #endif
 }
@@ -380,18 +387,21 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 
 }  // namespace bsr
 
-#ifdef BSR_WALK_STATS
-// Diagnostic build only: copies (and clears) the forward counters (which = 2) / its timeline (3).
+#if defined(BSR_WALK_STATS) || defined(BSR_WALK_TIMELINE)
+// Diagnostic builds only: copies (and clears) the forward counters (which = 2; stats build) / its timeline (3).
 extern "C" int bsr_debug_walk_stats_fwd(int which, void* out, size_t bytes)
 {
 	hipError_t e = hipDeviceSynchronize();
-	if (e == hipSuccess)
-		e = which == 2 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_stats), bytes)
-		               : hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_times), bytes);
+#ifdef BSR_WALK_STATS
 	if (e == hipSuccess && which == 2) {
+		e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_stats), bytes);
 		static unsigned long long zeros[BSR_NSTAT_F];
-		e = hipMemcpyToSymbol(HIP_SYMBOL(bsr::g_fwd_stats), zeros, sizeof(zeros));
+		if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(bsr::g_fwd_stats), zeros, sizeof(zeros));
+		return e == hipSuccess ? 0 : 1;
 	}
+#endif
+	if (which != 3) return 1;
+	if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(bsr::g_fwd_times), bytes);
 	return e == hipSuccess ? 0 : 1;
 }
 #endif

@@ -30,7 +30,13 @@ def main():
     ap.add_argument("--scale-mul", type=float, default=1.0, help="scene A with all scales multiplied (denser lists)")
     ap.add_argument("--lib", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                   "bloomscene_amd", "libbsr_rast_stats.so"))
+    ap.add_argument("--dump", default=None, help="with --timeline: also save the raw stamps as <prefix>_fwd.npy / _bwd.npy")
+    ap.add_argument("--timeline", action="store_true",
+                    help="`make timeline` build (libbsr_rast_timeline.so): start / end stamps of both walks AS SHIPPED, no "
+                         "counters (the stats build's counters slow the forward ~10x and distort its stamps)")
     args = ap.parse_args()
+    if args.timeline and args.lib.endswith("libbsr_rast_stats.so"):
+        args.lib = args.lib.replace("libbsr_rast_stats.so", "libbsr_rast_timeline.so")
     from bloomscene_amd import GaussianRasterizationSettings, GaussianRasterizer, _capi
     _capi.use_library(args.lib)
     from bloomscene_amd.synthetic import scene_a, upstream_grads
@@ -54,7 +60,7 @@ def main():
     gC, gD = gC.to(dev), gD.to(dev)
     fstats = np.zeros(24, dtype=np.uint64)
     for it in range(3):
-        if it == 2:
+        if it == 2 and not args.timeline:
             torch.cuda.synchronize()
             assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0   # clears what the warm-up forwards counted
         m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
@@ -62,7 +68,6 @@ def main():
                                    shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
         torch.autograd.backward((color, depth), (gC, gD))
     torch.cuda.synchronize()
-    assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0
     T = ((W + 15) // 16) * ((H + 15) // 16)
     nblk = (T + 7) // 8 * 8
     out = {"config": args.config, "scale_mul": args.scale_mul, "tiles": T}
@@ -70,6 +75,23 @@ def main():
     assert fnf(3, ftl.ctypes.data, ftl.nbytes) == 0
     ftl = ftl.reshape(-1, 4)[:nblk]
     ftl = ftl[ftl[:, 1] > 0]
+    if args.timeline:
+        fnb = lib.bsr_debug_walk_timeline_bwd
+        fnb.restype = C.c_int
+        fnb.argtypes = [C.c_void_p, C.c_size_t]
+        btl = np.zeros(4 * 70000, dtype=np.uint64)
+        assert fnb(btl.ctypes.data, btl.nbytes) == 0
+        btl = btl.reshape(-1, 4)[:nblk]
+        btl = btl[btl[:, 1] > 0]
+        if args.dump:
+            np.save(args.dump + "_fwd.npy", ftl)
+            np.save(args.dump + "_bwd.npy", btl)
+        out["build"] = "timeline (walks as shipped)"
+        out["forward"] = {"timeline": timeline(ftl)}
+        out["backward"] = {"timeline": timeline(btl)}
+        print(json.dumps(out))
+        return
+    assert fnf(2, fstats.ctypes.data, fstats.nbytes) == 0
     f = fstats.astype(np.float64)
     out["forward"] = {
         "lists": "one per 8x4 half of a quadrant when tiles average >= 48 instances, else one per quadrant",
@@ -108,6 +130,24 @@ def timeline(tl):
         "time_below_half_peak_us": round(float(sum(1 for c in conc if c < 0.5 * slots)) * float(total) / 200, 1),
         "last_start_us": round(float(st.max()), 1),
         "resident_at_10pct_steps": [conc[i] for i in range(0, 201, 20)],
+        "resident_at_5pct_steps_of_last_30pct": [conc[i] for i in range(140, 201, 10)],
+        "corr_duration_entries": round(float(np.corrcoef(dur, n_in_tile)[0, 1]), 3) if len(dur) > 2 and n_in_tile.std() > 0 else None,
+        "per_xcc_last_end_us": [round(float(en[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x)].max()), 1)
+                                for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_busy_us": [round(float(dur[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x)].sum()), 1)
+                            for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_workgroups": [int(((tl[:, 2] & np.uint64(0xf)) == np.uint64(x)).sum())
+                               for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_median_duration_us": [round(float(np.median(dur[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x)])), 2)
+                                       for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_mean_entries": [round(float(n_in_tile[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x)].mean()), 1)
+                                 for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_first_tile": [int((tl[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x), 3] & np.uint64(0xffffffff)).min())
+                               for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "per_xcc_cus_seen": [int(len(set((tl[(tl[:, 2] & np.uint64(0xf)) == np.uint64(x), 2] >> np.uint64(32)).astype(np.int64) & 0x7f00 )))
+                             for x in sorted(set(int(v & np.uint64(0xf)) for v in tl[:, 2]))],
+        "duration_by_start_decile_us": [round(float(np.median(dur[(st >= np.percentile(st, 10 * i)) & (st <= np.percentile(st, 10 * i + 10))])), 1)
+                                        for i in range(10)],
         "xcc_ids_seen": sorted(set(int(x & np.uint64(0xf)) for x in tl[:, 2])),
     }
 
