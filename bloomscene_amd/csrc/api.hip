@@ -83,7 +83,7 @@ BinState BinState::carve(char* p, size_t R, bool with_slab)
 }
 size_t ImgState::bytes(size_t N, size_t T)
 {
-	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + 256 + align_up(3 * T * 4, 256) + 256;
+	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + BSR_FLAGS_BYTES + align_up(3 * T * 4, 256) + 256;
 }
 ImgState ImgState::carve(char* p, size_t N, size_t T)
 {
@@ -92,7 +92,7 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 	i.final_T = (float*)p;        p += align_up(N * 4, 256);
 	i.n_contrib = (uint32_t*)p;   p += align_up(N * 4, 256);
 	i.tile_start = (uint32_t*)p;  p += align_up((T + 1) * 4, 256);
-	i.flags = (int*)p;            p += 256;
+	i.flags = (int*)p;            p += BSR_FLAGS_BYTES;
 	i.big_tiles = (uint32_t*)p;
 	return i;
 }
@@ -194,11 +194,11 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, bool exact_exp, bool nan_on_overflow, hipStream_t s);
+                       float* out_depth, bool exact_exp, bool nan_on_overflow, int* pool_ctr, hipStream_t s);
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       const int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s);
+                       int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- options (bsr_set_option)
@@ -496,7 +496,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			                            ? img.flags + 6 : nullptr;
 			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, masks_flag, geom.rec,
 			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
-			                  (flags & BSR_FLAG_EXACT_EXP) != 0, no_readback, s);
+			                  (flags & BSR_FLAG_EXACT_EXP) != 0, no_readback, img.flags + BSR_POOL_FWD, s);
 		}
 		return 0;
 	};

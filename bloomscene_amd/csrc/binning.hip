@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__
 			flags[3] = (int)area;
 			flags[1] = flags[4] = flags[5] = 0;   // counters of k_tile_ranges (the image buffer arrives uninitialised)
 			flags[6] = flags[7] = 0;
+			flags[BSR_POOL_FWD] = flags[BSR_POOL_BWD] = 0;   // pool counters of the two tile walks (common.h: pooled_tile)
 		}
 		return;
 	}

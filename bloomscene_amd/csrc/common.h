@@ -80,9 +80,10 @@ struct ImgState {
 	float* final_T;        // [N]
 	uint32_t* n_contrib;   // [N]
 	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
-	int* flags;            // [8]: prefiltered violation | #tiles (1024, 4096] | kept instances | rect tiles (= reference
+	int* flags;            // [BSR_FLAGS_BYTES / 4]: prefiltered violation | #tiles (1024, 4096] | kept instances | rect tiles (= reference
 	                       //      num_rendered) | #tiles (4096, 8192] | #tiles > 8192 | point_list words carry the forward's
-	                       //      per-half box tests in their top byte (k_render_fwd -> k_render_bwd*) | -
+	                       //      per-half box tests in their top byte (k_render_fwd -> k_render_bwd*) | - | ... |
+	                       //      [64], [96]: pool counters of k_render_fwd / k_render_bwd_t (pooled_tile below)
 	uint32_t* big_tiles;   // [3][T] tiles with more than 1024 instances, one list per size class (any order):
 	                       //        work lists of the wide sort kernels
 	static size_t bytes(size_t N, size_t T);
@@ -233,6 +234,63 @@ __device__ __forceinline__ int xcd_tile(int b, int n_tiles)
 {
 	const int per = (n_tiles + 7) >> 3;
 	return (b & 7) * per + (b >> 3);
+}
+
+// Tail pool of the default tile walks (k_render_fwd, k_render_bwd_t).  The hardware deals workgroups to the eight XCDs in
+// turn whatever their speed, and the XCDs of one chip differ by a few per cent (per box: tools/walk_stats.py
+// --timeline): with xcd_tile alone the slowest XCD ends 3-5 % (forward) / 2-3 % (backward) behind the mean.  So the
+// last BSR_POOL_K tiles of every band are not owned by anybody: the grid carries BSR_POOL_K + BSR_POOL_E workgroups per
+// XCD behind the band's owned part, and each of them draws its tile from ONE counter -- draw j = tile own + j / 8 of
+// band j % 8 -- or leaves when the 8 K pool tiles are gone.  An XCD that is through with its owned tiles early draws
+// more than K, a late one fewer; every workgroup still renders at most one tile (a resident grid looping over tiles
+// was measured and rejected: docs/EXPERIMENTS.md).  The workgroup that makes the launch's last draw zeroes the counter
+// (every pool workgroup draws exactly once), so a second backward on the same forward state finds it as k_scans left it.
+// Counters: flags[BSR_POOL_FWD], flags[BSR_POOL_BWD], each on a 128-byte line of its own (a line shared with flags[2] /
+// flags[6], which every tile reads, made tiles 1.7x slower in the resident-grid experiment).
+#ifndef BSR_POOL_K
+#define BSR_POOL_K 64
+#endif
+#ifndef BSR_POOL_E
+#define BSR_POOL_E 48
+#endif
+#define BSR_FLAGS_BYTES 512
+#define BSR_POOL_FWD 64
+#define BSR_POOL_BWD 96
+// 0: launches of less than ~2.5 rounds of resident workgroups (under 4096 tiles) -- there the draws cost more than the
+// XCDs differ (800 x 800, 2500 tiles: k_render_fwd 0.025 -> 0.030 ms with the pool)
+__host__ __device__ __forceinline__ int pool_tiles_per_band(int n_tiles)
+{
+	const int per = (n_tiles + 7) >> 3;
+	return per >= 8 * BSR_POOL_K ? BSR_POOL_K : 0;
+}
+// workgroups of a pooled launch
+static inline int pooled_grid(int n_tiles)
+{
+	const int per = (n_tiles + 7) >> 3;
+	return 8 * (per + (pool_tiles_per_band(n_tiles) ? BSR_POOL_E : 0));
+}
+// The calling workgroup's tile, -1 = none.  ALL threads of the workgroup call this (one barrier on the pool path);
+// s_slot: one int of LDS.
+__device__ __forceinline__ int pooled_tile(int b, int n_tiles, int* pool_ctr, int* s_slot)
+{
+	const int per = (n_tiles + 7) >> 3;
+	const int k = pool_tiles_per_band(n_tiles), own = per - k;
+	const int i = b >> 3;
+	int tile;
+	if (i < own) {
+		tile = (b & 7) * per + i;
+	} else {
+		if (threadIdx.x == 0) {
+			const int j = atomicAdd(pool_ctr, 1);
+			if (j == 8 * (k + BSR_POOL_E) - 1) *pool_ctr = 0;   // the launch's last draw
+			*s_slot = j;
+		}
+		__syncthreads();
+		const int j = __builtin_amdgcn_readfirstlane(*s_slot);
+		tile = j < 8 * k ? (j & 7) * per + own + (j >> 3) : n_tiles;
+	}
+	tile = __builtin_amdgcn_readfirstlane(tile);   // (wave-uniform on both paths: keep everything derived from it scalar)
+	return tile < n_tiles ? tile : -1;
 }
 
 }  // namespace bsr

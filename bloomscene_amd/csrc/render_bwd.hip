@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
                                                             const float* __restrict__ dL_dpixels,
                                                             const float* __restrict__ out_depth,   // DEPTH only
                                                             const float* __restrict__ dL_depths,   // DEPTH only
-                                                            const int* __restrict__ masks_flag,    // forward's hand-over word (flags[6]; flags[2] = kept instances)
+                                                            int* __restrict__ masks_flag,          // forward's hand-over word (flags[6]; flags[2] = kept instances)
                                                                  int capacity,                          // the R the call was handed
                                                             float4* __restrict__ slab)        // [R][9 or 10 floats]
 {
@@ -581,11 +581,13 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	static_assert(B <= 64 && B % 4 == 0, "a wave stages a batch lane by lane");
 	__shared__ BwtShared<NV, NS> sh;
 
-	const int tile = xcd_tile(blockIdx.x, n_tiles);
-	if (tile >= n_tiles) return;
 	// more instances kept than the R this call was handed: an overflowed BSR_FLAG_NO_READBACK forward -- no lists exist
-	// (k_preprocess_bwd writes NaN gradients, the thread's next forward reports it)
+	// (k_preprocess_bwd writes NaN gradients, the thread's next forward reports it).  (Ahead of the pool draw: either
+	// every workgroup of the launch draws or none does.)
 	if (__builtin_amdgcn_readfirstlane(masks_flag[-4]) > capacity) return;
+	__shared__ int s_slot;
+	const int tile = pooled_tile(blockIdx.x, n_tiles, masks_flag + (BSR_POOL_BWD - 6), &s_slot);
+	if (tile < 0) return;
 #ifdef BSR_WALK_TIMELINE
 	const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -983,8 +985,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 		else row[8] = 0.f;
 	}
 #ifdef BSR_WALK_TIMELINE
-	if (tid == 0 && blockIdx.x < 70000) {   // (wave 0 leaves last or nearly so: it owns every batch's epilogue)
-		unsigned long long* t = g_bwd_times + 4 * (size_t)blockIdx.x;
+	if (tid == 0 && tile < 70000) {   // (wave 0 leaves last or nearly so: it owns every batch's epilogue; filed under the tile)
+		unsigned long long* t = g_bwd_times + 4 * (size_t)tile;
 		uint32_t xcc, hwid;
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -999,7 +1001,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
-                       const int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s)
+                       int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s)
 {
 	const int n_tiles = gx * gy;
 	const int blocks = ((n_tiles + 7) / 8) * 8;
@@ -1010,8 +1012,8 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 #define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
-	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,       \
-	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
+	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(pooled_grid(n_tiles)), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H,      \
+	                   tile_start, point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,   \
 	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 	// Default: the transposed-reduction walk, for every frame.  (Until round 5 frames with > 1900 reference instances
 	// per tile -- C5, scales x 3 -- kept round 3's per-visit network walk, 0-4 % faster there; with the forward's half

@@ -57,13 +57,14 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
                                                           float* __restrict__ final_T,
                                                           uint32_t* __restrict__ n_contrib,
                                                           float* __restrict__ out_color,
-                                                          float* __restrict__ out_depth)
+                                                          float* __restrict__ out_depth, int* __restrict__ pool_ctr)
 {
 	__shared__ TileStageS<FB, NS> st;
 	__shared__ int s_done[4];
+	__shared__ int s_slot;
 
-	const int tile = xcd_tile(blockIdx.x, n_tiles);
-	if (tile >= n_tiles) return;
+	const int tile = pooled_tile(blockIdx.x, n_tiles, pool_ctr, &s_slot);
+	if (tile < 0) return;
 	// the three scalar loads leave together (a sparse view's tile lives for little more than its chain of dependent loads)
 	const int n_instances = *n_ptr;
 	const uint32_t start = tile_start[tile];
@@ -350,8 +351,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 			if (wstat[i]) atomicAdd(&g_fwd_stats[i], wstat[i]);
 #endif
 #if defined(BSR_WALK_STATS) || defined(BSR_WALK_TIMELINE)
-	if (lane == 0 && wave == 0 && blockIdx.x < 70000) {
-		unsigned long long* t = g_fwd_times + 4 * (size_t)blockIdx.x;
+	if (lane == 0 && wave == 0 && tile < 70000) {   // (filed under the TILE: every tile is rendered exactly once per launch)
+		unsigned long long* t = g_fwd_times + 4 * (size_t)tile;
 		uint32_t xcc, hwid;
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -366,10 +367,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
-                       float* out_depth, bool exact, bool nan_on_overflow, hipStream_t s)
+                       float* out_depth, bool exact, bool nan_on_overflow, int* pool_ctr, hipStream_t s)
 {
 	const int n_tiles = gx * gy * n_views;
-	const int blocks = ((n_tiles + 7) / 8) * 8;
+	const int blocks = pooled_grid(n_tiles);
 	// split lists pay off once tiles hold a few dozen entries (C3: 360, C5: 1800); on the sparse views of a camera sweep
 	// (a dozen entries per tile, most tiles empty) their 8 box tests per entry and the padding are pure overhead.
 	// Both instantiations produce identical bits.
@@ -377,7 +378,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	const bool split = (long long)capacity >= 48ll * n_tiles;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
 	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_FWD_BATCH, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
-	                   n_ptr, capacity, nan_on_overflow ? 1 : 0, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth)
+	                   n_ptr, capacity, nan_on_overflow ? 1 : 0, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth, pool_ctr)
 	if (split && exact) BSR_LAUNCH_FWD(2, true);
 	else if (split) BSR_LAUNCH_FWD(2, false);
 	else if (exact) BSR_LAUNCH_FWD(1, true);

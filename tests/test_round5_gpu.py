@@ -342,3 +342,55 @@ def test_backward_without_its_trailing_barrier_gives_the_bits_of_the_build_that_
     assert a.keys() == b.keys() and len(a) == 8
     for case in a:
         assert a[case] == b[case], case
+
+
+def test_tail_pool_of_the_tile_walks_changes_no_bit():
+    """Frames of 4096 tiles and more hand the last 64 tiles of every XCD band out through a counter (common.h:
+    pooled_tile): which workgroup renders a tile then depends on the XCDs' speeds, the tile's result must not.  Every
+    output of forward + backward (with and without the depth-gradient instantiation) of a 1024 x 1024 frame: the same
+    bits from the product library, from the same call repeated, and from the debug build without the pool."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "bloomscene_amd", "libbsr_no_pool.so")
+    assert os.path.exists(variant), "bloomscene_amd/libbsr_no_pool.so missing: run __graft_entry__.build()"
+    tool = os.path.join(root, "tools", "gradient_digest.py")
+
+    def digest(extra):
+        r = subprocess.run([sys.executable, tool] + extra + ["--pooled"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = digest([]), digest(["--lib", variant])
+    assert a.keys() == b.keys() and len(a) == 4
+    for case in a:
+        assert a[case] == b[case], case
+    assert a["pooled_4096_tiles"] == a["pooled_4096_tiles_again"]
+    assert a["pooled_4096_tiles+depth"] == a["pooled_4096_tiles_again+depth"]
+
+
+def test_second_backward_on_one_forward_state_finds_the_pool_counter_reset():
+    """The backward's pool counter is zeroed by the forward's k_scans and by the draw that empties a launch's pool; a
+    second and third backward through the same graph (retain_graph) must therefore walk every tile again: the same
+    gradients, bit for bit."""
+    from bloomscene_amd import GaussianRasterizer
+    c = Hh.make_case(P=120000, W=1024, H=1024, deg=1, seed=6, scale_mul=1.5)
+    dev = torch.device("cuda")
+    leaves = {k: getattr(c, k).to(dev).clone().requires_grad_(True)
+              for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    rast = GaussianRasterizer(raster_settings=Hh.hip_settings(c, dev))
+    m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, depth = rast(means3D=leaves["means3D"], means2D=m2d, opacities=leaves["opacities"], shs=leaves["shs"],
+                               scales=leaves["scales"], rotations=leaves["rotations"])
+    gC, gD = c.gC.to(dev), c.gD.to(dev)
+    grads = []
+    for _ in range(3):
+        for v in list(leaves.values()) + [m2d]:
+            v.grad = None
+        torch.autograd.backward((color, depth), (gC, gD), retain_graph=True)
+        torch.cuda.synchronize()
+        g = {k: v.grad.clone() for k, v in leaves.items()}
+        g["means2D"] = m2d.grad.clone()
+        grads.append(g)
+    for g in grads[1:]:
+        for k in g:
+            assert torch.equal(g[k], grads[0][k]), k
+    assert float(grads[0]["means3D"].abs().sum()) > 0

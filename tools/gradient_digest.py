@@ -8,10 +8,14 @@ from bloomscene_amd import _capi
 if len(sys.argv) > 2 and sys.argv[1] == "--lib":
     _capi.use_library(sys.argv[2])
 import helpers as Hh
+POOLED = "--pooled" in sys.argv   # only the frame large enough for the tile walks' tail pool (>= 4096 tiles), twice
 
 CASES = {"c3_small": dict(P=60000, W=480, H=270, deg=3, seed=0), "dense": dict(P=40000, W=160, H=96, deg=1, seed=4, scale_mul=6.0),
          "precomp": dict(P=30000, W=200, H=120, deg=0, seed=2, color_mode="precomp", scale_mul=2.0),
          "long_lists": dict(P=20000, W=48, H=48, deg=1, seed=7, scale_mul=12.0)}
+if POOLED:
+    CASES = {"pooled_4096_tiles": dict(P=150000, W=1024, H=1024, deg=1, seed=5, scale_mul=1.5),
+             "pooled_4096_tiles_again": dict(P=150000, W=1024, H=1024, deg=1, seed=5, scale_mul=1.5)}
 out = {}
 for name, kw in CASES.items():
     c = Hh.make_case(**kw)
