@@ -36,6 +36,10 @@ if [ -f bloomscene_amd/libbsr_rast_stats.so ]; then
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --scale-mul 3 2>/dev/null | tail -1 > "$OUT/walk_stats_c3_dense.json"
   python tools/walk_stats.py --lib $ROOT/bloomscene_amd/libbsr_rast_stats.so --config c5 2>/dev/null | tail -1 > "$OUT/walk_stats_c5.json"
 fi
+if [ -f bloomscene_amd/libbsr_rast_timeline.so ]; then
+  python tools/walk_stats.py --timeline 2>/dev/null | tail -1 > "$OUT/timeline_c3.json"
+  python tools/walk_stats.py --timeline --config c5 2>/dev/null | tail -1 > "$OUT/timeline_c5.json"
+fi
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-secondary > "$OUT/bench_under_rocprof.log" 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_trace_c5" -- python3 "$ROOT/bench.py" --config c5 --steps 10 --warmup 3 --no-cpu-baseline --no-c4 > "$OUT/bench_c5_under_rocprof.log" 2>&1 )
 bash tools/pmc_passes.sh "gpurun_out/$TAG/pmc" > /dev/null 2>&1
