@@ -238,6 +238,7 @@ def main():
     worst = (0.0, None, None)
     n_cond = 0
     worst_img, n_img_loose, n_valid_moved = 0.0, 0, 0
+    n_pooled = 0   # frames of >= 4096 tiles: the tile walks hand their last tiles out through the tail pool
     while time.time() < t_end:
         if args.mode == "hint":
             P, W, H = 6000, 233, 141
@@ -249,6 +250,7 @@ def main():
             P = int(rng.choice([1, 7, 300, 2000, 10000, 40000]))
             W = int(rng.integers(1, 420))
             H = int(rng.integers(1, 300))
+        n_pooled += ((W + 15) // 16) * ((H + 15) // 16) >= 4096
         deg = int(rng.integers(0, 4))
         kw = dict(P=P, W=W, H=H, deg=deg, seed=int(rng.integers(0, 1 << 30)),
                   scale_mul=float(np.exp(rng.uniform(np.log(0.3), np.log(25.0)))),
@@ -341,7 +343,7 @@ def main():
     print(f"stress ok: {n} random cases ({n_cond} tensors judged by conditioning), "
           f"worst gradient error / scale = {worst[0]:.2e} ({worst[1]}, {worst[2]}); default-mode images: worst error / "
           f"scale {worst_img:.1e}, {n_img_loose} images above 2e-5 (a stop decision moved), {n_valid_moved} pixels whose "
-          f"depth validity (acc > 0.5) moved")
+          f"depth validity (acc > 0.5) moved; {n_pooled} frames of >= 4096 tiles (tail pool)")
 
 
 if __name__ == "__main__":
