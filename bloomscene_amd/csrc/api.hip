@@ -33,7 +33,6 @@ size_t GeomState::bytes(size_t P)
 	s += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
 	s += align_up(P * sizeof(uint64_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
-	s += align_up(P * 6 * sizeof(float), 256);
 	s += align_up(P * sizeof(uint8_t), 256);
 	s += align_up(P * sizeof(float), 256);
 	return s + 256;
@@ -49,7 +48,6 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.hist1 = (uint32_t*)p;       p += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
 	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
-	g.cov3D = (float*)p;     p += align_up(P * 6 * sizeof(float), 256);
 	g.clamped = (uint8_t*)p; p += align_up(P * sizeof(uint8_t), 256);
 	g.depth = (float*)p;
 	return g;

@@ -31,7 +31,6 @@ struct GeomState {
 	                        //   First radix pass = k_emit_scatter: instances are written straight to their pass-1 place.
 	uint64_t* kept_mask;    // [P] see q3 above
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled
-	float* cov3D;       // [P][6]
 	uint8_t* clamped;   // [P] bit ch = SH colour channel ch was clamped at 0
 	float* depth;           // [P] view-space depth again, compact: k_emit_scatter needs nothing else of the 64-B record
 	static size_t bytes(size_t P);
@@ -227,6 +226,24 @@ __device__ __forceinline__ uint32_t kept_count(uint32_t area, uint64_t mask)
 // buckets are laid out.)  `per` = ceil(n_wg / 8); columns whose workgroup does not exist count as zero.
 __device__ __forceinline__ int hist1_column(int wg, int per) { return (wg & 7) * per + (wg >> 3); }
 __device__ __forceinline__ int hist1_wg_of_column(int c, int per) { return (c % per) * 8 + c / per; }
+
+// reference forward.cu:118-152 (quaternion NOT normalised, :127)
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float4 q, float* cov3D)
+{
+	const float s0 = mod * scale[0], s1 = mod * scale[1], s2 = mod * scale[2];
+	const float r = q.x, x = q.y, y = q.z, z = q.w;
+	// M[c][k] = s_k * R[c][k]
+	const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)), m02 = s2 * (2.f * (x * z + r * y));
+	const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)), m12 = s2 * (2.f * (y * z - r * x));
+	const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)), m22 = s2 * (1.f - 2.f * (x * x + y * y));
+	cov3D[0] = m00 * m00 + m01 * m01 + m02 * m02;
+	cov3D[1] = m10 * m00 + m11 * m01 + m12 * m02;
+	cov3D[2] = m20 * m00 + m21 * m01 + m22 * m02;
+	cov3D[3] = m10 * m10 + m11 * m11 + m12 * m12;
+	cov3D[4] = m20 * m10 + m21 * m11 + m22 * m12;
+	cov3D[5] = m20 * m20 + m21 * m21 + m22 * m22;
+}
+
 
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a
 // contiguous band of tiles; neighbouring tiles gather many of the same splat records.

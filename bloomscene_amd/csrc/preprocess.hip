@@ -63,23 +63,6 @@ __device__ __forceinline__ void cov2d_eval(const Cov2DTerms& t, const float* c, 
 	cc += 0.3f;
 }
 
-// reference forward.cu:118-152 (quaternion NOT normalised, :127)
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* scale, float mod, const float4 q, float* cov3D)
-{
-	const float s0 = mod * scale[0], s1 = mod * scale[1], s2 = mod * scale[2];
-	const float r = q.x, x = q.y, y = q.z, z = q.w;
-	// M[c][k] = s_k * R[c][k]
-	const float m00 = s0 * (1.f - 2.f * (y * y + z * z)), m01 = s1 * (2.f * (x * y - r * z)), m02 = s2 * (2.f * (x * z + r * y));
-	const float m10 = s0 * (2.f * (x * y + r * z)), m11 = s1 * (1.f - 2.f * (x * x + z * z)), m12 = s2 * (2.f * (y * z - r * x));
-	const float m20 = s0 * (2.f * (x * z - r * y)), m21 = s1 * (2.f * (y * z + r * x)), m22 = s2 * (1.f - 2.f * (x * x + y * y));
-	cov3D[0] = m00 * m00 + m01 * m01 + m02 * m02;
-	cov3D[1] = m10 * m00 + m11 * m01 + m12 * m02;
-	cov3D[2] = m20 * m00 + m21 * m01 + m22 * m02;
-	cov3D[3] = m10 * m10 + m11 * m11 + m12 * m12;
-	cov3D[4] = m20 * m10 + m21 * m11 + m22 * m12;
-	cov3D[5] = m20 * m20 + m21 * m21 + m22 * m22;
-}
-
 // reference auxiliary.h:41-44 (double-precision literals)
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
@@ -240,10 +223,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 	if (vis) {
 		rect_out = make_ushort4((unsigned short)rmin[0], (unsigned short)(rmin[1] + ty_off),
 		                        (unsigned short)rmax[0], (unsigned short)(rmax[1] + ty_off));
-		// kept for the backward, which only visits Gaussians with radius > 0 (the reference stores it for
-		// every Gaussian in front of the camera, rasterizer_impl.cu / forward.cu:208-214)
-#pragma unroll
-		for (int k = 0; k < 6; k++) a.geom.cov3D[(size_t)gid * 6 + k] = cov3D[k];
+		// (The reference keeps cov3D for its backward, forward.cu:208-214.  Here k_preprocess_bwd forms it again from
+		// scale and rotation, which it reads anyway, with the same function -- the same bits -- instead of 24 B written
+		// here and read there per Gaussian; a precomputed covariance is the caller's array in both passes.)
 		float rgb[3];
 		uint8_t clamp_bits = 0;
 		if (COLOR == 1) {

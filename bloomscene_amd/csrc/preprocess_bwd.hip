@@ -270,9 +270,17 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 
 		// ------------------------------------------------ computeCov2DCUDA, backward.cu:144-274
 		float V[6];
-		const float* cov_src = a.cov3D_precomp ? a.cov3D_precomp + (size_t)idx * 6 : a.geom.cov3D + (size_t)idx * 6;
+		float sc_in[3] = {0.f, 0.f, 0.f};                   // scale and rotation: read once, used here and by computeCov3D below
+		float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (a.cov3D_precomp) {
 #pragma unroll
-		for (int k = 0; k < 6; k++) V[k] = cov_src[k];
+			for (int k = 0; k < 6; k++) V[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
+		} else {
+			// the forward's cov3D again (same function, same operands: same bits) instead of 24 B of scratch per Gaussian
+			sc_in[0] = a.scales[3 * idx]; sc_in[1] = a.scales[3 * idx + 1]; sc_in[2] = a.scales[3 * idx + 2];
+			q_in = reinterpret_cast<const float4*>(a.rotations)[idx];
+			cov3d_from_scale_rot(sc_in, a.scale_modifier, q_in, V);
+		}
 		const float dcx = g[2], dcy = g[3], dcw = g[4];
 
 		// shared prologue (same expressions as the forward)
@@ -366,10 +374,9 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 
 		if (a.scales) {
 			// computeCov3D (backward), backward.cu:278-341
-			const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+			const float4 q = q_in;
 			const float r = q.x, x = q.y, y = q.z, z = q.w;
-			const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-			                    a.scale_modifier * a.scales[3 * idx + 2]};
+			const float s[3] = {a.scale_modifier * sc_in[0], a.scale_modifier * sc_in[1], a.scale_modifier * sc_in[2]};
 			// Rm[c][k] = R[c][k] (glm column c, row k)
 			const float Rm[3][3] = {
 			    {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},

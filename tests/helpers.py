@@ -363,7 +363,6 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     off += _al((256 * (((P + 255) // 256 + 7) // 8 * 8) + 256) * 4)   # hist1 (pass-1 histogram) + digit totals
     out.kept_mask = geom[off:off + P * 8].view(np.uint64); off += _al(P * 8)
     out.rect = geom[off:off + P * 8].view(np.uint16).reshape(P, 4); off += _al(P * 8)
-    out.cov3D = geom[off:off + P * 24].view(np.float32).reshape(P, 6); off += _al(P * 24)
     out.clamped = geom[off:off + P].copy()
     N = W * H
     T = ((W + 15) // 16) * ((H + 15) // 16)
