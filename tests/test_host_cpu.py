@@ -30,7 +30,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.bsr_last_error() == b""
     # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
     assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)
-    assert lib.bsr_geometry_bytes(1000) >= 1000 * (64 + 4 + 8 + 24 + 1) + 256 * 8 * 4
+    # record 64, instance offset 4, kept mask 8, rect 8, clamp bits 1, depth 4 per Gaussian (cov3D is not kept: round 5)
+    assert lib.bsr_geometry_bytes(1000) >= 1000 * (64 + 4 + 8 + 8 + 1 + 4) + 256 * 8 * 4
     assert lib.bsr_binning_bytes(1000) >= 1000 * 28
     assert lib.bsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 4
     # include/bloomscene_anchors.h: one u32 per workgroup of 256 // K anchors, + the total
