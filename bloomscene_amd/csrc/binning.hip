@@ -637,9 +637,9 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 // Order = (tile, depth bits, Gaussian id) = the reference's stable radix-sort order (rasterizer_impl.cu:304-309): the
 // tile part is done by the radix passes, here every tile's segment is sorted on the 64-bit key (depth bits, id).
 // The network is the all-ascending form of bitonic sort (first step of every merge compares mirrored partners), so
-// keys beyond n behave as +infinity pads.  Segments of up to 8192 keys are sorted in LDS by the round-based network
-// below; longer ones (rare: a tile overlapped by > 8192 splats) run hybrid: every 8192-key chunk is sorted in LDS,
-// then each merge does only its steps with partner distance >= 8192 in global memory (the plain steps right here)
+// keys beyond n behave as +infinity pads.  Segments of up to 4096 keys are sorted in LDS by the round-based network
+// below; longer ones (rare: a tile overlapped by > 4096 splats) run hybrid: every 4096-key chunk is sorted in LDS,
+// then each merge does only its steps with partner distance >= 4096 in global memory (the plain steps right here)
 // and finishes chunk by chunk in LDS.
 #define BSR_PAD_KEY 0xFFFFFFFFFFFFFFFFull
 __device__ __forceinline__ void cx(uint64_t& a, uint64_t& b)
@@ -973,38 +973,18 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0);   // (> 512 keys: two runs per lane)
 }
 
-// Wide classes: a fixed grid strides over the big-tile list; (min_n, CAP] picks the class.
-template <int CAP, int NT>
-__global__ void __launch_bounds__(NT) k_sort_tiles_big(int min_n, int count_flag, const int* __restrict__ n_ptr,
-                                                        int capacity, const uint32_t* __restrict__ tile_start,
-                                                        const uint32_t* __restrict__ big_tiles,
-                                                        const int* __restrict__ flags, const BinElem* __restrict__ elems,
-                                                        uint32_t* __restrict__ point_list, int force_int)
-{
-	__shared__ uint64_t s_keys[CAP];
-	if (*n_ptr > capacity) return;
-	// a bounded grid strides over the class's list: a frame without such tiles (C3) pays a small launch instead of
-	// thousands of workgroups that read the count and leave (round 4: 5.1 -> 2.4 us at C3)
-	const int count = flags[count_flag];
-	for (int b = blockIdx.x; b < count; b += gridDim.x) {
-		const uint32_t tile = big_tiles[b];
-		const uint32_t start = tile_start[tile];
-		const int n = (int)(tile_start[tile + 1] - start);
-		if (n <= min_n || n > CAP) continue;   // another class (uniform over the workgroup)
-		int n2 = 1024;
-		while (n2 < n) n2 <<= 1;
-		sort_segment_block<NT, 3>(s_keys, n2, start, n, (int)threadIdx.x, elems, point_list, force_int != 0);
-		__syncthreads();   // (the keys are read out to point_list before the next segment is loaded)
-	}
-}
-
-// keys: scratch for the oversized segments = the other (now free) ping-pong buffer, viewed as u64
-#define BSR_SORT_CHUNK 8192
-#define BSR_SORT_NT 1024
-// One launch for the two rare classes: workgroups [0, g4) take the (4096, 8192] list (big_tiles[T..2T), count
-// flags[4]) and sort in LDS; workgroups [g4, g4 + g8) take the > 8192 list (big_tiles[2T..3T), flags[5]).
-__global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, const int* __restrict__ n_ptr,
-                                                                 int capacity,
+// Wide classes, ONE launch (a frame without long lists -- C3 -- pays one near-empty launch instead of two; until round 5
+// the two upper classes had a 1024-thread, 64-KB kernel of their own): 512 threads, 4096 keys = 32 KB of LDS.
+// Workgroups [0, g1) stride over the (1024, 4096] list (big_tiles[0..T), count flags[1]) and sort each segment in LDS;
+// workgroups [g1, g1 + gw) stride over the two longer lists (big_tiles[T..2T), flags[4]; [2T..3T), flags[5]) with the
+// hybrid: every 4096-key chunk sorted in LDS, the merge steps between chunks in global scratch (`keys` = the free
+// ping-pong buffer viewed as u64), the steps inside a chunk in LDS again.  Bounded grids: n instances fill at most
+// n / 1025 (n / 4097) such tiles, capped -- the workgroups stride.
+#define BSR_SORT_CHUNK 4096
+#define BSR_SORT_NT 512
+// (64 VGPRs: with 33 KB of LDS a CU holds four workgroups = 8 waves per SIMD; the hybrid path alone would take 70 and
+// cost the common (1024, 4096] class its fourth workgroup: C5's tile sort 0.184 -> 0.206 ms)
+__global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_sort_tiles_wide(int T, int g1, const int* __restrict__ n_ptr, int capacity,
                                                                  const uint32_t* __restrict__ tile_start,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
@@ -1015,21 +995,23 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
 	if (*n_ptr > capacity) return;
-	if ((int)blockIdx.x < g4) {   // bounded grids striding over the two lists (see k_sort_tiles_big)
-		const int count = flags[4];
-		for (int b = blockIdx.x; b < count; b += g4) {
-			const uint32_t tile = big_tiles[(size_t)T + b];
+	if ((int)blockIdx.x < g1) {
+		const int count = flags[1];
+		for (int b = blockIdx.x; b < count; b += g1) {
+			const uint32_t tile = big_tiles[b];
 			const uint32_t start = tile_start[tile];
 			const int n = (int)(tile_start[tile + 1] - start);
-			if (n <= 4096 || n > CH) continue;   // (uniform over the workgroup)
-			sort_segment_block<NT, 3>(s_keys, CH, start, n, tid, elems, point_list, force_int != 0);
-			__syncthreads();
+			if (n <= BSR_SORT_SMALL || n > CH) continue;   // another class (uniform over the workgroup)
+			int n2 = 1024;
+			while (n2 < n) n2 <<= 1;
+			sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, elems, point_list, force_int != 0);
+			__syncthreads();   // (the keys are read out to point_list before the next segment is loaded)
 		}
 		return;
 	}
-	const int g8 = (int)gridDim.x - g4, count8 = flags[5];
-	for (int b = (int)blockIdx.x - g4; b < count8; b += g8) {
-		const uint32_t tile = big_tiles[2 * (size_t)T + b];
+	const int gw = (int)gridDim.x - g1, count4 = flags[4], count8 = flags[5];
+	for (int b = (int)blockIdx.x - g1; b < count4 + count8; b += gw) {
+		const uint32_t tile = b < count4 ? big_tiles[(size_t)T + b] : big_tiles[2 * (size_t)T + (b - count4)];
 		const uint32_t start = tile_start[tile];
 		const int n = (int)(tile_start[tile + 1] - start);
 		if (n <= CH) continue;
@@ -1056,7 +1038,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) k_sort_tiles_huge(int T, int g4, 
 				const int m = min(CH, n - base);
 				__syncthreads();
 				for (int i = tid; i < CH; i += NT) s_keys[swz_m<3>(i)] = i < m ? k[base + i] : BSR_PAD_KEY;
-				lds_stride_rounds<NT, 3, true, false>(s_keys, CH, 13, tid);   // strides CH/2 .. 1
+				lds_stride_rounds<NT, 3, true, false>(s_keys, CH, 12, tid);   // strides CH/2 .. 1
 				__syncthreads();
 				for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
 			}
@@ -1131,10 +1113,10 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 	*elems_free = eo;
 }
 
-// Size classes: (0, 1024] -> 8 KB LDS, one workgroup per tile; the wide classes (1024, 4096] -> 32 KB,
-// (4096, 8192] -> 64 KB and > 8192 -> hybrid take one entry of the big-tile list per workgroup.  n
-// instances can fill at most n / 1024 such tiles (n / 4096, n / 8192 for the wider classes), which
-// bounds their grids: a frame without long lists pays near-empty launches, not 3 x T idle workgroups.
+// Size classes: (0, 1024] -> one WAVE per tile (8 KB of LDS each); the wide classes share ONE launch
+// (k_sort_tiles_wide): (1024, 4096] sorted in 32 KB of LDS, longer segments hybrid in 4096-key chunks, one entry of a
+// work list per workgroup.  n instances can fill at most n / 1024 (n / 4096) such tiles, which bounds the grid: a frame
+// without long lists pays one near-empty launch, not 3 x T idle workgroups.
 void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
                        uint32_t* point_list, hipStream_t s)
@@ -1150,20 +1132,15 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 		                   point_list);
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
 	                   force_int, tiny ? 64 : 0);
-	// n instances can fill at most n / 1025 tiles of the first wide class, n / 4097 of the second, n / 8193 of the
-	// third: each kernel's grid covers its own list completely (n_bound >= the real count)
-	// (upper bounds of the list lengths, capped: the kernels stride over their lists)
-	// (test hook "sort_small_grids": caps of 2 / 1 / 1, so that ordinary test frames drive several tiles through one
-	// workgroup's striding loop -- with the product caps that takes > 2560 / 512 / 512 long tiles in one frame)
+	// n instances can fill at most n / 1025 tiles of the first wide class and n / 4097 of the two longer ones: the grid
+	// covers both work lists (n_bound >= the real count), capped -- the workgroups stride over their lists
+	// (test hook "sort_small_grids": caps of 2 / 1, so that ordinary test frames drive several tiles through one
+	// workgroup's striding loop -- with the product caps that takes > 2560 / 512 long tiles in one frame)
 	const bool small_grids = opt_sort_small_grids() != 0;
 	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), small_grids ? 2 : 2560),
-	          g4 = min(min(T, n_bound / 4097), small_grids ? 1 : 512),
-	          g8 = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
-	if (g1 > 0)
-		hipLaunchKernelGGL((k_sort_tiles_big<4096, 512>), dim3(g1), dim3(512), 0, s, BSR_SORT_SMALL, 1, n_ptr, capacity,
-		                   tile_start, big_tiles, flags, elems, point_list, force_int);
-	if (g4 + g8 > 0)
-		hipLaunchKernelGGL(k_sort_tiles_huge, dim3(g4 + g8), dim3(BSR_SORT_NT), 0, s, T, g4, n_ptr, capacity, tile_start,
+	          gw = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
+	if (g1 + gw > 0)
+		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1 + gw), dim3(BSR_SORT_NT), 0, s, T, g1, n_ptr, capacity, tile_start,
 		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int);
 }
 
