@@ -185,10 +185,10 @@ void launch_pack_rows(int R, int P, int n_src, const float* const* src, const in
 void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
-                    int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s);
+                    int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s);
 void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
-                       uint32_t* point_list, hipStream_t s);
+                       uint32_t* point_list, int compact, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
@@ -458,6 +458,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	BinState bin;
 	BinElem* elems_sorted = nullptr;
 	BinElem* elems_free = nullptr;
+	int elems_compact = 0;   // the binning wrote 8-byte elements (common.h: load_elem_m)
 	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
 	// from device memory and returns at once if it exceeds the capacity
 	auto run_tail = [&](size_t capacity, bool rerun) -> int {
@@ -477,13 +478,13 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		{
 			StageTimer t("binning", s);
 			launch_binning((int)P_rows, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
-			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, s);
+			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, &elems_compact, s);
 		}
 		STAGE_CHECK("binning", debug, s);
 		{
 			StageTimer t("sort_tiles", s);
 			launch_sort_tiles(T, (int)capacity, n_ptr, (int)capacity, img.tile_start, img.big_tiles, img.flags,
-			                  elems_sorted, elems_free, bin.point_list, s);
+			                  elems_sorted, elems_free, bin.point_list, elems_compact, s);
 		}
 		STAGE_CHECK("sort_tiles", debug, s);
 		{

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
                                                       const uint64_t* __restrict__ kept_mask,
                                                       const float* __restrict__ depth,
                                                       const uint32_t* __restrict__ hist1, BinElem* __restrict__ elems,
-                                                      uint32_t* __restrict__ zero_me, int n_zero)
+                                                      uint32_t* __restrict__ zero_me, int n_zero, int compact)
 {
 	__shared__ uint32_t s_off[BSR_RADIX_BINS];   // next output position per digit for this workgroup
 	__shared__ uint32_t s_scan[4];
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 			if (!tile_kept(area, mask, k)) continue;
 			const uint32_t tile = (uint32_t)(y * gx + x);
 			const uint32_t pos = atomicAdd(&s_off[tile & (BSR_RADIX_BINS - 1)], 1u);   // LDS
-			store_elem(elems + pos, BinElem{tile, (uint32_t)idx, depth_bits});   // one 12-B store
+			store_elem_m(elems, pos, BinElem{tile, (uint32_t)idx, depth_bits}, compact);   // one 8- or 12-B store
 		}
 }
 
@@ -370,13 +370,13 @@ __device__ __forceinline__ BucketSlice bucket_slice(uint32_t my_total, int d1, i
 }
 
 // LDS histogram of the high byte over elems[beg, end): four loads in flight per trip
-__device__ __forceinline__ void slice_histogram(const BinElem* __restrict__ elems, BucketSlice sl, uint32_t* s_hist)
+__device__ __forceinline__ void slice_histogram(const BinElem* __restrict__ elems, BucketSlice sl, uint32_t* s_hist, int compact)
 {
 	const int tid = threadIdx.x;
 	for (int i = sl.beg + tid; i < sl.end; i += 1024) {
 		uint32_t t[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) t[k] = (i + 256 * k < sl.end) ? elems[i + 256 * k].x : 0u;
+		for (int k = 0; k < 4; k++) t[k] = (i + 256 * k < sl.end) ? elem_tile_m(elems, (size_t)(i + 256 * k), compact) : 0u;
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			if (i + 256 * k < sl.end) atomicAdd(&s_hist[(t[k] >> BSR_RADIX_BITS) & (BSR_RADIX_BINS - 1)], 1u);
@@ -385,7 +385,8 @@ __device__ __forceinline__ void slice_histogram(const BinElem* __restrict__ elem
 
 __global__ void __launch_bounds__(256) k_tile_count(int T, int n_slices, const int* __restrict__ n_ptr, int capacity,
                                                     const uint32_t* __restrict__ digit_total1,
-                                                    const BinElem* __restrict__ elems, uint32_t* __restrict__ tile_count)
+                                                    const BinElem* __restrict__ elems, uint32_t* __restrict__ tile_count,
+                                                    int compact)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
 	__shared__ uint32_t s_scan[4];
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(256) k_tile_count(int T, int n_slices, const i
 	const int d1 = (int)blockIdx.x / n_slices, s = (int)blockIdx.x % n_slices;
 	s_hist[tid] = 0;
 	const BucketSlice sl = bucket_slice(digit_total1[tid], d1, s, n_slices, s_scan, s_base);   // (barriers inside)
-	slice_histogram(elems, sl, s_hist);
+	slice_histogram(elems, sl, s_hist, compact);
 	__syncthreads();
 	const uint32_t c = s_hist[tid];
 	const uint32_t t = ((uint32_t)tid << BSR_RADIX_BITS) | (uint32_t)d1;
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
                                                       const BinElem* __restrict__ elems_in,
                                                       BinElem* __restrict__ elems_out,
                                                       const uint32_t* __restrict__ tile_start,
-                                                      uint32_t* __restrict__ tile_cursor)
+                                                      uint32_t* __restrict__ tile_cursor, int compact)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
 	__shared__ uint32_t s_off[BSR_RADIX_BINS];
@@ -521,13 +522,13 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
 #pragma unroll
 		for (int k = 0; k < BSR_SLICE_REGS; k++) {
 			const int i = sl.beg + tid + 256 * k;
-			e[k] = i < sl.end ? load_elem(elems_in + i) : BinElem{0u, 0u, 0u};
+			e[k] = i < sl.end ? load_elem_m(elems_in, (size_t)i, compact) : BinElem{0u, 0u, 0u};
 		}
 #pragma unroll
 		for (int k = 0; k < BSR_SLICE_REGS; k++)
 			if (sl.beg + tid + 256 * k < sl.end) atomicAdd(&s_hist[(e[k].x >> BSR_RADIX_BITS) & (BSR_RADIX_BINS - 1)], 1u);
 	} else {
-		slice_histogram(elems_in, sl, s_hist);
+		slice_histogram(elems_in, sl, s_hist, compact);
 	}
 	__syncthreads();
 	{
@@ -543,7 +544,7 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
 		for (int k = 0; k < BSR_SLICE_REGS; k++)
 			if (sl.beg + tid + 256 * k < sl.end) {
 				const uint32_t pos = atomicAdd(&s_off[(e[k].x >> BSR_RADIX_BITS) & (BSR_RADIX_BINS - 1)], 1u);   // LDS
-				store_elem(elems_out + pos, e[k]);
+				store_elem_m(elems_out, pos, e[k], compact);
 			}
 		return;
 	}
@@ -551,12 +552,12 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
 		BinElem f[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++)
-			if (i + 256 * k < sl.end) f[k] = load_elem(elems_in + i + 256 * k);
+			if (i + 256 * k < sl.end) f[k] = load_elem_m(elems_in, (size_t)(i + 256 * k), compact);
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			if (i + 256 * k < sl.end) {
 				const uint32_t pos = atomicAdd(&s_off[(f[k].x >> BSR_RADIX_BITS) & (BSR_RADIX_BINS - 1)], 1u);   // LDS
-				store_elem(elems_out + pos, f[k]);
+				store_elem_m(elems_out, pos, f[k], compact);
 			}
 	}
 }
@@ -870,7 +871,7 @@ __device__ __forceinline__ void lds_sort_rounds(uint64_t* keys, int n2, int t)
 // a positive, normal, finite binary64".
 template <int NT, int M>
 __device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_t start, int n, int t,
-                                                 const BinElem* __restrict__ elems)
+                                                 const BinElem* __restrict__ elems, int compact)
 {
 	constexpr int K = 1 << M;
 	bool plain = true;
@@ -878,7 +879,7 @@ __device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_
 		uint64_t e[K];
 #pragma unroll
 		for (int j = 0; j < K; j++) {
-			e[j] = i + j < n ? elem_key(load_elem(elems + start + i + j)) : BSR_PAD_KEY;
+			e[j] = i + j < n ? elem_key_m(elems, (size_t)start + (size_t)(i + j), compact) : BSR_PAD_KEY;
 			plain = plain && (i + j >= n || key_is_plain_double(e[j]));
 		}
 		reg_sort<M, false>(e);
@@ -904,9 +905,9 @@ __device__ __forceinline__ void merge_loaded_runs(uint64_t* keys, int n2, uint32
 template <int M>
 __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32_t start, int n, int lane,
                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
-                                                  bool force_int)
+                                                  bool force_int, int compact)
 {
-	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems) && !force_int;
+	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems, compact) && !force_int;
 	if (wave_ballot(!plain) == 0ull)
 		merge_loaded_runs<64, M, false, true>(keys, n2, start, n, lane, point_list);
 	else
@@ -917,9 +918,9 @@ __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32
 template <int NT, int M>
 __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint32_t start, int n, int tid,
                                                    const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
-                                                   bool force_int)
+                                                   bool force_int, int compact)
 {
-	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems) && !force_int;
+	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems, compact) && !force_int;
 	if (__syncthreads_and(plain))
 		merge_loaded_runs<NT, M, true, true>(keys, n2, start, n, tid, point_list);
 	else
@@ -933,7 +934,7 @@ __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint3
 __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __restrict__ n_ptr, int capacity,
                                                          const uint32_t* __restrict__ tile_start,
                                                          const BinElem* __restrict__ elems,
-                                                         uint32_t* __restrict__ point_list)
+                                                         uint32_t* __restrict__ point_list, int compact)
 {
 	const int lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -943,7 +944,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 	const int n = (int)(tile_start[tile + 1] - start);
 	if (n_instances > capacity || n > 64 || n <= 0) return;   // (scratch too small: stage is re-run) / another class / empty
 	uint64_t key = ~0ull;
-	if (lane < n) key = elem_key(load_elem(elems + start + lane));
+	if (lane < n) key = elem_key_m(elems, (size_t)start + (size_t)lane, compact);
 	const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
 	uint32_t rank = 0;
 	for (int j = 0; j < n; j++) {
@@ -959,7 +960,8 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const BinElem* __restrict__ elems,
-                                                          uint32_t* __restrict__ point_list, int force_int, int min_n)
+                                                          uint32_t* __restrict__ point_list, int force_int, int min_n,
+                                                          int compact)
 {
 	__shared__ uint64_t s_keys[4][BSR_SORT_SMALL];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -970,7 +972,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	if (n > BSR_SORT_SMALL || n <= min_n) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (min_n = 64) or empty
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
-	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0);   // (> 512 keys: two runs per lane)
+	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0, compact);   // (> 512 keys: two runs per lane)
 }
 
 // Wide classes, ONE launch (a frame without long lists -- C3 -- pays one near-empty launch instead of two; until round 5
@@ -989,7 +991,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
                                                                  const BinElem* __restrict__ elems, uint64_t* keys,
-                                                                 uint32_t* __restrict__ point_list, int force_int)
+                                                                 uint32_t* __restrict__ point_list, int force_int, int compact)
 {
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
 	__shared__ uint64_t s_keys[CH];
@@ -1004,7 +1006,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 			if (n <= BSR_SORT_SMALL || n > CH) continue;   // another class (uniform over the workgroup)
 			int n2 = 1024;
 			while (n2 < n) n2 <<= 1;
-			sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, elems, point_list, force_int != 0);
+			sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, elems, point_list, force_int != 0, compact);
 			__syncthreads();   // (the keys are read out to point_list before the next segment is loaded)
 		}
 		return;
@@ -1022,7 +1024,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 		for (int base = 0; base < n; base += CH) {
 			const int m = min(CH, n - base);
 			__syncthreads();
-			load_sorted_runs<NT, 3>(s_keys, CH, start + (uint32_t)base, m, tid, elems);
+			load_sorted_runs<NT, 3>(s_keys, CH, start + (uint32_t)base, m, tid, elems, compact);
 			lds_sort_rounds<NT, 3, true, false>(s_keys, CH, tid);
 			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
 		}
@@ -1060,16 +1062,19 @@ void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, ui
 // final order.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
-                    int* flags, BinElem** elems_sorted, BinElem** elems_free, hipStream_t s)
+                    int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s)
 {
 	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_scans
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
 	const bool tile_owned = bits <= 2 * BSR_RADIX_BITS && 2 * (size_t)T <= (size_t)BSR_RADIX_BINS * hist_blocks_max;
+	// 8-byte elements where the tile-owned pass runs and Gaussian ids fit 24 bits (common.h: load_elem_m)
+	const int compact = (tile_owned && P <= (1 << 24)) ? 1 : 0;
+	*compact_out = compact;
 	uint32_t* tile_count = hist;          // [T]   (the histogram area of the generic passes, unused on this path)
 	uint32_t* tile_cursor = hist + T;     // [T]
 	hipLaunchKernelGGL(k_emit_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect,
-	                   geom.kept_mask, geom.depth, geom.hist1, elems_a, tile_count, tile_owned ? 2 * T : 0);
+	                   geom.kept_mask, geom.depth, geom.hist1, elems_a, tile_count, tile_owned ? 2 * T : 0, compact);
 	if (tile_owned) {
 		// tile ids of up to 16 bits (every single-view call up to 4096 x 4096): count -> starts -> scatter
 		const int n_wg = (P + 255) / 256, n_col = 8 * ((n_wg + 7) >> 3);
@@ -1079,7 +1084,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 		int n_slices = capacity / (BSR_RADIX_BINS * 3072) + 1;
 		n_slices = n_slices > 256 ? 256 : n_slices;
 		hipLaunchKernelGGL(k_tile_count, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
-		                   digit_total1, elems_a, tile_count);
+		                   digit_total1, elems_a, tile_count, compact);
 		if (T <= 8192)
 			hipLaunchKernelGGL(k_tile_starts<8>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
 			                   big_tiles, flags);
@@ -1087,7 +1092,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 			hipLaunchKernelGGL(k_tile_starts<64>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
 			                   big_tiles, flags);
 		hipLaunchKernelGGL(k_tile_scatter, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
-		                   digit_total1, elems_a, elems_b, tile_start, tile_cursor);
+		                   digit_total1, elems_a, elems_b, tile_start, tile_cursor, compact);
 		*elems_sorted = elems_b;
 		*elems_free = elems_a;
 		return;
@@ -1119,7 +1124,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 // without long lists pays one near-empty launch, not 3 x T idle workgroups.
 void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
                        const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
-                       uint32_t* point_list, hipStream_t s)
+                       uint32_t* point_list, int compact, hipStream_t s)
 {
 	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
 	// which real inputs reach only with NaN / non-positive depth bits
@@ -1129,9 +1134,9 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	const bool tiny = (long long)n_bound < 128ll * T;
 	if (tiny)
 		hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems,
-		                   point_list);
+		                   point_list, compact);
 	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
-	                   force_int, tiny ? 64 : 0);
+	                   force_int, tiny ? 64 : 0, compact);
 	// n instances can fill at most n / 1025 tiles of the first wide class and n / 4097 of the two longer ones: the grid
 	// covers both work lists (n_bound >= the real count), capped -- the workgroups stride over their lists
 	// (test hook "sort_small_grids": caps of 2 / 1, so that ordinary test frames drive several tiles through one
@@ -1141,7 +1146,7 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	          gw = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
 	if (g1 + gw > 0)
 		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1 + gw), dim3(BSR_SORT_NT), 0, s, T, g1, n_ptr, capacity, tile_start,
-		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int);
+		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int, compact);
 }
 
 }  // namespace bsr

@@ -63,6 +63,39 @@ __device__ __forceinline__ void store_elem(BinElem* p, const BinElem e)
 {
 	*reinterpret_cast<bsr_u32x3_a4*>(p) = bsr_u32x3{e.x, e.y, e.z};
 }
+// Compact form of an element in memory (8 bytes instead of 12) for the common case -- tile ids of up to 16 bits (the
+// tile-owned second binning pass) and Gaussian ids below 2^24: word 0 = tile id bits 8..15 << 24 | Gaussian id, word 1 =
+// depth bits.  The low tile byte is the pass-1 bucket the element lies in, which every reader knows.  In registers an
+// element is a BinElem either way (x = the tile id, its low byte zero when read back from the compact form).  `compact`
+// is uniform over the launch.  The buffers are sized for the 12-byte form.
+__device__ __forceinline__ BinElem load_elem_m(const BinElem* base, size_t i, int compact)
+{
+	if (compact) {
+		const uint2 v = reinterpret_cast<const uint2*>(base)[i];
+		return BinElem{(v.x >> 24) << 8, v.x & 0x00ffffffu, v.y};
+	}
+	return load_elem(base + i);
+}
+__device__ __forceinline__ void store_elem_m(BinElem* base, size_t i, const BinElem e, int compact)
+{
+	if (compact) reinterpret_cast<uint2*>(base)[i] = make_uint2(((e.x >> 8) << 24) | e.y, e.z);
+	else store_elem(base + i, e);
+}
+// the element's tile id alone (low byte zero in the compact form)
+__device__ __forceinline__ uint32_t elem_tile_m(const BinElem* base, size_t i, int compact)
+{
+	return compact ? (reinterpret_cast<const uint2*>(base)[i].x >> 24) << 8 : base[i].x;
+}
+// its sort key inside a tile: (depth bits, Gaussian id)
+__device__ __forceinline__ uint64_t elem_key_m(const BinElem* base, size_t i, int compact)
+{
+	if (compact) {
+		const uint2 v = reinterpret_cast<const uint2*>(base)[i];
+		return ((uint64_t)v.y << 32) | (uint64_t)(v.x & 0x00ffffffu);
+	}
+	const BinElem e = load_elem(base + i);
+	return ((uint64_t)e.z << 32) | (uint64_t)e.y;
+}
 #define BSR_HIST_BLOCKS_MAX 2048
 struct BinState {
 	uint32_t* point_list; // [R] gaussian ids, tile-major, (depth, id)-sorted  (first: the backward needs only this); once
