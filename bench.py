@@ -596,7 +596,7 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
               "rows_per_rank": info["counts"],
               "bytes_per_rank": info["bytes"], "filter_ms": round(info["filter_ms"], 3), "pack_ms": round(info["pack_ms"], 3),
               "comm_ms": round(D.max_over_ranks(info["comm_ms"]), 3), "distribution_ms": round(dist_s * 1e3, 3)}
-    if D.multi and args.c4_forms == "all":
+    if D.multi and args.experimental and args.c4_forms == "all":
         # the two pipelined forms beside it (DESIGN.md "Multi-GPU"): which one a node prefers is for such a record to say.
         # Opt-in: their unbatched point-to-point sends have never run on RCCL with more than one rank, and a hang there
         # must not cost the default invocation its line.
@@ -627,7 +627,7 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     # then packs and sends rank by rank (remote ranks first, own block last); every rank renders from its arrival on.
     # Evaluated for even view blocks and for the best UNEVEN split (the source, busy distributing, takes fewer views);
     # broadcast path: 236 B P / link rate + ceil(views / N) views per rank.
-    if D.rank == 0:
+    if D.rank == 0 and args.experimental:
         LINK_GBS = 153.0   # xGMI, one link (MI355X guide); point-to-point mesh: the N - 1 sends run on their own links
         row_bytes = (3 + 3 + 4 + 1 + 3 * M) * 4
         per_view_ms = sc_out["views_per_call_16"]["ms_per_view_per_rank"]
@@ -755,6 +755,13 @@ def main():
     ap.add_argument("--strict-gradients", action="store_true",
                     help="BSR_FLAG_EXACT_GRAD on every call: the reference's per-pair operations in the backward tile "
                          "walk (meets SURVEY 8(d)'s elementwise gradient bar); the metric is quoted on the default")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the long legs (the 180- and 720-view C4 presets, capacity-mode and HIP-graph legs) and "
+                         "echo the detail record on stderr; the contract line on stdout stays compact either way")
+    ap.add_argument("--experimental", action="store_true",
+                    help="C4 leg: also evaluate the latency model of the visible-subset distribution and (with --c4-forms "
+                         "all) its pipelined forms (bloomscene_amd.experimental; validated on gloo only)")
+    ap.add_argument("--detail", default="", help="where the detail record (JSON) is written")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps run for this long BEFORE the W warm-up steps of the headline workload, so that the "
                          "GPU clocks have ramped when the K timed steps start (reported as prewarm_steps)")
@@ -805,7 +812,7 @@ def main():
             return err or {"error": "abandoned: this leg failed on another rank"}
         return res
     c4 = None if args.no_c4 else guarded(c4_sweep, D, args)
-    if c4 is not None and headline and "error" not in c4:
+    if c4 is not None and headline and args.full and "error" not in c4:
         # the reference's own rotate360 preset: 180 views, 2 degrees apart (utils/trajectory.py:102-126)
         c4_180 = guarded(c4_sweep, D, args, n_views=180, repeats=3)
         keep = ("workload", "views", "views_per_rank", "broadcast_ms", "views_per_call_16", "views_per_call_16_compacted",
@@ -818,98 +825,170 @@ def main():
     secondary = None
     if D.world == 1 and headline and not args.no_secondary:
         sec_steps = max(20, args.steps // 2)
-        secondary = {
-            "c3_dense_scales_x3": secondary_line(raster_workload(D, args, P, W, H, deg, True, scale_mul=3.0, steps=sec_steps,
-                                                                 label="c3-dense")),
-            "c3_camera_changes_every_step": secondary_line(raster_workload(D, args, P, W, H, deg, True, cycle_views=8,
-                                                                           steps=sec_steps, label="c3-cycling")),
-            "bloomscene_shape": bloomscene_shape_workload(D, args),
-            "bloomscene_shape_no_host_wait": bloomscene_shape_workload(D, args, mode="capacity"),
-            "bloomscene_shape_hip_graph": bloomscene_shape_workload(D, args, mode="graph"),
-            # the forward without its host wait (include/bloomscene_rast.h BSR_FLAG_NO_READBACK), and the whole step as a
-            # HIP graph: the headline workload, and the rasterizer alone at BloomScene's call shape (500 k selected
-            # Gaussians, colors_precomp, sh_degree 1, 512 x 512) where launch gaps and the wait are a larger share
-            # (the headline workload once more, in the same place of the process as the two legs below)
-            "c3_default_again": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
-                                                               label="c3-again")),
-            "c3_capacity_mode": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
-                                                               label="c3-capacity", mode="capacity")),
-            "c3_hip_graph_replay": secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps,
-                                                                  label="c3-graph", mode="graph")),
-            "raster_512_precomp": {m: secondary_line(raster_workload(D, args, 500_000, 512, 512, 1, True, precomp=True,
-                                                                     steps=sec_steps, label="512-" + m, mode=m))
-                                   for m in ("default", "capacity", "graph")},
-        }
 
+        def leg(label, **kw):
+            return secondary_line(raster_workload(D, args, P, W, H, deg, True, steps=sec_steps, label=label, **kw))
+
+        def with_flags(**flags):
+            # a leg under other per-call numerics flags than the headline's (bloomscene_amd.numerics: thread context)
+            from bloomscene_amd import numerics
+
+            def run(label, **kw):
+                with numerics(**flags):
+                    return leg(label, **kw)
+            return run
+        secondary = {
+            "c3_dense_scales_x3": leg("c3-dense", scale_mul=3.0),
+            "c3_camera_changes_every_step": leg("c3-cycling", cycle_views=8),
+            "bloomscene_shape": bloomscene_shape_workload(D, args),
+        }
+        if not (args.exact_exp or args.strict_gradients):
+            # the two bit-for-bit modes of the library on the headline workload: BSR_FLAG_EXACT_GRAD
+            # (the reference's per-pair operations in the backward walk) and BSR_FLAG_EXACT_EXP (forward bit-equal to
+            # the oracle)
+            secondary["c3_strict_gradients"] = with_flags(strict_gradients=True)("c3-strict-gradients")
+            secondary["c3_exact_exp"] = with_flags(exact_exp=True)("c3-exact-exp")
+        if args.full:
+            secondary.update({
+                "bloomscene_shape_no_host_wait": bloomscene_shape_workload(D, args, mode="capacity"),
+                "bloomscene_shape_hip_graph": bloomscene_shape_workload(D, args, mode="graph"),
+                # the forward without its host wait (include/bloomscene_rast.h BSR_FLAG_NO_READBACK), and the whole step
+                # as a HIP graph: the headline workload, and the rasterizer alone at BloomScene's call shape (500 k
+                # selected Gaussians, colors_precomp, sh_degree 1, 512 x 512) where launch gaps and the wait are a larger
+                # share (the headline workload once more, in the same place of the process as the two legs below)
+                "c3_default_again": leg("c3-again"),
+                "c3_capacity_mode": leg("c3-capacity", mode="capacity"),
+                "c3_hip_graph_replay": leg("c3-graph", mode="graph"),
+                "raster_512_precomp": {m: secondary_line(raster_workload(D, args, 500_000, 512, 512, 1, True, precomp=True,
+                                                                         steps=sec_steps, label="512-" + m, mode=m))
+                                       for m in ("default", "capacity", "graph")},
+            })
+
+    device_ids = D.gather_ints(D.dev.index)   # (a collective: every rank)
     if D.rank == 0:
         stages, alg = r["stages"], r["alg"]
         dom = max(stages, key=lambda k: stages[k]) if stages else None
-        roofline = None
+        roofline, roofline_detail = None, None
         if dom is not None:
             achieved = alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9
             traffic, valu, src = measured_traffic(args.config, dom) if headline else (None, None, None)
+            # roofline.traffic is a CONSTANT read from a committed rocprofv3 --pmc profile of the same kernel sources,
+            # never a measurement of this run (counters cannot be collected inside it): traffic_profile names it
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "traffic_source": src, "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4),
-                        "launches_timed": int(r["prof"][dom][1]),
-                        # which stage carried hipEvents INSIDE the timed region (the others: untimed pass afterwards)
-                        "timed_region_events": r["timed_region_events"],
-                        # what actually bounds the tile renderers (same committed PMC passes): VALU instructions
-                        # issued per SIMD and core-clock cycle
-                        "valu_insts_per_simd_cycle": valu}
+                        "traffic_profile": (src or {}).get("profile") if (src or {}).get("matches_timed_build") else None,
+                        "algorithmic_bytes": alg.get(dom, 0), "launch_ms": round(stages[dom], 4),
+                        "launches_timed": int(r["prof"][dom][1])}
+            roofline_detail = dict(roofline, traffic_source=src,
+                                   # which stage carried hipEvents INSIDE the timed region (the others: untimed pass)
+                                   timed_region_events=r["timed_region_events"],
+                                   # what actually bounds the tile renderers (same committed PMC passes): VALU
+                                   # instructions issued per SIMD and core-clock cycle
+                                   valu_insts_per_simd_cycle=valu)
         whole = r["step_bytes"] / (r["ms_per_step"] * 1e-3) / 1e9
-        src = (roofline or {}).get("traffic_source") or {}
-        # roofline.traffic is a CONSTANT read from a committed rocprofv3 --pmc profile of the same kernel sources, never
-        # a measurement of this run (counters cannot be collected inside it)
-        traffic_kind = (f"committed:{src.get('profile')}" if src.get("matches_timed_build") else
-                        "none (committed profile is of other kernel sources)" if src else "none")
-        out = {
+        # ---- the contract line: compact (< 4 KB, asserted), the LAST line of stdout.  Everything else -- per-step
+        # arrays, the C4 record, the secondary legs -- goes to the detail file named in "detail" (and to stderr).
+        line = {
             "metric": "Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3; fraction of HBM roofline" if headline
             else f"Msplats/s ({args.config})",
             "value": round(r["value"], 3), "unit": "Msplats/s", "n_gpus": D.world, "steps": r["steps"],
-            "warmup": r["warmup"], "prewarm_steps": r["prewarm_steps"], "ms_per_step": round(r["ms_per_step"], 4),
-            "higher_is_better": True,
+            "warmup": r["warmup"], "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": r["workload"], "gaussians": P, "width": W, "height": H, "sh_degree": r["deg"],
                        "num_rendered": r["R"], "visible": r["visible"],
                        "parallelism": f"view-parallel x{D.world}" + (" + gradient all-reduce" if args.allreduce_grads
                                                                       and D.multi and do_bwd else ""),
-                       "broadcast_ms": round(r["bcast_ms"], 3), "csrc_sha256": csrc_sha256(),
-                       "exact_exp": int(args.exact_exp), "strict_gradients": int(args.strict_gradients),
-                       # ---- diagnostics of the timed region, flat, so that a record that keeps `config` whole can say
-                       # whether a slow headline was one outlier, a host-bound loop or a uniformly slow leg:
-                       # per-step GPU time (event to event) and per-step HOST time (enqueue loop), in order
+                       "csrc_sha256": csrc_sha256(), "exact_exp": int(args.exact_exp),
+                       "strict_gradients": int(args.strict_gradients),
                        "ms_per_step_median": round(r["ms_per_step_median"], 4),
                        "step_ms_first": round(r["step_ms_first"], 4), "step_ms_max": round(r["step_ms_max"], 4),
-                       "steps_over_1p15x_median": r["steps_over_1p15x_median"],
-                       "host_max_ms_per_step": round(r["max_host_ms"], 3),
-                       "host_median_ms_per_step": round(r["host_median_ms"], 3),
-                       "closing_fence_tail_ms": round(r["tail_ms"], 4),
-                       "device_allocs_in_timed_region": r["device_allocs"],
-                       "sum_stage_ms": round(sum(stages.values()), 4),
-                       "prewarm_steps": r["prewarm_steps"], "prewarm_ms": args.prewarm_ms,
-                       "step_ms": r["step_ms"], "host_step_ms": r["host_step_ms"],
-                       "traffic_kind": traffic_kind},
-            "ms_per_step_median": round(r["ms_per_step_median"], 4),
-            # every timed step on the GPU's clock (event to event), in order, when there are few enough to list
-            "step_ms": r["step_ms"],
+                       "host_max_ms_per_step": round(r["max_host_ms"], 3), "prewarm_steps": r["prewarm_steps"]},
             "roofline": roofline,
             "roofline_step": {"algorithmic_bytes": r["step_bytes"], "achieved": round(whole, 2),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-            "host": {"device_allocs_in_timed_region": r["device_allocs"],
-                     "max_host_ms_per_step": round(r["max_host_ms"], 3)},
         }
+        if D.multi:
+            line["world_size"] = D.world
+            line["config"]["broadcast_ms"] = round(r["bcast_ms"], 3)
+            line["devices"] = device_ids
         if args.allreduce_grads and D.multi:
-            out["config"]["allreduce_ms_per_step"] = round(r["allreduce_ms_per_step"], 4)
+            line["config"]["allreduce_ms_per_step"] = round(r["allreduce_ms_per_step"], 4)
         if c4 is not None:
-            out["c4"] = c4
+            line["c4"] = c4_summary(c4)
         if secondary is not None:
-            out["secondary"] = secondary
+            line["secondary_Msplats_per_s"] = {k: (v.get("value") if isinstance(v, dict) and "value" in v else None)
+                                               for k, v in secondary.items() if k != "raster_512_precomp"}
         if D.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, P, W, H, r["deg"], do_bwd, precomp)
-        print(json.dumps(out), flush=True)
+            line["cpu_baseline"] = cpu_baseline(args, P, W, H, r["deg"], do_bwd, precomp)
+        detail = dict(line)
+        detail["roofline"] = roofline_detail
+        detail["config"] = dict(line["config"], broadcast_ms=round(r["bcast_ms"], 3),
+                                steps_over_1p15x_median=r["steps_over_1p15x_median"],
+                                host_median_ms_per_step=round(r["host_median_ms"], 3),
+                                closing_fence_tail_ms=round(r["tail_ms"], 4),
+                                device_allocs_in_timed_region=r["device_allocs"],
+                                sum_stage_ms=round(sum(stages.values()), 4), prewarm_ms=args.prewarm_ms)
+        detail["step_ms"] = r["step_ms"]
+        detail["host_step_ms"] = r["host_step_ms"]
+        detail.pop("secondary_Msplats_per_s", None)
+        if c4 is not None:
+            detail["c4"] = c4
+        if secondary is not None:
+            detail["secondary"] = secondary
+        line["detail"] = write_detail(detail, args)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) >= MAX_LINE_BYTES:   # never print a line the driver cannot parse: drop the optional blocks
+            for k in ("secondary_Msplats_per_s", "c4", "roofline_step", "devices"):
+                line.pop(k, None)
+            line["truncated"] = True
+            text = json.dumps(line, separators=(",", ":"))
+        sys.stdout.flush()
+        print(text, flush=True)
     D.close()
+
+
+MAX_LINE_BYTES = 4096
+
+
+def c4_summary(c4):
+    """The C4 record in a handful of numbers (the whole record: the detail file).  cold = Gaussians on rank 0 when the
+    clock starts (packed RCCL broadcast + sweep); resident = the sweep alone, Gaussians already on every rank."""
+    if "error" in c4:
+        return {"error": str(c4["error"])[:200]}
+    v16 = c4.get("views_per_call_16", {})
+    sv = c4.get("scatter_visible", {})
+    out = {"views": c4.get("views"), "scaling": "strong", "n_gpus": c4.get("n_gpus"),
+           "views_per_rank": c4.get("views_per_rank"), "unit": "Msplats/s",
+           "broadcast_ms": c4.get("broadcast_ms"),
+           "sweep_ms_resident": v16.get("sweep_ms"), "value_resident": v16.get("value"),
+           "sweep_ms_cold": round(v16.get("sweep_ms", 0.0) + c4.get("broadcast_ms", 0.0), 3),
+           "value_cold": v16.get("value_including_broadcast"),
+           "sweep_ms_1_view_per_call": c4.get("views_per_call_1", {}).get("sweep_ms")}
+    if sv:
+        loc = sv.get("views_per_call_16", {})
+        out["scatter_visible"] = {"distribution_ms": sv.get("distribution_ms"), "sweep_ms": loc.get("sweep_ms"),
+                                  "value_cold": loc.get("value_including_distribution")}
+    return out
+
+
+def write_detail(detail, args):
+    """Everything the contract line leaves out, as JSON: to the file --detail names (default bench_detail.json beside
+    bench.py, or under gpurun_out/ when that exists so that it travels back from a GPU box) and, with --full, to stderr.
+    Returns the path written (None when no location was writable)."""
+    text = json.dumps(detail)
+    if args.full:
+        print(text, file=sys.stderr, flush=True)
+    path = args.detail
+    if not path:
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        path = os.path.join(out_dir if os.path.isdir(out_dir) else ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as fh:
+            fh.write(text + "\n")
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        return None
 
 
 def cpu_baseline(args, P, W, H, deg, do_bwd, precomp=False):

@@ -7,22 +7,37 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-def _run_bench(extra, env_extra=None, nproc=None):
-    """bench.py as a child process (optionally under torch.distributed.run with one rank); returns its JSON line."""
+MAX_LINE_BYTES = 4096   # the driver reads the LAST stdout line; round 5's 22 KB line left BENCH_r05.parsed = null
+
+
+def _run_bench(extra, env_extra=None, nproc=None, want_line=False):
+    """bench.py as a child process (optionally under torch.distributed.run with one rank).  Checks the contract of
+    its stdout -- the LAST line is one compact JSON object -- and returns the DETAIL record it wrote (a superset of the
+    line: per-step arrays, the whole C4 record, the secondary legs); want_line: (line, detail)."""
     import json
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **(env_extra or {}))
     cmd = [sys.executable]
     if nproc:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                 "--master-port", "29533"]
-    cmd += [os.path.join(root, "bench.py")] + extra
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
-    return json.loads(lines[-1])
+    with tempfile.TemporaryDirectory() as tmp:
+        detail_path = os.path.join(tmp, "detail.json")
+        cmd += [os.path.join(root, "bench.py")] + extra + ["--detail", detail_path]
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip(), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+        last = r.stdout.rstrip("\n").splitlines()[-1]
+        assert len(last.encode()) < MAX_LINE_BYTES, len(last)
+        line = json.loads(last)                       # the last line alone must parse
+        assert line["detail"] == detail_path
+        with open(detail_path) as fh:
+            detail = json.load(fh)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "config", "roofline", "stage_ms"):
+        assert line[k] == detail[k] or k in ("config", "roofline"), k
+    return (line, detail) if want_line else detail
 
 
 def test_bench_rccl_path_on_one_rank():
@@ -50,7 +65,7 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     ranks on the one GPU of this box over gloo (RCCL refuses two ranks on one device; the RCCL calls themselves are
     exercised by test_bench_rccl_path_on_one_rank).  A reduced Gaussian count keeps it short."""
     d = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "200000", "--allreduce-grads",
-                    "--no-cpu-baseline", "--c4-forms", "all"],
+                    "--no-cpu-baseline", "--experimental", "--c4-forms", "all"],
                    env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=2)
     sv = d["c4"]["scatter_visible"]
     assert sv["distribution_ms_pipelined"] > 0 and sv["distribution_ms_blockwise"] > 0
@@ -74,28 +89,49 @@ def test_bench_launches_its_own_ranks_when_typed_plainly():
 
 
 def test_bench_headline_line_has_the_contract_keys():
-    """The default invocation's JSON (shortened): contract keys, roofline, C4 and the secondary workloads."""
-    d = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-sample", "20000"])
+    """The default invocation (shortened): the LAST stdout line is a compact (< 4 KB) JSON object with the contract
+    keys, config.workload, roofline and cpu_baseline -- what the driver parses into BENCH_rNN.json -- and the detail
+    record beside it holds the C4 sweep and the secondary workloads."""
+    line, d = _run_bench(["--steps", "8", "--warmup", "2", "--cpu-sample", "20000"], want_line=True)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["steps"] == 8 and d["config"]["gaussians"] == 1_000_000 and d["dtype"] == "f32"
-    rf = d["roofline"]
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_step", "stage_ms", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"].startswith("Msplats/s fwd+bwd @1M Gaussians 1920x1080 SH3")
+    assert line["steps"] == 8 and line["warmup"] == 2 and line["n_gpus"] == 1 and line["dtype"] == "f32"
+    assert line["vs_baseline"] is None and line["higher_is_better"] is True and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["workload"].startswith("c3: 1000000 Gaussians, SH deg 3, 1920x1080, fwd+bwd")
+    assert cfg["gaussians"] == 1_000_000 and cfg["num_rendered"] > 4_000_000 and "model" not in cfg
+    assert len(cfg["csrc_sha256"]) == 16 and cfg["exact_exp"] == 0 and cfg["strict_gradients"] == 0
+    for k in ("ms_per_step_median", "step_ms_first", "step_ms_max", "host_max_ms_per_step"):
+        assert cfg[k] > 0, k
+    assert abs(line["value"] - 1e-3 * cfg["gaussians"] / line["ms_per_step"]) < 0.01 * line["value"]
+    rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel"] == "render_bwd" and 0 < rf["frac"] < 1 and rf["peak"] == 8000.0
     assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-4
+    assert abs(rf["algorithmic_bytes"] / (rf["launch_ms"] * 1e-3) / 1e9 - rf["achieved"]) < 0.01 * rf["achieved"]
     # inside the timed region only the dominant stage carries events (every 4th of the 8 steps); the stage table is complete
-    assert rf["timed_region_events"]["stage"] == "render_bwd" and rf["launches_timed"] == 2
-    assert set(d["stage_ms"]) >= {"preprocess", "scan_wg", "binning", "sort_tiles", "render_fwd", "render_bwd",
-                                  "preprocess_bwd"}
+    assert rf["launches_timed"] == 2 and d["roofline"]["timed_region_events"]["stage"] == "render_bwd"
+    assert set(line["stage_ms"]) >= {"preprocess", "scan_wg", "binning", "sort_tiles", "render_fwd", "render_bwd",
+                                     "preprocess_bwd"}
     # the committed counter passes count only while they belong to the kernel sources being timed
-    src = rf["traffic_source"]
+    src = d["roofline"]["traffic_source"]
     assert src is None or (rf["traffic"] is not None) == src["matches_timed_build"]
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    assert d["c4"]["views_per_rank"] == [64] and d["c4"]["broadcast_ms"] == 0.0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Msplats/s" and cb["sample"]
+    # the C4 summary of the line, and the whole record in the detail file
+    c4 = line["c4"]
+    assert c4["views"] == 64 and c4["views_per_rank"] == [64] and c4["broadcast_ms"] == 0.0
+    assert c4["value_resident"] > 0 and c4["sweep_ms_cold"] >= c4["sweep_ms_resident"] > 0
+    assert d["c4"]["views_per_rank"] == [64] and "predicted" not in d["c4"]        # (the model: --experimental only)
     sec = d["secondary"]
     assert sec["c3_dense_scales_x3"]["instances_per_gaussian"] > 10       # long tile lists
     assert sec["c3_camera_changes_every_step"]["value"] > 0 and sec["bloomscene_shape"]["value"] > 0
-    assert d["host"]["device_allocs_in_timed_region"] == 0
+    # the strict-gradient and exact-exp modes are on the record, beside the default they are slower than
+    assert 0 < sec["c3_strict_gradients"]["value"] and 0 < sec["c3_exact_exp"]["value"]
+    assert line["secondary_Msplats_per_s"]["c3_strict_gradients"] == sec["c3_strict_gradients"]["value"]
+    assert d["config"]["device_allocs_in_timed_region"] == 0
+    assert len(d["step_ms"]) == 8
 
 
 def test_profile_only_brackets_one_stage():
