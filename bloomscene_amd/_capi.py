@@ -19,6 +19,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _F = C.c_void_p  # device pointer
 ABI_VERSION = 3  # BSR_VERSION of include/bloomscene_rast.h this binding was written against
+OLDER_ABI_ACCEPTED = frozenset({2})   # use_library(..., allow_older_abi=True): 2 -> 3 only added entry points
 
 
 class StageProfile(C.Structure):
@@ -116,7 +117,8 @@ def lib():
         # a stale build of another ABI version would shift arguments silently (several entry points changed their
         # parameter lists in place between versions): refuse it before binding anything
         handle.bsr_version.restype = C.c_int
-        older = handle.bsr_version() < ABI_VERSION and _allow_older_abi
+        # (only 2 -> 3 was additive; a version-1 library bound with these signatures would shift arguments silently)
+        older = handle.bsr_version() in OLDER_ABI_ACCEPTED and _allow_older_abi
         if handle.bsr_version() != ABI_VERSION and not older:
             raise RuntimeError(f"{LIB_PATH} is ABI version {handle.bsr_version()}, this binding needs {ABI_VERSION}: "
                                f"rebuild it (make -C {CSRC})")

@@ -81,7 +81,7 @@ BinState BinState::carve(char* p, size_t R, bool with_slab)
 }
 size_t ImgState::bytes(size_t N, size_t T)
 {
-	return 2 * align_up(N * 4, 256) + align_up((T + 1) * 4, 256) + BSR_FLAGS_BYTES + align_up(3 * T * 4, 256) + 256;
+	return 2 * align_up(N * 4, 256) + align_up(T * sizeof(uint2), 256) + BSR_FLAGS_BYTES + align_up(3 * T * 4, 256) + 256;
 }
 ImgState ImgState::carve(char* p, size_t N, size_t T)
 {
@@ -89,7 +89,7 @@ ImgState ImgState::carve(char* p, size_t N, size_t T)
 	p = (char*)align_up((size_t)p, 256);
 	i.final_T = (float*)p;        p += align_up(N * 4, 256);
 	i.n_contrib = (uint32_t*)p;   p += align_up(N * 4, 256);
-	i.tile_start = (uint32_t*)p;  p += align_up((T + 1) * 4, 256);
+	i.tile_range = (uint2*)p;     p += align_up(T * sizeof(uint2), 256);
 	i.flags = (int*)p;            p += BSR_FLAGS_BYTES;
 	i.big_tiles = (uint32_t*)p;
 	return i;
@@ -182,18 +182,19 @@ void launch_visible_filter_views(int P, int V, const float* means3D, const float
                                  uint32_t* group_counts, hipStream_t s);
 void launch_pack_rows(int R, int P, int n_src, const float* const* src, const int* widths, const int64_t* idx,
                       int idx_stride, float* dst_packed, float* const* dst_each, hipStream_t s);
-void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s);
+void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, int* host_counts,
+                  hipStream_t s);
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
-                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint2* tile_range, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s);
-void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
-                       const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
-                       uint32_t* point_list, int compact, hipStream_t s);
-void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+void launch_sort_tiles(int P, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
+                       const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
+                       BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s);
+void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint2* tile_range,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, bool exact_exp, bool nan_on_overflow, int* pool_ctr, hipStream_t s);
-void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+void launch_render_bwd(int gx, int gy, int W, int H, const uint2* tile_range, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
                        int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s);
@@ -375,6 +376,15 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	{   // the deferred status of this thread's previous no-readback forward comes first
 		SyncCache* sc0 = sync_cache();
 		if (!sc0) return 1;
+		if (sc0->pending) {
+			// the check is a blocking host wait on an event: inside a stream capture that would invalidate the capture
+			// (or hang, depending on the capture mode) -- say so instead
+			hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+			if (hipStreamIsCapturing(s, &cs0) != hipSuccess) { (void)hipGetLastError(); cs0 = hipStreamCaptureStatusNone; }
+			if (cs0 != hipStreamCaptureStatusNone)
+				return fail("forward during stream capture while the overflow check of this thread's previous BSR_FLAG_NO_READBACK "
+				            "forward is pending: call bsr_check_deferred() before hipStreamBeginCapture");
+		}
 		if (check_deferred(sc0)) return 1;
 	}
 	if (no_readback) *num_rendered = (int)given_capacity;   // what the backward must be handed as R (same carve)
@@ -435,9 +445,20 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		}
 		STAGE_CHECK("preprocess", debug, s);
 	}
+	SyncCache* sc = sync_cache();
+	if (!sc) return 1;
+	// k_scans writes the four counters straight into this thread's pinned, device-mapped landing buffer (no copy on the
+	// stream) -- unless the stream is capturing: a graph must not carry a pointer into a host thread's buffer, and an
+	// event recorded into a graph cannot be waited for on the host anyway
+	bool capturing = false;
+	if (no_readback) {
+		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+		capturing = cs != hipStreamCaptureStatusNone;
+	}
 	{
 		StageTimer t("scan_wg", s);
-		launch_scans(n_wg, geom.wg_kept, geom.wg_area, img.flags, geom.hist1, s);
+		launch_scans(n_wg, geom.wg_kept, geom.wg_area, img.flags, geom.hist1, capturing ? nullptr : sc->pinned_dev, s);
 	}
 	STAGE_CHECK("scan_wg", debug, s);
 
@@ -451,8 +472,6 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	// read, all remaining kernels are enqueued behind the copy, and the host only waits for the copy's
 	// event (to return num_rendered).  If the guess was too small those kernels returned without touching
 	// anything and the tail is simply run again with the exact size.
-	SyncCache* sc = sync_cache();
-	if (!sc) return 1;
 	const bool guess = sc->last_P == P && sc->last_W == width && sc->last_H == height && sc->last_V == V && sc->last_R > 0;
 	size_t cap = 0;
 	BinState bin;
@@ -478,13 +497,15 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		{
 			StageTimer t("binning", s);
 			launch_binning((int)P_rows, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
-			               img.tile_start, img.big_tiles, img.flags, &elems_sorted, &elems_free, &elems_compact, s);
+			               img.tile_range, img.big_tiles, img.flags, &elems_sorted, &elems_free, &elems_compact, s);
 		}
 		STAGE_CHECK("binning", debug, s);
 		{
 			StageTimer t("sort_tiles", s);
-			launch_sort_tiles(T, (int)capacity, n_ptr, (int)capacity, img.tile_start, img.big_tiles, img.flags,
-			                  elems_sorted, elems_free, bin.point_list, elems_compact, s);
+			// (the 256 digit totals of pass 1 lie behind the rows of hist1)
+			const uint32_t* digit_total1 = geom.hist1 + (size_t)256 * (((size_t)n_wg + 7) / 8 * 8);
+			launch_sort_tiles((int)P_rows, T, (int)capacity, n_ptr, (int)capacity, img.tile_range, img.big_tiles, img.flags,
+			                  digit_total1, elems_sorted, elems_free, bin.point_list, elems_compact, s);
 		}
 		STAGE_CHECK("sort_tiles", debug, s);
 		{
@@ -493,7 +514,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			// backward in the top byte of the point_list words (flags[6] says whether it did)
 			int* const masks_flag = (V == 1 && P <= (1 << 24) && !g_opt_no_half_masks.load(std::memory_order_relaxed))
 			                            ? img.flags + 6 : nullptr;
-			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_start, bin.point_list, masks_flag, geom.rec,
+			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_range, bin.point_list, masks_flag, geom.rec,
 			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
 			                  (flags & BSR_FLAG_EXACT_EXP) != 0, no_readback, img.flags + BSR_POOL_FWD, s);
 		}
@@ -503,11 +524,8 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		// The caller's capacity sizes the scratch; nothing is waited for.  The counters still travel to the pinned buffer
 		// (checked by this thread's next forward / bsr_check_deferred) unless the stream is capturing: an event recorded
 		// into a graph cannot be waited for on the host.
-		hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-		if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-		if (cs == hipStreamCaptureStatusNone) {
-			HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-			HIP_TRY(hipEventRecord(sc->deferred, s));
+		if (!capturing) {
+			HIP_TRY(hipEventRecord(sc->deferred, s));   // (behind k_scans, which wrote the counters to the pinned buffer)
 			sc->pending = true;
 			sc->pending_capacity = (size_t)given_capacity;
 		}
@@ -515,8 +533,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		STAGE_CHECK("render_fwd", debug, s);
 		return 0;
 	}
-	HIP_TRY(hipMemcpyAsync(sc->pinned, img.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-	HIP_TRY(hipEventRecord(sc->copied, s));
+	HIP_TRY(hipEventRecord(sc->copied, s));   // behind k_scans: the counters are in the pinned buffer when it completes
 	if (guess) {
 		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
 		if (c > 0x7fffffffu) c = 0x7fffffffu;
@@ -915,7 +932,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	if (R > 0) {
 		{
 			StageTimer t("render_bwd", s);
-			launch_render_bwd(gx, gy, width, height, img.tile_start, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
+			launch_render_bwd(gx, gy, width, height, img.tile_range, bin.point_list, geom.rec, geom.wg_kept, background, img.final_T,
 			                  img.n_contrib, dL_dpix, out_depth, out_depth ? dL_depths : nullptr, img.flags + 6, slab,
 			                  (flags & BSR_FLAG_EXACT_GRAD) != 0, R, s);
 		}

@@ -89,7 +89,7 @@ struct Hist1ColumnValid {
 };
 __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__ wg_kept,
                                                 uint32_t* __restrict__ wg_area, int* __restrict__ flags,
-                                                uint32_t* __restrict__ hist1)
+                                                uint32_t* __restrict__ hist1, int* __restrict__ host_counts)
 {
 	__shared__ uint32_t s_w[16];
 	__shared__ uint32_t s_c;
@@ -103,6 +103,16 @@ __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__
 			flags[1] = flags[4] = flags[5] = 0;   // counters of k_tile_ranges (the image buffer arrives uninitialised)
 			flags[6] = flags[7] = 0;
 			flags[BSR_POOL_FWD] = flags[BSR_POOL_BWD] = 0;   // pool counters of the two tile walks (common.h: pooled_tile)
+			if (host_counts != nullptr) {
+				// the forward's one read-back (reference rasterizer_impl.cu:282), without a copy: the four counters go
+				// straight into the calling thread's pinned, device-mapped landing buffer; the host waits for the event
+				// recorded behind this kernel (a 16-byte hipMemcpyAsync was a 4 us operation of its own on the stream)
+				host_counts[0] = flags[0];
+				host_counts[1] = 0;
+				host_counts[2] = (int)kept;
+				host_counts[3] = (int)area;
+				__threadfence_system();
+			}
 		}
 		return;
 	}
@@ -430,7 +440,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
 template <int NC>   // chunks held in registers: 8 (up to 8192 tiles: one 1080p view) or 64 (16-bit tile ids)
 __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restrict__ n_ptr, int capacity,
                                                       const uint32_t* __restrict__ tile_count,
-                                                      uint32_t* __restrict__ tile_start,
+                                                      uint2* __restrict__ tile_range,
                                                       uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
 {
 	__shared__ uint32_t s_tot[1024];         // [chunk][wave] totals (NC x 16 used), then their exclusive prefix
@@ -444,7 +454,7 @@ __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restri
 		const int n = *n_ptr;
 		if (n > capacity) return;   // overflow: the stage is re-run
 		if (n <= 0) {               // nothing kept: every tile is empty (the counts were not even zeroed)
-			for (int t = tid; t <= T; t += 1024) tile_start[t] = 0u;
+			for (int t = tid; t < T; t += 1024) tile_range[t] = make_uint2(0u, 0u);
 			return;
 		}
 	}
@@ -471,12 +481,14 @@ __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restri
 		uint32_t run = incl - mine;
 		for (int w = 0; w < wave; w++) run += s_w[w];
 		s_tot[tid] = run;
-		if (tid == 1023) tile_start[T] = run + mine;   // the total
 	}
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NC; j++)
-		if (j < chunks && (j << 10) + tid < T) tile_start[(j << 10) + tid] = s_tot[j * 16 + wave] + c[j];
+		if (j < chunks && (j << 10) + tid < T) {
+			const uint32_t first = s_tot[j * 16 + wave] + c[j];
+			tile_range[(j << 10) + tid] = make_uint2(first, first + tile_count[(j << 10) + tid]);   // (the count: an L2 hit)
+		}
 	if (__syncthreads_or(any_big)) {   // rare: the filing re-reads the counts
 		for (int j = 0; j < chunks; j++) {
 			const int t = (j << 10) + tid;
@@ -500,7 +512,7 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
                                                       const uint32_t* __restrict__ digit_total1,
                                                       const BinElem* __restrict__ elems_in,
                                                       BinElem* __restrict__ elems_out,
-                                                      const uint32_t* __restrict__ tile_start,
+                                                      const uint2* __restrict__ tile_range,
                                                       uint32_t* __restrict__ tile_cursor, int compact)
 {
 	__shared__ uint32_t s_hist[BSR_RADIX_BINS];
@@ -535,7 +547,7 @@ __global__ void __launch_bounds__(256) k_tile_scatter(int T, int n_slices, const
 		const uint32_t c = s_hist[tid];
 		const uint32_t t = ((uint32_t)tid << BSR_RADIX_BITS) | (uint32_t)d1;
 		uint32_t off = 0;
-		if (c != 0u && t < (uint32_t)T) off = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+		if (c != 0u && t < (uint32_t)T) off = tile_range[t].x + atomicAdd(&tile_cursor[t], c);
 		s_off[tid] = off;
 	}
 	__syncthreads();
@@ -593,11 +605,11 @@ __device__ __forceinline__ int first_not_below_row16(const BinElem* __restrict__
 }
 
 // One wave per three tiles: row k (16 lanes) finds the start of tile 3w + k, k = 0..3; rows 0..2 own their tile
-// (start written, size class decided with the next row's start as the end), row 3 only delivers the end of tile
-// 3w + 2.  The wave that owns tile T - 1 also writes tile_start[T].
+// (range written, size class decided with the next row's start as the end), row 3 only delivers the end of tile
+// 3w + 2.
 __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restrict__ n_ptr, int capacity,
                                                      const BinElem* __restrict__ elems_sorted,
-                                                     uint32_t* __restrict__ tile_start,
+                                                     uint2* __restrict__ tile_range,
                                                      uint32_t* __restrict__ big_tiles, int* __restrict__ flags)
 {
 	int n = *n_ptr;
@@ -612,8 +624,8 @@ __global__ void __launch_bounds__(256) k_tile_ranges(int T, const int* __restric
 		const int lo = (t <= T) ? first_not_below_row16(elems_sorted, n, (uint32_t)t, lane) : n;
 		const int hi = __shfl_down(lo, 16, 64);   // the next row's start
 		const bool owner = row < 3 && (lane & 15) == 0;
-		if (owner && t <= T) tile_start[t] = (uint32_t)lo;
 		if (owner && t < T) {
+			tile_range[t] = make_uint2((uint32_t)lo, (uint32_t)hi);
 			cnt_t = hi - lo;
 			big = cnt_t > BSR_SORT_SMALL;
 		}
@@ -869,9 +881,19 @@ __device__ __forceinline__ void lds_sort_rounds(uint64_t* keys, int n2, int t)
 // are sorted in registers on the way in (integer compare-exchange: the flavour of the merges is only known once every
 // key has been seen) and the pads up to n2 are stored with them; returns this thread's vote on "every key I loaded is
 // a positive, normal, finite binary64".
-template <int NT, int M>
-__device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_t start, int n, int t,
-                                                 const BinElem* __restrict__ elems, int compact)
+// Where a segment's unsorted keys come from: the binning elements (8- or 12-byte form), or plain 64-bit keys
+// (k_bucket_sort stages its long tiles that way).  operator()(i) = key at global position i.
+struct ElemKeys {
+	const BinElem* __restrict__ elems;
+	int compact;
+	__device__ __forceinline__ uint64_t operator()(size_t i) const { return elem_key_m(elems, i, compact); }
+};
+struct RawKeys {
+	const uint64_t* keys;   // (no __restrict__: k_bucket_sort writes the scratch it then sorts from)
+	__device__ __forceinline__ uint64_t operator()(size_t i) const { return keys[i]; }
+};
+template <int NT, int M, typename Src>
+__device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_t start, int n, int t, const Src src)
 {
 	constexpr int K = 1 << M;
 	bool plain = true;
@@ -879,7 +901,7 @@ __device__ __forceinline__ bool load_sorted_runs(uint64_t* keys, int n2, uint32_
 		uint64_t e[K];
 #pragma unroll
 		for (int j = 0; j < K; j++) {
-			e[j] = i + j < n ? elem_key_m(elems, (size_t)start + (size_t)(i + j), compact) : BSR_PAD_KEY;
+			e[j] = i + j < n ? src((size_t)start + (size_t)(i + j)) : BSR_PAD_KEY;
 			plain = plain && (i + j >= n || key_is_plain_double(e[j]));
 		}
 		reg_sort<M, false>(e);
@@ -907,7 +929,7 @@ __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32
                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
                                                   bool force_int, int compact)
 {
-	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, elems, compact) && !force_int;
+	const bool plain = load_sorted_runs<64, M>(keys, n2, start, n, lane, ElemKeys{elems, compact}) && !force_int;
 	if (wave_ballot(!plain) == 0ull)
 		merge_loaded_runs<64, M, false, true>(keys, n2, start, n, lane, point_list);
 	else
@@ -915,12 +937,11 @@ __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32
 }
 
 // Workgroup-owned segment (the wide classes): the same, with workgroup barriers and a workgroup vote.
-template <int NT, int M>
-__device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint32_t start, int n, int tid,
-                                                   const BinElem* __restrict__ elems, uint32_t* __restrict__ point_list,
-                                                   bool force_int, int compact)
+template <int NT, int M, typename Src>
+__device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint32_t start, int n, int tid, const Src src,
+                                                   uint32_t* __restrict__ point_list, bool force_int)
 {
-	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, elems, compact) && !force_int;
+	const bool plain = load_sorted_runs<NT, M>(keys, n2, start, n, tid, src) && !force_int;
 	if (__syncthreads_and(plain))
 		merge_loaded_runs<NT, M, true, true>(keys, n2, start, n, tid, point_list);
 	else
@@ -932,7 +953,7 @@ __device__ __forceinline__ void sort_segment_block(uint64_t* keys, int n2, uint3
 // tile), counted against the wave's keys broadcast one by one from SGPRs.  27 keys: ~110 instructions, against a
 // merge network that keeps 4 of 64 lanes busy and a 32-KB LDS footprint that caps the small class at 20 waves per CU.
 __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __restrict__ n_ptr, int capacity,
-                                                         const uint32_t* __restrict__ tile_start,
+                                                         const uint2* __restrict__ tile_range,
                                                          const BinElem* __restrict__ elems,
                                                          uint32_t* __restrict__ point_list, int compact)
 {
@@ -940,8 +961,9 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 	const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (tile >= T) return;
 	const int n_instances = *n_ptr;
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
+	const uint2 range = tile_range[tile];
+	const uint32_t start = range.x;
+	const int n = (int)(range.y - range.x);
 	if (n_instances > capacity || n > 64 || n <= 0) return;   // (scratch too small: stage is re-run) / another class / empty
 	uint64_t key = ~0ull;
 	if (lane < n) key = elem_key_m(elems, (size_t)start + (size_t)lane, compact);
@@ -958,7 +980,7 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 // Small class (min_n < n <= BSR_SORT_SMALL): one WAVE per tile, four tiles per workgroup, no workgroup barrier; 8 keys per
 // lane and round (16 in two trips beyond 512 keys).
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
-                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint2* __restrict__ tile_range,
                                                           const BinElem* __restrict__ elems,
                                                           uint32_t* __restrict__ point_list, int force_int, int min_n,
                                                           int compact)
@@ -967,12 +989,67 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * 4 + wave;
 	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
+	const uint2 range = tile_range[tile];
+	const uint32_t start = range.x;
+	const int n = (int)(range.y - range.x);
 	if (n > BSR_SORT_SMALL || n <= min_n) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (min_n = 64) or empty
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
 	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0, compact);   // (> 512 keys: two runs per lane)
+}
+
+// One long segment, 1024 < n <= BSR_SORT_CHUNK keys, sorted in `s_keys` (BSR_SORT_CHUNK slots) by the NT threads of
+// the workgroup and read out to point_list[start ..).  Ends with a barrier (the keys are read out before the caller
+// loads the next segment).
+#define BSR_SORT_CHUNK 4096
+template <int NT, typename Src>
+__device__ __forceinline__ void sort_long_tile_lds(uint64_t* s_keys, uint32_t start, int n, int tid, const Src src,
+                                                   uint32_t* __restrict__ point_list, bool force_int)
+{
+	int n2 = 1024;
+	while (n2 < n) n2 <<= 1;
+	sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, src, point_list, force_int);
+	__syncthreads();
+}
+// One segment of n > BSR_SORT_CHUNK keys, hybrid: every 4096-key chunk sorted in LDS into the global scratch k[0 .. n)
+// (`src` may read that very scratch: a chunk is loaded completely before it is written back), the merge steps between
+// chunks in global memory, the steps inside a chunk in LDS again.  Integer compare-exchange throughout (the global
+// steps compare integers too).
+template <int NT, typename Src>
+__device__ __forceinline__ void sort_long_tile_hybrid(uint64_t* s_keys, uint64_t* k, uint32_t start, int n, int tid,
+                                                      const Src src, uint32_t* __restrict__ point_list)
+{
+	constexpr int CH = BSR_SORT_CHUNK;
+	int n2 = 1;
+	while (n2 < n) n2 <<= 1;
+	// runs of CH: every chunk sorted on its own in LDS
+	for (int base = 0; base < n; base += CH) {
+		const int m = min(CH, n - base);
+		__syncthreads();
+		load_sorted_runs<NT, 3>(s_keys, CH, start + (uint32_t)base, m, tid, src);
+		lds_sort_rounds<NT, 3, true, false>(s_keys, CH, tid);
+		for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
+	}
+	// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
+	for (int size = 2 * CH; size <= n2; size <<= 1) {
+		__syncthreads();
+		merge_mirror_step<NT>(k, n, n2, size, tid);
+		for (int stride = size >> 2; stride >= CH; stride >>= 1) {
+			__syncthreads();
+			merge_stride_step<NT>(k, n, n2, stride, tid);
+		}
+		for (int base = 0; base < n; base += CH) {
+			const int m = min(CH, n - base);
+			__syncthreads();
+			for (int i = tid; i < CH; i += NT) s_keys[swz_m<3>(i)] = i < m ? k[base + i] : BSR_PAD_KEY;
+			lds_stride_rounds<NT, 3, true, false>(s_keys, CH, 12, tid);   // strides CH/2 .. 1
+			__syncthreads();
+			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
+	__syncthreads();
 }
 
 // Wide classes, ONE launch (a frame without long lists -- C3 -- pays one near-empty launch instead of two; until round 5
@@ -982,12 +1059,11 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 // hybrid: every 4096-key chunk sorted in LDS, the merge steps between chunks in global scratch (`keys` = the free
 // ping-pong buffer viewed as u64), the steps inside a chunk in LDS again.  Bounded grids: n instances fill at most
 // n / 1025 (n / 4097) such tiles, capped -- the workgroups stride.
-#define BSR_SORT_CHUNK 4096
 #define BSR_SORT_NT 512
 // (64 VGPRs: with 33 KB of LDS a CU holds four workgroups = 8 waves per SIMD; the hybrid path alone would take 70 and
 // cost the common (1024, 4096] class its fourth workgroup: C5's tile sort 0.184 -> 0.206 ms)
 __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_sort_tiles_wide(int T, int g1, const int* __restrict__ n_ptr, int capacity,
-                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 const uint2* __restrict__ tile_range,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
                                                                  const BinElem* __restrict__ elems, uint64_t* keys,
@@ -997,84 +1073,269 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 	__shared__ uint64_t s_keys[CH];
 	const int tid = threadIdx.x;
 	if (*n_ptr > capacity) return;
+	const ElemKeys src{elems, compact};
 	if ((int)blockIdx.x < g1) {
 		const int count = flags[1];
 		for (int b = blockIdx.x; b < count; b += g1) {
 			const uint32_t tile = big_tiles[b];
-			const uint32_t start = tile_start[tile];
-			const int n = (int)(tile_start[tile + 1] - start);
+			const uint2 range = tile_range[tile];
+			const uint32_t start = range.x;
+			const int n = (int)(range.y - range.x);
 			if (n <= BSR_SORT_SMALL || n > CH) continue;   // another class (uniform over the workgroup)
-			int n2 = 1024;
-			while (n2 < n) n2 <<= 1;
-			sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, elems, point_list, force_int != 0, compact);
-			__syncthreads();   // (the keys are read out to point_list before the next segment is loaded)
+			sort_long_tile_lds<NT>(s_keys, start, n, tid, src, point_list, force_int != 0);
 		}
 		return;
 	}
 	const int gw = (int)gridDim.x - g1, count4 = flags[4], count8 = flags[5];
 	for (int b = (int)blockIdx.x - g1; b < count4 + count8; b += gw) {
 		const uint32_t tile = b < count4 ? big_tiles[(size_t)T + b] : big_tiles[2 * (size_t)T + (b - count4)];
-		const uint32_t start = tile_start[tile];
-		const int n = (int)(tile_start[tile + 1] - start);
+		const uint2 range = tile_range[tile];
+		const uint32_t start = range.x;
+		const int n = (int)(range.y - range.x);
 		if (n <= CH) continue;
-		uint64_t* k = keys + start;
-		int n2 = 1;
-		while (n2 < n) n2 <<= 1;
-		// runs of CH: every chunk sorted on its own in LDS (integer flavour: the global steps compare integers too)
-		for (int base = 0; base < n; base += CH) {
-			const int m = min(CH, n - base);
-			__syncthreads();
-			load_sorted_runs<NT, 3>(s_keys, CH, start + (uint32_t)base, m, tid, elems, compact);
-			lds_sort_rounds<NT, 3, true, false>(s_keys, CH, tid);
-			for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
-		}
-		// merges of runs longer than CH: far partners in global memory, the rest per chunk in LDS
-		for (int size = 2 * CH; size <= n2; size <<= 1) {
-			__syncthreads();
-			merge_mirror_step<NT>(k, n, n2, size, tid);
-			for (int stride = size >> 2; stride >= CH; stride >>= 1) {
-				__syncthreads();
-				merge_stride_step<NT>(k, n, n2, stride, tid);
-			}
-			for (int base = 0; base < n; base += CH) {
-				const int m = min(CH, n - base);
-				__syncthreads();
-				for (int i = tid; i < CH; i += NT) s_keys[swz_m<3>(i)] = i < m ? k[base + i] : BSR_PAD_KEY;
-				lds_stride_rounds<NT, 3, true, false>(s_keys, CH, 12, tid);   // strides CH/2 .. 1
-				__syncthreads();
-				for (int i = tid; i < m; i += NT) k[base + i] = s_keys[swz_m<3>(i)];
-			}
+		sort_long_tile_hybrid<NT>(s_keys, keys + start, start, n, tid, src, point_list);
+	}
+}
+
+// ---- bucket-owned second pass + per-tile sort, ONE launch (frames of up to 8192 tiles with short lists) ----------------
+// After pass 1 (k_emit_scatter) the instances of tile t all lie in bucket t & 255, a contiguous range whose bounds follow
+// from the 256 digit totals alone.  Nothing downstream needs the tile segments in TILE order -- the tile walks and the
+// backward take (start, end) per tile from tile_range -- so the segments of a bucket's tiles can simply be laid out
+// inside the bucket's own range, in order of the high tile byte: a segment's position then depends on the counts of
+// ITS bucket only, and the chain  k_tile_count -> k_tile_starts (one workgroup, a global scan) -> k_tile_scatter ->
+// k_sort_tiles_small -> k_sort_tiles_wide  (five launches, the elements written and read once more) collapses into
+// one kernel without any communication between workgroups:
+//   workgroup (bucket d, part j of k): streams the WHOLE bucket once (8-byte elements; the k parts of a bucket run on
+//   the same XCD back to back: one HBM read, k - 1 L2 hits), counts every element by its high tile byte in LDS -- the
+//   same returning atomic hands an element of one of ITS tiles (high byte = j mod k, at most one tile per wave) its
+//   slot in that tile's 1024-key LDS area -- then scans the 256 counts (bucket-local tile offsets: identical in all k
+//   parts), writes its tiles' ranges, and every wave sorts its tile in place (the wave-owned network of
+//   k_sort_tiles_small, from LDS instead of global memory; up to 64 keys: ranks by counting) and writes the ids.
+//   A tile of more than 1024 instances (rare where this kernel is chosen) is staged as plain keys in global scratch
+//   by a second pass over the bucket and sorted by the whole workgroup with the long-tile routines above.
+// Chosen by the host from sizes alone (binning_plan): both this kernel and the chain are correct for every input.
+#define BSR_BKT_NT 512
+#define BSR_BKT_NW (BSR_BKT_NT / 64)
+#define BSR_BKT_AREA 1024   // keys per wave-owned tile area (== BSR_SORT_SMALL)
+__global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, const int* __restrict__ n_ptr, int capacity,
+                                                            const uint32_t* __restrict__ digit_total1,
+                                                            const BinElem* __restrict__ elems, uint2* __restrict__ tile_range,
+                                                            uint64_t* big_keys, uint32_t* __restrict__ point_list,
+                                                            int force_int)
+{
+	constexpr int NT = BSR_BKT_NT, NW = BSR_BKT_NW, AREA = BSR_BKT_AREA;
+	__shared__ uint64_t s_keys[NW * AREA];          // 64 KB: one area per wave; the long-tile routines use the first 4096 slots
+	__shared__ uint32_t s_cnt[BSR_RADIX_BINS];      // elements of the bucket per high tile byte
+	__shared__ uint32_t s_off[BSR_RADIX_BINS];      // their exclusive prefix
+	__shared__ uint32_t s_scan[NW];
+	__shared__ uint32_t s_base[2];
+	__shared__ uint32_t s_cur[NW];                  // second pass: fill counters of this part's long tiles
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int k = 1 << k_log2;
+	// parts of one bucket are neighbours on one XCD: workgroups b, b + 8, b + 16, ... share an XCD
+	const int xcd = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3;
+	const int j = r & (k - 1), d = ((r >> k_log2) << 3) | xcd;
+	const int nt = d < T ? ((T - 1 - d) >> BSR_RADIX_BITS) + 1 : 0;      // tiles of this bucket: (hi << 8) | d < T
+	const int m = nt > j ? (nt - j + k - 1) >> k_log2 : 0;               // ... of this part: hi = j + k L, L < m <= NW
+	const int n_all = *n_ptr;
+	if (n_all > capacity) return;   // scratch too small: the stage is re-run
+	if (n_all <= 0) {               // nothing kept: every tile is empty
+		if (tid < m) tile_range[(uint32_t)((j + (tid << k_log2)) << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(0u, 0u);
+		return;
+	}
+	// the bucket's range: exclusive scan of the 256 digit totals
+	{
+		const uint32_t v = tid < BSR_RADIX_BINS ? digit_total1[tid] : 0u;
+		if (tid < BSR_RADIX_BINS) s_cnt[tid] = 0u;
+		const uint32_t incl = wave_inclusive_sum_dpp(v);
+		if (lane == 63) s_scan[wave] = incl;
+		__syncthreads();
+		uint32_t before = incl - v;
+		for (int w = 0; w < wave; w++) before += s_scan[w];
+		if (tid == d) {
+			s_base[0] = before;
+			s_base[1] = v;
 		}
 		__syncthreads();
-		for (int i = tid; i < n; i += NT) point_list[start + i] = (uint32_t)k[i];
+	}
+	const uint32_t beg = s_base[0], size = s_base[1];
+	const uint2* const src = reinterpret_cast<const uint2*>(elems) + beg;
+	// ---- pass over the bucket: count by high byte; elements of this part's tiles go to their wave's area
+	for (uint32_t i0 = 0; i0 < size; i0 += NT * 8) {
+		uint2 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
+			v[u] = i < size ? src[i] : make_uint2(0u, 0u);
+		}
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
+			if (i < size) {
+				const uint32_t hi = v[u].x >> 24;
+				const uint32_t pos = atomicAdd(&s_cnt[hi], 1u);   // LDS
+				if ((int)(hi & (uint32_t)(k - 1)) == j && pos < (uint32_t)AREA)
+					s_keys[(hi >> k_log2) * AREA + swz_m<3>((int)pos)] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
+			}
+		}
+	}
+	__syncthreads();
+	// ---- bucket-local tile offsets; ranges of this part's tiles
+	{
+		const uint32_t c = tid < BSR_RADIX_BINS ? s_cnt[tid] : 0u;
+		const uint32_t incl = wave_inclusive_sum_dpp(c);
+		if (lane == 63) s_scan[wave] = incl;
 		__syncthreads();
+		uint32_t before = incl - c;
+		for (int w = 0; w < wave; w++) before += s_scan[w];
+		if (tid < BSR_RADIX_BINS) s_off[tid] = before;
+		__syncthreads();
+	}
+	if (tid < m) {
+		const uint32_t hi = (uint32_t)(j + (tid << k_log2));
+		const uint32_t first = beg + s_off[hi];
+		tile_range[(hi << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(first, first + s_cnt[hi]);
+	}
+	// ---- every wave sorts its tile
+	bool any_long = false;   // (workgroup-uniform: every thread looks at all of the part's counts)
+	for (int L = 0; L < m; L++) any_long = any_long || s_cnt[j + (L << k_log2)] > (uint32_t)AREA;
+	if (wave < m) {
+		const uint32_t hi = (uint32_t)(j + (wave << k_log2));
+		const int n = (int)s_cnt[hi];
+		const uint32_t start = beg + s_off[hi];
+		uint64_t* const keys = s_keys + wave * AREA;
+		if (n > 0 && n <= 64) {
+			// ranks by counting ((depth bits, id) pairs are unique within a tile): no network, no further LDS traffic
+			uint64_t key = ~0ull;
+			if (lane < n) key = keys[swz_m<3>(lane)];
+			const uint32_t kh = (uint32_t)(key >> 32), kl = (uint32_t)key;
+			uint32_t rank = 0;
+			for (int q = 0; q < n; q++) {
+				const uint64_t kq = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kh, q) << 32) |
+				                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kl, q);
+				rank += kq < key ? 1u : 0u;
+			}
+			if (lane < n) point_list[start + rank] = kl;
+		} else if (n > 64 && n <= AREA) {
+			int n2 = 128;
+			while (n2 < n) n2 <<= 1;
+			// pads, then runs of 8 sorted in registers, in place: a lane reads and writes the same eight slots
+			round_sync<false>();
+			for (int i = n + lane; i < n2; i += 64) keys[swz_m<3>(i)] = BSR_PAD_KEY;
+			round_sync<false>();
+			bool plain = true;
+			for (int i = lane * 8; i < n2; i += 64 * 8) {
+				uint64_t e[8];
+				const int p0 = swz_m<3>(i);
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					e[q] = keys[p0 ^ swz_m<3>(q)];
+					plain = plain && (i + q >= n || key_is_plain_double(e[q]));
+				}
+				reg_sort<3, false>(e);
+#pragma unroll
+				for (int q = 0; q < 8; q++) keys[p0 ^ swz_m<3>(q)] = e[q];
+			}
+			if (wave_ballot(!(plain && !force_int)) == 0ull)
+				merge_loaded_runs<64, 3, false, true>(keys, n2, start, n, lane, point_list);
+			else
+				merge_loaded_runs<64, 3, false, false>(keys, n2, start, n, lane, point_list);
+		}
+	}
+	if (!any_long) return;
+	// ---- long tiles of this part: second pass over the bucket stages their keys in global scratch, at the segment's own
+	// positions; then the whole workgroup sorts them one by one
+	__syncthreads();
+	if (tid < NW) s_cur[tid] = 0u;
+	__syncthreads();
+	for (uint32_t i0 = 0; i0 < size; i0 += NT * 4) {
+		uint2 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
+			v[u] = i < size ? src[i] : make_uint2(0u, 0u);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
+			if (i < size) {
+				const uint32_t hi = v[u].x >> 24;
+				if ((int)(hi & (uint32_t)(k - 1)) == j && s_cnt[hi] > (uint32_t)AREA) {
+					const uint32_t pos = atomicAdd(&s_cur[hi >> k_log2], 1u);   // LDS
+					big_keys[(size_t)beg + s_off[hi] + pos] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
+				}
+			}
+		}
+	}
+	__threadfence();
+	__syncthreads();
+	const RawKeys raw{big_keys};
+	for (int L = 0; L < m; L++) {
+		const uint32_t hi = (uint32_t)(j + (L << k_log2));
+		const int n = (int)s_cnt[hi];
+		if (n <= AREA) continue;   // (uniform)
+		const uint32_t start = beg + s_off[hi];
+		if (n <= BSR_SORT_CHUNK)
+			sort_long_tile_lds<NT>(s_keys, start, n, tid, raw, point_list, force_int != 0);
+		else
+			sort_long_tile_hybrid<NT>(s_keys, big_keys + start, start, n, tid, raw, point_list);
 	}
 }
 
 // once per forward call, right after k_preprocess (independent of the instance count: runs before the read-back)
-void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, hipStream_t s)
+void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, int* host_counts,
+                  hipStream_t s)
 {
-	hipLaunchKernelGGL(k_scans, dim3(BSR_RADIX_BINS + 1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags, hist1);
+	hipLaunchKernelGGL(k_scans, dim3(BSR_RADIX_BINS + 1), dim3(1024), 0, s, n_wg, wg_kept, wg_area, flags, hist1,
+	                   host_counts);
 }
 
-// Bins the kept instances (their number is read from *n_ptr on the device): emit -> radix passes on
-// the tile id -> tile ranges.  elems_a / elems_b ping-pong; *elems_sorted is the buffer holding the
-// final order.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
+// Which second pass a forward call runs -- decided on the host from sizes alone, every plan is correct for every input:
+//   0  tile ids beyond 16 bits (stacked views, > 4096 x 4096): the remaining LSD radix passes + k_tile_ranges,
+//   1  tile-owned chain: k_tile_count -> k_tile_starts -> k_tile_scatter, then the per-tile sort launches,
+//   2  k_bucket_sort (one launch for the second pass AND the sort): up to 8192 tiles, Gaussian ids below 2^24, and a
+//      scratch capacity (>= the reference's num_rendered, + 25 % when guessed) of at most BSR_BUCKET_MAX_PER_TILE per
+//      tile -- a workgroup streams its whole bucket up to four times over, which pays while the lists are short (C3:
+//      670 per tile; the dense leg: 2800, C5: 3400).
+// The debug builds libbsr_chain_only.so / libbsr_bucket_always.so (csrc/Makefile) pin plan 1 / 2 for the tests.
+#ifndef BSR_BUCKET_MAX_PER_TILE
+#define BSR_BUCKET_MAX_PER_TILE 1280
+#endif
+int binning_plan(int P, int T, int capacity)
+{
+	int bits = 0;
+	while ((1 << bits) < T) bits++;
+	const bool tile_owned = bits <= 2 * BSR_RADIX_BITS && 2 * (size_t)T <= (size_t)BSR_RADIX_BINS * BSR_HIST_BLOCKS_MAX;
+	if (!tile_owned) return 0;
+	if (P <= (1 << 24) && T <= BSR_BKT_NW * BSR_RADIX_BINS * 4 && (long long)capacity <= (long long)BSR_BUCKET_MAX_PER_TILE * T)
+		return 2;
+	return 1;
+}
+
+// Bins the kept instances (their number is read from *n_ptr on the device): emit -> second pass on the tile id -> tile
+// ranges (plan 2: the second pass is part of launch_sort_tiles).  elems_a / elems_b ping-pong; *elems_sorted is the
+// buffer the sort stage reads.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
 void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
-                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint32_t* tile_start, uint32_t* big_tiles,
+                    BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint2* tile_range, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s)
 {
 	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_scans
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
-	const bool tile_owned = bits <= 2 * BSR_RADIX_BITS && 2 * (size_t)T <= (size_t)BSR_RADIX_BINS * hist_blocks_max;
+	const int plan = binning_plan(P, T, capacity);
+	const bool tile_owned = plan != 0;
 	// 8-byte elements where the tile-owned pass runs and Gaussian ids fit 24 bits (common.h: load_elem_m)
 	const int compact = (tile_owned && P <= (1 << 24)) ? 1 : 0;
 	*compact_out = compact;
 	uint32_t* tile_count = hist;          // [T]   (the histogram area of the generic passes, unused on this path)
 	uint32_t* tile_cursor = hist + T;     // [T]
 	hipLaunchKernelGGL(k_emit_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect,
-	                   geom.kept_mask, geom.depth, geom.hist1, elems_a, tile_count, tile_owned ? 2 * T : 0, compact);
+	                   geom.kept_mask, geom.depth, geom.hist1, elems_a, tile_count, plan == 1 ? 2 * T : 0, compact);
+	if (plan == 2) {   // the bucket-owned second pass is fused with the sort (launch_sort_tiles)
+		*elems_sorted = elems_a;
+		*elems_free = elems_b;
+		return;
+	}
 	if (tile_owned) {
 		// tile ids of up to 16 bits (every single-view call up to 4096 x 4096): count -> starts -> scatter
 		const int n_wg = (P + 255) / 256, n_col = 8 * ((n_wg + 7) >> 3);
@@ -1086,13 +1347,13 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 		hipLaunchKernelGGL(k_tile_count, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
 		                   digit_total1, elems_a, tile_count, compact);
 		if (T <= 8192)
-			hipLaunchKernelGGL(k_tile_starts<8>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
+			hipLaunchKernelGGL(k_tile_starts<8>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_range,
 			                   big_tiles, flags);
 		else
-			hipLaunchKernelGGL(k_tile_starts<64>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_start,
+			hipLaunchKernelGGL(k_tile_starts<64>, dim3(1), dim3(1024), 0, s, T, n_ptr, capacity, tile_count, tile_range,
 			                   big_tiles, flags);
 		hipLaunchKernelGGL(k_tile_scatter, dim3(BSR_RADIX_BINS * n_slices), dim3(256), 0, s, T, n_slices, n_ptr, capacity,
-		                   digit_total1, elems_a, elems_b, tile_start, tile_cursor, compact);
+		                   digit_total1, elems_a, elems_b, tile_range, tile_cursor, compact);
 		*elems_sorted = elems_b;
 		*elems_free = elems_a;
 		return;
@@ -1111,8 +1372,8 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 		                   eo, hist, digit_total);
 		BinElem* tt = ei; ei = eo; eo = tt;
 	}
-	// one wave per three tiles (+ one for tile_start[T] when T is a multiple of 3)
-	hipLaunchKernelGGL(k_tile_ranges, dim3((T / 3 + 1 + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, ei, tile_start,
+	// one wave per three tiles
+	hipLaunchKernelGGL(k_tile_ranges, dim3((T / 3 + 1 + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, ei, tile_range,
 	                   big_tiles, flags);
 	*elems_sorted = ei;
 	*elems_free = eo;
@@ -1122,10 +1383,20 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 // (k_sort_tiles_wide): (1024, 4096] sorted in 32 KB of LDS, longer segments hybrid in 4096-key chunks, one entry of a
 // work list per workgroup.  n instances can fill at most n / 1024 (n / 4096) such tiles, which bounds the grid: a frame
 // without long lists pays one near-empty launch, not 3 x T idle workgroups.
-void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const uint32_t* tile_start,
-                       const uint32_t* big_tiles, const int* flags, const BinElem* elems, BinElem* elems_free,
-                       uint32_t* point_list, int compact, hipStream_t s)
+void launch_sort_tiles(int P, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
+                       const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
+                       BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s)
 {
+	if (binning_plan(P, T, capacity) == 2) {
+		// second pass + sort in one launch: `elems` is still in pass-1 order; the free buffer holds the keys of long tiles
+		const int nt_max = (T + BSR_RADIX_BINS - 1) / BSR_RADIX_BINS;
+		int k_log2 = 0;
+		while ((BSR_BKT_NW << k_log2) < nt_max) k_log2++;
+		hipLaunchKernelGGL(k_bucket_sort, dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr, capacity,
+		                   digit_total1, elems, tile_range, reinterpret_cast<uint64_t*>(elems_free), point_list,
+		                   opt_sort_force_int());
+		return;
+	}
 	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
 	// which real inputs reach only with NaN / non-positive depth bits
 	const int force_int = opt_sort_force_int();
@@ -1133,9 +1404,9 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	// where tiles average 128 entries or more the few short ones stay with the small class (one launch fewer)
 	const bool tiny = (long long)n_bound < 128ll * T;
 	if (tiny)
-		hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems,
+		hipLaunchKernelGGL(k_sort_tiles_tiny, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_range, elems,
 		                   point_list, compact);
-	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_start, elems, point_list,
+	hipLaunchKernelGGL(k_sort_tiles_small, dim3((T + 3) / 4), dim3(256), 0, s, T, n_ptr, capacity, tile_range, elems, point_list,
 	                   force_int, tiny ? 64 : 0, compact);
 	// n instances can fill at most n / 1025 tiles of the first wide class and n / 4097 of the two longer ones: the grid
 	// covers both work lists (n_bound >= the real count), capped -- the workgroups stride over their lists
@@ -1145,7 +1416,7 @@ void launch_sort_tiles(int T, int n_bound, const int* n_ptr, int capacity, const
 	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), small_grids ? 2 : 2560),
 	          gw = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
 	if (g1 + gw > 0)
-		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1 + gw), dim3(BSR_SORT_NT), 0, s, T, g1, n_ptr, capacity, tile_start,
+		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1 + gw), dim3(BSR_SORT_NT), 0, s, T, g1, n_ptr, capacity, tile_range,
 		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int, compact);
 }
 

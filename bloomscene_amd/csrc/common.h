@@ -111,7 +111,9 @@ struct BinState {
 struct ImgState {
 	float* final_T;        // [N]
 	uint32_t* n_contrib;   // [N]
-	uint32_t* tile_start;  // [T + 1] ranges[t] = [start[t], start[t+1]) in point_list
+	uint2* tile_range;     // [T] ranges[t] = [x, y) in point_list (the reference's `ranges`, rasterizer_impl.h:47).  The segments
+	                       //     tile the first `kept` entries of point_list, in tile order or -- after k_bucket_sort -- in
+	                       //     (low tile byte, high tile byte) order: nobody reads across a segment's ends
 	int* flags;            // [BSR_FLAGS_BYTES / 4]: prefiltered violation | #tiles (1024, 4096] | kept instances | rect tiles (= reference
 	                       //      num_rendered) | #tiles (4096, 8192] | #tiles > 8192 | point_list words carry the forward's
 	                       //      per-half box tests in their top byte (k_render_fwd -> k_render_bwd*) | - | ... |

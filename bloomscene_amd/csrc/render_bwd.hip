@@ -233,7 +233,7 @@ __device__ __forceinline__ void pair_terms_reference(PairState& st, const PixelC
 // term in dL/dalpha.  out_depth is the forward's depth image (its zeros are the acc <= 0.5 gate).
 template <bool DEPTH>
 __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd_strict(int n_tiles, int gx, int W, int H,
-                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 const uint2* __restrict__ tile_range,
                                                                  const uint32_t* __restrict__ point_list,
                                                                  const float4* __restrict__ rec,
                                                                  const uint32_t* __restrict__ wg_base,
@@ -266,8 +266,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) k_render_bwd_strict(int n_tiles, in
 	const size_t pix_id = (size_t)W * py + px;
 	const size_t plane = (size_t)H * W;
 
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
+	const uint2 range = tile_range[tile];
+	const uint32_t start = range.x;
+	const int n = (int)(range.y - range.x);
 	// (the forward may have left its box tests in the top byte of the point_list words: k_render_bwd_t; unused here)
 	const uint32_t id_mask = __builtin_amdgcn_readfirstlane(*masks_flag) != 0 ? 0x00ffffffu : 0xffffffffu;
 
@@ -562,7 +563,7 @@ template <bool DEPTH, int NS>
 #endif
 #define BSR_BWT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(BSR_BWT_WAVES, BSR_BWT_WAVES)))
 __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(int n_tiles, int gx, int W, int H,
-                                                            const uint32_t* __restrict__ tile_start,
+                                                            const uint2* __restrict__ tile_range,
                                                             const uint32_t* __restrict__ point_list,
                                                             const float4* __restrict__ rec,
                                                             const uint32_t* __restrict__ wg_base,
@@ -602,8 +603,9 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 	const size_t pix_id = (size_t)W * py + px;
 	const size_t plane = (size_t)H * W;
 
-	const uint32_t start = tile_start[tile];
-	const int n = (int)(tile_start[tile + 1] - start);
+	const uint2 range = tile_range[tile];
+	const uint32_t start = range.x;
+	const int n = (int)(range.y - range.x);
 	// The forward's split-list staging left its eight per-half box tests in the top byte of every point_list word it
 	// staged (render_fwd.hip; a word the forward never staged lies beyond every pixel's last contributor): the waves then
 	// take their lists from that byte and only wave 0 gathers records.  0: plain ids, every wave tests for itself.
@@ -998,7 +1000,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_BWT_WAVES_ATTR k_render_bwd_t(i
 #endif
 }
 
-void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start, const uint32_t* point_list,
+void launch_render_bwd(int gx, int gy, int W, int H, const uint2* tile_range, const uint32_t* point_list,
                        const float4* rec, const uint32_t* wg_base, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
                        int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s)
@@ -1008,12 +1010,12 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint32_t* tile_start,
 	const unsigned pad = occupancy_sweep_lds_pad("BSR_SWEEP_LDS_PAD_BWD");
 	const bool depth = out_depth && dL_depths;
 #define BSR_LAUNCH_STRICT(D_)                                                                                            \
-	hipLaunchKernelGGL((k_render_bwd_strict<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_start,     \
+	hipLaunchKernelGGL((k_render_bwd_strict<D_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H, tile_range,     \
 	                   point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,           \
 	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 #define BSR_LAUNCH_BWT(D_, N_)                                                                                             \
 	hipLaunchKernelGGL((k_render_bwd_t<D_, N_>), dim3(pooled_grid(n_tiles)), dim3(BSR_BLOCK), pad, s, n_tiles, gx, W, H,      \
-	                   tile_start, point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,   \
+	                   tile_range, point_list, rec, wg_base, bg, final_T, n_contrib, dL_dpix, depth ? out_depth : nullptr,   \
 	                   depth ? dL_depths : nullptr, masks_flag, num_rendered, slab)
 	// Default: the transposed-reduction walk, for every frame.  (Until round 5 frames with > 1900 reference instances
 	// per tile -- C5, scales x 3 -- kept round 3's per-visit network walk, 0-4 % faster there; with the forward's half

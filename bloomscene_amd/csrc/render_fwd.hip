@@ -50,7 +50,7 @@ __device__ unsigned long long g_fwd_times[4 * 70000];
 template <int NS, int FB, bool EXACT>
 __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int n_tiles, int gx, int gy, int W, int H,
                                                           const int* __restrict__ n_ptr, int capacity, int nan_on_overflow,
-                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint2* __restrict__ tile_range,
                                                           uint32_t* point_list, int* __restrict__ masks_flag,
                                                           const float4* __restrict__ rec,
                                                           const float* __restrict__ bg_color,
@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 	if (tile < 0) return;
 	// the three scalar loads leave together (a sparse view's tile lives for little more than its chain of dependent loads)
 	const int n_instances = *n_ptr;
-	const uint32_t start = tile_start[tile];
-	const uint32_t end = tile_start[tile + 1];
+	const uint2 range = tile_range[tile];
+	const uint32_t start = range.x, end = range.y;
 	if (n_instances > capacity) {
 		// launched ahead of the host's read-back with too small a scratch: the default path re-runs the tail.  A
 		// BSR_FLAG_NO_READBACK call has no re-run: its frame says so itself (NaN), never a stale or half-written image
@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 				out_color[plane + pix_id] = nan;
 				out_color[2 * plane + pix_id] = nan;
 				out_depth[pix_id] = nan;
+				// the saved image state too (GaussianRasterizer(return_alpha=True) returns 1 - final_T): NaN, never
+				// whatever the uninitialised scratch held
+				if (final_T != nullptr) final_T[pix_id] = nan;
+				if (n_contrib != nullptr) n_contrib[pix_id] = 0u;
 			}
 		}
 		return;
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(BSR_BLOCK) BSR_FWD_WAVES_ATTR k_render_fwd(int
 #endif
 }
 
-void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint32_t* tile_start,
+void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint2* tile_range,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
                        float* out_depth, bool exact, bool nan_on_overflow, int* pool_ctr, hipStream_t s)
@@ -378,7 +382,7 @@ void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_p
 	const bool split = (long long)capacity >= 48ll * n_tiles;
 #define BSR_LAUNCH_FWD(NS_, EX_)                                                                                        \
 	hipLaunchKernelGGL((k_render_fwd<NS_, BSR_FWD_BATCH, EX_>), dim3(blocks), dim3(BSR_BLOCK), pad, s, n_tiles, gx, gy, W, H, \
-	                   n_ptr, capacity, nan_on_overflow ? 1 : 0, tile_start, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth, pool_ctr)
+	                   n_ptr, capacity, nan_on_overflow ? 1 : 0, tile_range, point_list, masks_flag, rec, bg, final_T, n_contrib, out_color, out_depth, pool_ctr)
 	if (split && exact) BSR_LAUNCH_FWD(2, true);
 	else if (split) BSR_LAUNCH_FWD(2, false);
 	else if (exact) BSR_LAUNCH_FWD(1, true);

@@ -94,7 +94,8 @@ int bsr_anchor_expand_backward(int n_anchors, int n_offsets, int num_selected,
  * near-plane test, radii 0, zero gradient rows).  S itself stays on the device (word n_wg of anchor_scratch; the mask
  * holds the selection).  On entry *num_rendered = the rasterizer's capacity (tile instances); on return *num_selected
  * = N * K and *num_rendered = that capacity: hand both to bsr_anchor_render_backward.  The frame and every gradient of
- * the selected rows are bit-identical to the default path's.  Capturable into a hipGraph (after one warm-up call). */
+ * the selected rows are bit-identical to the default path's.  Capturable into a hipGraph (after one warm-up call followed
+ * by bsr_check_deferred(): see BSR_FLAG_NO_READBACK in bloomscene_rast.h). */
 size_t bsr_anchor_gaussian_bytes(int num_selected);
 int bsr_anchor_render_forward(int n_anchors, int n_offsets,
                               const float* anchor, const float* grid_scaling, const float* grid_offsets,

@@ -61,7 +61,10 @@ extern "C" {
  *   path here (a 16-byte one, overlapped with the rest of the forward).  With this flag the CALLER states the size:
  *   on entry *num_rendered holds a CAPACITY (tile instances, > 0) -- the binning buffer is sized for it, every kernel
  *   takes the real count from device memory, and the call returns once everything is enqueued (nothing in it is illegal
- *   during hipStreamBeginCapture: a warmed-up forward + backward pair can be captured into a hipGraph and replayed).
+ *   during hipStreamBeginCapture: a warmed-up forward + backward pair can be captured into a hipGraph and replayed --
+ *   call bsr_check_deferred() AFTER the warm-up calls and BEFORE hipStreamBeginCapture: the warm-up leaves an overflow
+ *   check pending, which is a blocking host wait; a forward that finds one pending while its stream is capturing
+ *   returns an error instead of waiting).
  *   *num_rendered is left at the capacity: hand THAT to bsr_backward* as R (same scratch carve).
  *   Overflow (more instances kept than the capacity) is never silent: the frame's out_color / out_depth are filled with
  *   NaN by the tile kernel instead of being rendered, bsr_read_counts reports kept > capacity, and -- unless the stream
@@ -333,6 +336,10 @@ int bsr_gather_rows(int R, int P, int n_src,
  * M == 0; dL_dscale/dL_drot are written only when scales != NULL.  dL_dconic may be NULL, and so may
  * dL_dcolor when shs != NULL and dL_dcov3D when scales != NULL: they are then intermediate results the
  * reference materialises (rasterize_points.cu:154-162) but nobody reads, and are simply not written.
+ * The call WRITES into the forward's saved buffers (the slab in the binning buffer, the tail-pool counter in the image
+ * buffer): two backward calls on the SAME forward state must be stream-ordered (one after the other on one stream, or
+ * joined by an event) -- run concurrently on two streams they would share the counter and both be wrong.  Sequential
+ * repeats (retain_graph) are fine.
  * Replaces CudaRasterizer::Rasterizer::backward, cuda_rasterizer/rasterizer.h:75-105
  * (= rasterizer_impl.cu:403-504); bound by `_C.rasterize_gaussians_backward`, ext.cpp:17 /
  * rasterize_points.cu:119-200. */

@@ -369,10 +369,21 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     off = 0
     out.final_T = img[off:off + N * 4].view(np.float32); off += _al(N * 4)
     out.n_contrib = img[off:off + N * 4].view(np.uint32); off += _al(N * 4)
-    out.tile_start = img[off:off + (T + 1) * 4].view(np.uint32)
+    # tile_range[T] = (start, end) of every tile's segment in point_list (the reference's `ranges`); the segments tile
+    # the first `kept` entries, in tile order or in (low tile byte, high tile byte) order (csrc/binning.hip: k_bucket_sort)
+    rng = img[off:off + T * 8].view(np.uint32).reshape(T, 2).astype(np.int64); off += _al(T * 8)
+    out.tile_lo, out.tile_hi = rng[:, 0].copy(), rng[:, 1].copy()
+    out.tile_count = out.tile_hi - out.tile_lo
+    flags = img[off:off + 32].view(np.int32)
     # R = the reference's num_rendered (sum of rect areas) sizes the buffer; the instances actually
-    # kept after exact tile culling are the first tile_start[T] entries of point_list
-    out.kept = int(out.tile_start[T]) if R > 0 else 0
+    # kept after exact tile culling (flags[2]) are the first entries of point_list
+    out.kept = int(flags[2]) if R > 0 else 0
+    if R > 0:
+        assert (out.tile_count >= 0).all() and int(out.tile_count.sum()) == out.kept
+        order = np.argsort(out.tile_lo, kind="stable")
+        nz = order[out.tile_count[order] > 0]
+        # the non-empty segments tile [0, kept) without gaps or overlaps
+        assert (out.tile_lo[nz] == np.concatenate(([0], np.cumsum(out.tile_count[nz])[:-1]))).all()
     if R > 0:
         b = bin_t.cpu().numpy()
         words = b[0:out.kept * 4].view(np.uint32)   # point_list is the first section
@@ -394,8 +405,7 @@ def check_lists_against_oracle(c, st, b):
     W, H = c.W, c.H
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
-    ts = b.tile_start.astype(np.int64)
-    assert ts[0] == 0 and (np.diff(ts[:T + 1]) >= 0).all()
+    lo, hi = b.tile_lo, b.tile_hi
     n_h = b.n_contrib.reshape(H, W).astype(np.int64)
     n_o = st.n_contrib.reshape(H, W).astype(np.int64)
     xy = st.means2D.astype(np.float64)
@@ -404,7 +414,7 @@ def check_lists_against_oracle(c, st, b):
     for t in range(T):
         o0, o1 = int(st.ranges[t, 0]), int(st.ranges[t, 1])
         ol = st.point_list[o0:o1].astype(np.int64)
-        hl = b.point_list[ts[t]:ts[t + 1]].astype(np.int64)
+        hl = b.point_list[lo[t]:hi[t]].astype(np.int64)
         assert len(hl) <= len(ol)
         # subsequence: positions of hl's ids inside ol must be strictly increasing (ids are unique per tile)
         pos = {int(g): i for i, g in enumerate(ol)}

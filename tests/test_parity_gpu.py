@@ -53,6 +53,10 @@ CASES = {
     "shell_view": dict(P=2000, W=96, H=64, deg=2, seed=6, scene="b", view=3, scale_mul=5.0),
     "lists_gt_1024": dict(P=20000, W=48, H=48, deg=1, seed=7, scale_mul=12.0),       # 64-KB LDS sort class
     "lists_gt_8192": dict(P=30000, W=20, H=20, deg=0, seed=8, scale_mul=30.0),       # global-memory sort class
+    # sparse frames (920 tiles, ~130 / ~190 instances per tile on average: the bucket-owned second binning pass) holding
+    # lists of every sort class -- (1024, 4096], (4096, 8192], > 8192 -- in a cluster around the optical axis
+    "cluster_lists_1k_4k": dict(P=40000, W=640, H=360, deg=0, seed=3, scale_mul=2.0, squeeze_xy=0.25),
+    "cluster_lists_mixed": dict(P=60000, W=640, H=360, deg=0, seed=4, scale_mul=2.0, squeeze_xy=0.15),
     "clustered_84k_list": dict(P=150000, W=640, H=360, deg=1, seed=5, scale_mul=3.0, squeeze_xy=0.08, big_count=300),
     "free_camera_sh3": dict(P=3000, W=200, H=120, deg=3, seed=13, scale_mul=3.0, free_camera=True),
     "free_camera_precomp_cov": dict(P=2000, W=97, H=61, deg=2, seed=14, scale_mul=4.0, free_camera=True,

@@ -50,7 +50,8 @@ def _compare_default_with_exact(c, st, label):
     # discrete results
     assert R == R2 == st.num_rendered
     np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
-    np.testing.assert_array_equal(b.tile_start, b2.tile_start)
+    np.testing.assert_array_equal(b.tile_lo, b2.tile_lo)
+    np.testing.assert_array_equal(b.tile_hi, b2.tile_hi)
     np.testing.assert_array_equal(b.point_list, b2.point_list)
     flips = b.n_contrib != b2.n_contrib
     n_flip = int(flips.sum())
@@ -220,7 +221,7 @@ def _slab_window_case(monkeypatch, P, W, H, base_scale=1.0):
         if b2.kept > cap:
             break
         if carve_end(R2, b2.kept) > guess_bytes:
-            chosen = (s_mul, R2, b2.kept, np.diff(b2.tile_start.astype(np.int64)))
+            chosen = (s_mul, R2, b2.kept, b2.tile_count)
             break
     assert chosen is not None, ("no scale puts the carve behind the guess while the kept instances fit", R1, b1.kept, cap)
     s2, R2, kept2, tile_counts = chosen

@@ -70,7 +70,7 @@ def test_half_masks_cover_every_pixel_that_can_blend(name):
     T = gx * gy
     if R < 48 * T:
         pytest.skip("single-list forward: no hand-over")
-    ts = b.tile_start.astype(np.int64)
+    ts = b.tile_lo
     n_c = b.n_contrib.reshape(H, W).astype(np.int64)
     xy = st.means2D.astype(np.float64)
     con = st.conic_opacity.astype(np.float64)
@@ -313,7 +313,7 @@ def test_wide_sort_classes_on_capped_grids_keep_the_reference_order(name, force_
     with _option("sort_small_grids", 1), _option("sort_force_int", force_int):
         rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
     b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
-    n = np.diff(b.tile_start[:T + 1].astype(np.int64))
+    n = b.tile_count
     if name == "lists_gt_1024":
         assert ((n > 1024) & (n <= 4096)).sum() > 2
     if name == "lists_4097_8192":

@@ -1,0 +1,138 @@
+"""GPU tests added in round 6.
+
+* the two forms of the second binning pass -- the tile-owned chain and k_bucket_sort (csrc/binning.hip: binning_plan) --
+  produce the same bits in every output of forward + backward, on frames with short lists, with lists of every sort
+  class, with 1 / 2 / 4 parts per bucket; and the product library picks the bucket form on sparse frames, the chain on
+  dense ones,
+* an overflowed BSR_FLAG_NO_READBACK frame is NaN in EVERY output, the accumulated-opacity extension included
+  (csrc/render_fwd.hip: final_T / n_contrib of the saved image state),
+* a forward issued during stream capture while the previous no-readback forward's overflow check is pending fails
+  with a message naming bsr_check_deferred, instead of making a blocking host wait inside the capture (csrc/api.hip).
+"""
+import pytest
+import torch
+
+import helpers as Hh
+from test_parity_gpu import CASES, _dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _call(c, dev, **kw):
+    from bloomscene_amd import GaussianRasterizer
+    rast = GaussianRasterizer(Hh.hip_settings(c, dev), **kw)
+    t = {k: getattr(c, k).to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    return rast, t
+
+
+def test_overflowed_frame_is_nan_in_the_alpha_output_too():
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    c = Hh.make_case(**CASES["sh3"])
+    st, _ = Hh.run_oracle(c, backward=False)
+    rast, t = _call(c, dev, capacity=max(1, int(st.num_rendered) // 8))
+    with torch.no_grad():
+        color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"],
+                                          shs=t["shs"], scales=t["scales"], rotations=t["rotations"], return_alpha=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(color).all() and torch.isnan(depth).all()
+    assert torch.isnan(alpha).all()          # (until round 6: 1 - whatever the uninitialised scratch held)
+    with pytest.raises(RuntimeError, match="was not rendered"):
+        RZ.check_deferred()
+    # a capacity that fits: alpha = 1 - final_T of the default path, bit for bit
+    rast2, _ = _call(c, dev, capacity=int(st.num_rendered) + 1)
+    rast3, _ = _call(c, dev)
+    with torch.no_grad():
+        a2 = rast2(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"],
+                   scales=t["scales"], rotations=t["rotations"], return_alpha=True)[3]
+        a3 = rast3(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"],
+                   scales=t["scales"], rotations=t["rotations"], return_alpha=True)[3]
+    RZ.check_deferred()
+    assert torch.equal(a2.view(torch.int32), a3.view(torch.int32)) and not torch.isnan(a2).any()
+
+
+def test_forward_during_capture_with_a_pending_overflow_check_fails_loudly():
+    """The warm-up call of a capacity-mode step leaves its overflow check pending; capturing WITHOUT bsr_check_deferred()
+    first must raise (naming the fix), not wait on an event inside the capture."""
+    from bloomscene_amd import rasterizer as RZ
+    dev = _dev()
+    c = Hh.make_case(P=5000, W=160, H=96, deg=1, seed=2)
+    st, _ = Hh.run_oracle(c, backward=False)
+    rast, t = _call(c, dev, capacity=2 * int(st.num_rendered) + 4096)
+
+    def fwd():
+        with torch.no_grad():
+            return rast(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"],
+                        scales=t["scales"], rotations=t["rotations"])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ref = fwd()                      # warm-up: allocator, pinned buffer, events; leaves the check pending
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="bsr_check_deferred"):
+        with torch.cuda.graph(g):
+            fwd()
+    torch.cuda.synchronize()
+    # the documented order works: check, then capture, then replay
+    RZ.check_deferred()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        out = fwd()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0].view(torch.int32), ref[0].view(torch.int32)) and torch.equal(out[1], ref[1])
+
+
+def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
+    """libbsr_chain_only.so pins the tile-owned chain, libbsr_bucket_always.so k_bucket_sort (wherever it is eligible:
+    up to 8192 tiles); the product library chooses by size.  Every output and gradient of nine frames: three identical
+    digests.  (The order of the tile segments inside point_list differs between the forms; nothing visible may.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "gradient_digest.py")
+
+    def digest(extra):
+        r = subprocess.run([sys.executable, tool] + extra + ["--plans"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    libs = {}
+    for name in ("chain_only", "bucket_always"):
+        path = os.path.join(root, "bloomscene_amd", f"libbsr_{name}.so")
+        assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+        libs[name] = digest(["--lib", path])
+    product = digest([])
+    assert len(product) == 9 and product.keys() == libs["chain_only"].keys() == libs["bucket_always"].keys()
+    for case in product:
+        assert libs["chain_only"][case] == libs["bucket_always"][case], case
+        assert product[case] == libs["chain_only"][case], case
+
+
+@pytest.mark.parametrize("name,bucket_form", [("sh3", True), ("c2_100k_800x800", True), ("cluster_lists_mixed", True),
+                                               ("lists_gt_1024", False), ("lists_gt_8192", False)])
+def test_product_library_picks_the_binning_form_by_size(name, bucket_form):
+    """Sparse frames (scratch capacity <= 1280 instances per tile, <= 8192 tiles) take k_bucket_sort: their tile
+    segments lie in (low tile byte, high tile byte) order; dense frames take the chain: segments in tile order.  Either
+    way the lists are the oracle's (checked by _assert_forward_bit_exact)."""
+    import numpy as np
+    from test_parity_gpu import _assert_forward_bit_exact
+    from bloomscene_amd import numerics
+    c = Hh.make_case(**CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    with numerics(exact_exp=True):
+        rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+    b = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    T = len(b.tile_lo)
+    nz = np.nonzero(b.tile_count)[0]
+    tile_order = bool((np.diff(b.tile_lo[nz]) > 0).all())
+    key = (nz & 255) * 65536 + (nz >> 8)
+    bucket_order = bool((np.diff(b.tile_lo[nz[np.argsort(key)]]) > 0).all())
+    assert R <= 1280 * T if bucket_form else R > 1280 * T
+    if bucket_form:
+        assert bucket_order and (T <= 256 or not tile_order)
+    else:
+        assert tile_order

@@ -16,10 +16,22 @@ CASES = {"c3_small": dict(P=60000, W=480, H=270, deg=3, seed=0), "dense": dict(P
 if POOLED:
     CASES = {"pooled_4096_tiles": dict(P=150000, W=1024, H=1024, deg=1, seed=5, scale_mul=1.5),
              "pooled_4096_tiles_again": dict(P=150000, W=1024, H=1024, deg=1, seed=5, scale_mul=1.5)}
+if "--plans" in sys.argv:
+    # frames on which both second binning passes are eligible (up to 8192 tiles): short lists, lists of every sort class
+    # inside a sparse frame, 2 and 4 parts per bucket, a frame few Gaussians survive in
+    CASES = {"short_lists_k1": dict(P=60000, W=480, H=270, deg=3, seed=0),
+             "mixed_long_lists": dict(P=60000, W=640, H=360, deg=0, seed=4, scale_mul=2.0, squeeze_xy=0.15),
+             "lists_1k_4k": dict(P=40000, W=640, H=360, deg=0, seed=3, scale_mul=2.0, squeeze_xy=0.25),
+             "c2_k2": dict(P=100000, W=800, H=800, deg=1, seed=0),
+             "tiles_4096_k2": dict(P=150000, W=1024, H=1024, deg=1, seed=5, scale_mul=1.5),
+             "tiles_8160_k4": dict(P=200000, W=1920, H=1080, deg=0, seed=6, scale_mul=1.5),
+             "all_long_lists": dict(P=30000, W=20, H=20, deg=0, seed=8, scale_mul=30.0),
+             "mostly_culled": dict(P=3000, W=160, H=96, deg=1, seed=9, near_fraction=1.0),
+             "few_tiles": dict(P=500, W=40, H=24, deg=2, seed=10, scale_mul=3.0)}
 out = {}
 for name, kw in CASES.items():
     c = Hh.make_case(**kw)
-    for dg in (False, True):
+    for dg in ((False,) if "--plans" in sys.argv else (False, True)):
         r = Hh.run_hip(c, depth_gradient=dg)
         d = {"color": r.color, "depth": r.depth, "radii": r.radii}
         d.update({"grad_" + k: getattr(r.grads, k) for k in Hh.GRAD_KEYS if getattr(r.grads, k) is not None})

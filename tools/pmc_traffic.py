@@ -20,6 +20,7 @@ STAGE_OF = {   # kernel name prefix (template arguments stripped) -> bench stage
     "bsr::k_preprocess_bwd": "preprocess_bwd", "bsr::k_preprocess": "preprocess", "bsr::k_scans": "scan_wg", "bsr::k_emit": "binning", "bsr::k_radix_hist": "binning", "bsr::k_radix_rowscan": "binning",
     "bsr::k_radix_scatter": "binning", "bsr::k_tile_ranges": "binning", "bsr::k_tile_count": "binning",
     "bsr::k_tile_starts": "binning", "bsr::k_tile_scatter": "binning", "bsr::k_sort_tiles": "sort_tiles",
+    "bsr::k_bucket_sort": "sort_tiles",   # (second binning pass + per-tile sort in one launch: timed as the sort stage)
     "bsr::k_render_fwd": "render_fwd", "bsr::k_render_bwd": "render_bwd",
 }
 # kernels launched more than once per step: launches per step (radix passes at 1080p after the one fused
