@@ -108,6 +108,7 @@ struct SyncCache {
 	int device = -1;
 	int last_P = -1, last_W = -1, last_H = -1, last_V = -1;
 	uint32_t last_R = 0;
+	uint32_t last_kept = 0;      // kept instances of that call (the hint that picks the next call's binning plan)
 	bool pending = false;        // a BSR_FLAG_NO_READBACK forward's copy of the counters is in flight / unchecked
 	size_t pending_capacity = 0;
 };
@@ -184,10 +185,11 @@ void launch_pack_rows(int R, int P, int n_src, const float* const* src, const in
                       int idx_stride, float* dst_packed, float* const* dst_each, hipStream_t s);
 void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, uint32_t* hist1, int* host_counts,
                   hipStream_t s);
-void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
+int binning_plan(int P, int T, int capacity, long long kept_hint);
+void launch_binning(int plan, int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint2* tile_range, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s);
-void launch_sort_tiles(int P, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
+void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
                        const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
                        BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint2* tile_range,
@@ -480,7 +482,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	int elems_compact = 0;   // the binning wrote 8-byte elements (common.h: load_elem_m)
 	// bins, sorts and renders with scratch sized for `capacity` instances; every kernel takes the real count
 	// from device memory and returns at once if it exceeds the capacity
-	auto run_tail = [&](size_t capacity, bool rerun) -> int {
+	auto run_tail = [&](size_t capacity, bool rerun, long long kept_hint) -> int {
 		char* bin_p = binningBuffer(binning_user, BinState::bytes(capacity, V == 1));
 		if (!bin_p) return fail("scratch allocation callback returned null");
 		bin = BinState::carve(bin_p, capacity, V == 1);
@@ -494,9 +496,10 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			HIP_TRY(hipMemsetAsync(img.flags + 4, 0, 2 * sizeof(int), s));
 		}
 		const int* n_ptr = img.flags + 2;
+		const int plan = binning_plan((int)P_rows, T, (int)capacity, kept_hint);
 		{
 			StageTimer t("binning", s);
-			launch_binning((int)P_rows, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
+			launch_binning(plan, (int)P_rows, T, gx, n_ptr, (int)capacity, geom, bin.elems_a, bin.elems_b, bin.hist, BSR_HIST_BLOCKS_MAX,
 			               img.tile_range, img.big_tiles, img.flags, &elems_sorted, &elems_free, &elems_compact, s);
 		}
 		STAGE_CHECK("binning", debug, s);
@@ -504,7 +507,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			StageTimer t("sort_tiles", s);
 			// (the 256 digit totals of pass 1 lie behind the rows of hist1)
 			const uint32_t* digit_total1 = geom.hist1 + (size_t)256 * (((size_t)n_wg + 7) / 8 * 8);
-			launch_sort_tiles((int)P_rows, T, (int)capacity, n_ptr, (int)capacity, img.tile_range, img.big_tiles, img.flags,
+			launch_sort_tiles(plan, T, (int)capacity, n_ptr, (int)capacity, img.tile_range, img.big_tiles, img.flags,
 			                  digit_total1, elems_sorted, elems_free, bin.point_list, elems_compact, s);
 		}
 		STAGE_CHECK("sort_tiles", debug, s);
@@ -529,7 +532,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			sc->pending = true;
 			sc->pending_capacity = (size_t)given_capacity;
 		}
-		if (run_tail((size_t)given_capacity, false)) return 1;
+		if (run_tail((size_t)given_capacity, false, 0)) return 1;
 		STAGE_CHECK("render_fwd", debug, s);
 		return 0;
 	}
@@ -537,7 +540,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	if (guess) {
 		size_t c = (size_t)sc->last_R + (size_t)sc->last_R / 4 + 4096;
 		if (c > 0x7fffffffu) c = 0x7fffffffu;
-		if (run_tail(c, false)) return 1;   // the whole rest of the forward is in flight before the host waits
+		if (run_tail(c, false, (long long)sc->last_kept)) return 1;   // the whole rest of the forward is in flight before the host waits
 	}
 	HIP_TRY(hipEventSynchronize(sc->copied));
 	const int h_flag = prefiltered ? sc->pinned[0] : 0;
@@ -553,6 +556,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 		const uint32_t decayed = same ? sc->last_R - sc->last_R / 8 : 0u;
 		sc->last_P = P; sc->last_W = width; sc->last_H = height; sc->last_V = V;
 		sc->last_R = h_R > decayed ? h_R : decayed;
+		sc->last_kept = h_kept;
 	}
 	// The backward is handed R, not the capacity this call carved with: it finds point_list at the buffer's start and
 	// puts its slab (up to 40 B per KEPT instance) right behind point_list[R].  A guessed buffer serves it only if that
@@ -563,7 +567,7 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	if (!guess || (size_t)h_kept > cap || !backward_fits) {
 		// first call of this shape, more kept instances than the guessed scratch holds (the kernels of the first
 		// attempt then returned without touching anything), or a buffer the backward's carve would overrun
-		if (run_tail((size_t)R, guess)) return 1;
+		if (run_tail((size_t)R, guess, (long long)h_kept)) return 1;
 	}
 	STAGE_CHECK("render_fwd", debug, s);
 	return 0;

@@ -1101,42 +1101,46 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 // After pass 1 (k_emit_scatter) the instances of tile t all lie in bucket t & 255, a contiguous range whose bounds follow
 // from the 256 digit totals alone.  Nothing downstream needs the tile segments in TILE order -- the tile walks and the
 // backward take (start, end) per tile from tile_range -- so the segments of a bucket's tiles can simply be laid out
-// inside the bucket's own range, in order of the high tile byte: a segment's position then depends on the counts of
-// ITS bucket only, and the chain  k_tile_count -> k_tile_starts (one workgroup, a global scan) -> k_tile_scatter ->
-// k_sort_tiles_small -> k_sort_tiles_wide  (five launches, the elements written and read once more) collapses into
-// one kernel without any communication between workgroups:
-//   workgroup (bucket d, part j of k): streams the WHOLE bucket once (8-byte elements; the k parts of a bucket run on
-//   the same XCD back to back: one HBM read, k - 1 L2 hits), counts every element by its high tile byte in LDS -- the
-//   same returning atomic hands an element of one of ITS tiles (high byte = j mod k, at most one tile per wave) its
-//   slot in that tile's 1024-key LDS area -- then scans the 256 counts (bucket-local tile offsets: identical in all k
-//   parts), writes its tiles' ranges, and every wave sorts its tile in place (the wave-owned network of
+// inside the bucket's own range: a segment's position then depends on the counts of ITS bucket only, and the chain
+// k_tile_count -> k_tile_starts (one workgroup, a global scan) -> k_tile_scatter -> k_sort_tiles_small ->
+// k_sort_tiles_wide  (five launches, the elements written and read once more) collapses into one kernel without any
+// communication between workgroups:
+//   workgroup (bucket d, part j of k = 2^k_log2): owns the bucket's tiles whose high byte hi = j (mod k) -- at most
+//   NW * TPW of them, tile L = hi / k in LDS area L -- and streams the WHOLE bucket once (8-byte elements; the k parts
+//   of a bucket run on one XCD back to back: one HBM read, k - 1 L2 hits).  An element of one of its tiles takes its
+//   slot in the tile's area from an LDS counter (= the tile's count in the end); the others are only counted per PART
+//   (wave ballots, no LDS traffic), which is all the layout needs: the bucket's range holds part 0's tiles, then part
+//   1's, ..., inside a part in order of L -- every part computes the same part totals, so the segments tile the range.
+//   Then the ranges are written and every wave sorts its TPW tiles in place (the wave-owned network of
 //   k_sort_tiles_small, from LDS instead of global memory; up to 64 keys: ranks by counting) and writes the ids.
-//   A tile of more than 1024 instances (rare where this kernel is chosen) is staged as plain keys in global scratch
+//   A tile of more than AREA instances (rare where this kernel is chosen) is staged as plain keys in global scratch
 //   by a second pass over the bucket and sorted by the whole workgroup with the long-tile routines above.
 // Chosen by the host from sizes alone (binning_plan): both this kernel and the chain are correct for every input.
 #define BSR_BKT_NT 512
 #define BSR_BKT_NW (BSR_BKT_NT / 64)
-#define BSR_BKT_AREA 1024   // keys per wave-owned tile area (== BSR_SORT_SMALL)
+typedef uint32_t bsr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+template <int AREA, int TPW>   // keys per tile area (512 / 1024); tiles per wave
 __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, const int* __restrict__ n_ptr, int capacity,
                                                             const uint32_t* __restrict__ digit_total1,
                                                             const BinElem* __restrict__ elems, uint2* __restrict__ tile_range,
                                                             uint64_t* big_keys, uint32_t* __restrict__ point_list,
                                                             int force_int)
 {
-	constexpr int NT = BSR_BKT_NT, NW = BSR_BKT_NW, AREA = BSR_BKT_AREA;
-	__shared__ uint64_t s_keys[NW * AREA];          // 64 KB: one area per wave; the long-tile routines use the first 4096 slots
-	__shared__ uint32_t s_cnt[BSR_RADIX_BINS];      // elements of the bucket per high tile byte
-	__shared__ uint32_t s_off[BSR_RADIX_BINS];      // their exclusive prefix
+	constexpr int NT = BSR_BKT_NT, NW = BSR_BKT_NW, NA = NW * TPW;
+	static_assert(NA * AREA >= BSR_SORT_CHUNK, "the long-tile routines sort 4096-key chunks in this LDS");
+	__shared__ uint64_t s_keys[NA * AREA];          // one area per owned tile; the long-tile routines use the first 4096 slots
+	__shared__ uint32_t s_cnt[NA];                  // elements per owned tile (the fill counters of the pass)
+	__shared__ uint32_t s_part[4];                  // elements of the bucket per part
 	__shared__ uint32_t s_scan[NW];
 	__shared__ uint32_t s_base[2];
-	__shared__ uint32_t s_cur[NW];                  // second pass: fill counters of this part's long tiles
+	__shared__ uint32_t s_cur[NA];                  // second pass: fill counters of this part's long tiles
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int k = 1 << k_log2;
+	const int k = 1 << k_log2;                      // 1, 2 or 4
 	// parts of one bucket are neighbours on one XCD: workgroups b, b + 8, b + 16, ... share an XCD
 	const int xcd = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3;
 	const int j = r & (k - 1), d = ((r >> k_log2) << 3) | xcd;
 	const int nt = d < T ? ((T - 1 - d) >> BSR_RADIX_BITS) + 1 : 0;      // tiles of this bucket: (hi << 8) | d < T
-	const int m = nt > j ? (nt - j + k - 1) >> k_log2 : 0;               // ... of this part: hi = j + k L, L < m <= NW
+	const int m = nt > j ? (nt - j + k - 1) >> k_log2 : 0;               // ... of this part: hi = j + k L, L < m <= NA
 	const int n_all = *n_ptr;
 	if (n_all > capacity) return;   // scratch too small: the stage is re-run
 	if (n_all <= 0) {               // nothing kept: every tile is empty
@@ -1146,7 +1150,8 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	// the bucket's range: exclusive scan of the 256 digit totals
 	{
 		const uint32_t v = tid < BSR_RADIX_BINS ? digit_total1[tid] : 0u;
-		if (tid < BSR_RADIX_BINS) s_cnt[tid] = 0u;
+		if (tid < NA) s_cnt[tid] = 0u;
+		if (tid < 4) s_part[tid] = 0u;
 		const uint32_t incl = wave_inclusive_sum_dpp(v);
 		if (lane == 63) s_scan[wave] = incl;
 		__syncthreads();
@@ -1160,50 +1165,67 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	}
 	const uint32_t beg = s_base[0], size = s_base[1];
 	const uint2* const src = reinterpret_cast<const uint2*>(elems) + beg;
-	// ---- pass over the bucket: count by high byte; elements of this part's tiles go to their wave's area
-	for (uint32_t i0 = 0; i0 < size; i0 += NT * 8) {
-		uint2 v[8];
+	// one element of the pass: counted for its part; if it belongs to a tile of this part, stored in the tile's area
+	uint32_t part_cnt[4] = {0u, 0u, 0u, 0u};   // (wave-uniform: scalar registers)
+	auto take = [&](bool valid, uint32_t w0, uint32_t w1) {
+		const uint32_t hi = w0 >> 24;
+		const uint32_t part = hi & (uint32_t)(k - 1);
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			if (q < k) part_cnt[q] += (uint32_t)__popcll(wave_ballot(valid && part == (uint32_t)q));
+		if (valid && (int)part == j) {
+			const uint32_t L = hi >> k_log2;
+			const uint32_t pos = atomicAdd(&s_cnt[L], 1u);   // LDS
+			if (pos < (uint32_t)AREA) s_keys[L * AREA + swz_m<3>((int)pos)] = ((uint64_t)w1 << 32) | (uint64_t)(w0 & 0x00ffffffu);
+		}
+	};
+	// ---- the pass over the bucket: two elements per 16-byte load, eight loads in flight
+	for (uint32_t i0 = 0; i0 < size; i0 += NT * 16) {
+		bsr_u32x4_a8 v[8];
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
-			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
-			v[u] = i < size ? src[i] : make_uint2(0u, 0u);
+			const uint32_t i = i0 + 2u * (uint32_t)(u * NT + tid);
+			if (i + 1 < size) v[u] = *reinterpret_cast<const bsr_u32x4_a8*>(src + i);
+			else if (i < size) { const uint2 e = src[i]; v[u] = bsr_u32x4_a8{e.x, e.y, 0u, 0u}; }
+			else v[u] = bsr_u32x4_a8{0u, 0u, 0u, 0u};
 		}
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
-			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
-			if (i < size) {
-				const uint32_t hi = v[u].x >> 24;
-				const uint32_t pos = atomicAdd(&s_cnt[hi], 1u);   // LDS
-				if ((int)(hi & (uint32_t)(k - 1)) == j && pos < (uint32_t)AREA)
-					s_keys[(hi >> k_log2) * AREA + swz_m<3>((int)pos)] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
+			const uint32_t i = i0 + 2u * (uint32_t)(u * NT + tid);
+			if (i0 + 2u * (uint32_t)(u * NT) < size) {   // (wave-uniform bound: at least the wave's first lane is in range)
+				take(i < size, v[u].x, v[u].y);
+				take(i + 1 < size, v[u].z, v[u].w);
 			}
 		}
 	}
+	if (lane == 0) {
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			if (q < k && part_cnt[q] != 0u) atomicAdd(&s_part[q], part_cnt[q]);   // LDS
+	}
 	__syncthreads();
-	// ---- bucket-local tile offsets; ranges of this part's tiles
-	{
-		const uint32_t c = tid < BSR_RADIX_BINS ? s_cnt[tid] : 0u;
-		const uint32_t incl = wave_inclusive_sum_dpp(c);
-		if (lane == 63) s_scan[wave] = incl;
-		__syncthreads();
-		uint32_t before = incl - c;
-		for (int w = 0; w < wave; w++) before += s_scan[w];
-		if (tid < BSR_RADIX_BINS) s_off[tid] = before;
-		__syncthreads();
-	}
+	// ---- layout: part-major inside the bucket's range, tiles of a part in order of L
+	uint32_t part_beg = beg;
+	for (int q = 0; q < j; q++) part_beg += s_part[q];
+	auto tile_first = [&](int L) {   // first position of owned tile L
+		uint32_t f = part_beg;
+		for (int q = 0; q < L; q++) f += s_cnt[q];
+		return f;
+	};
 	if (tid < m) {
-		const uint32_t hi = (uint32_t)(j + (tid << k_log2));
-		const uint32_t first = beg + s_off[hi];
-		tile_range[(hi << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(first, first + s_cnt[hi]);
+		const uint32_t first = tile_first(tid);
+		tile_range[(uint32_t)((j + (tid << k_log2)) << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(first, first + s_cnt[tid]);
 	}
-	// ---- every wave sorts its tile
+	// ---- every wave sorts its tiles
 	bool any_long = false;   // (workgroup-uniform: every thread looks at all of the part's counts)
-	for (int L = 0; L < m; L++) any_long = any_long || s_cnt[j + (L << k_log2)] > (uint32_t)AREA;
-	if (wave < m) {
-		const uint32_t hi = (uint32_t)(j + (wave << k_log2));
-		const int n = (int)s_cnt[hi];
-		const uint32_t start = beg + s_off[hi];
-		uint64_t* const keys = s_keys + wave * AREA;
+	for (int L = 0; L < m; L++) any_long = any_long || s_cnt[L] > (uint32_t)AREA;
+#ifdef BSR_BKT_SORT_TWICE   // (cost-attribution builds only)
+	for (int rep = 0; rep < 2; rep++)
+#endif
+	for (int L = wave; L < m; L += NW) {
+		const int n = (int)s_cnt[L];
+		const uint32_t start = tile_first(L);
+		uint64_t* const keys = s_keys + L * AREA;
 		if (n > 0 && n <= 64) {
 			// ranks by counting ((depth bits, id) pairs are unique within a tile): no network, no further LDS traffic
 			uint64_t key = ~0ull;
@@ -1243,10 +1265,10 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		}
 	}
 	if (!any_long) return;
-	// ---- long tiles of this part: second pass over the bucket stages their keys in global scratch, at the segment's own
-	// positions; then the whole workgroup sorts them one by one
+	// ---- long tiles of this part: a second pass over the bucket stages their keys in global scratch, at the segment's
+	// own positions; then the whole workgroup sorts them one by one
 	__syncthreads();
-	if (tid < NW) s_cur[tid] = 0u;
+	if (tid < NA) s_cur[tid] = 0u;
 	__syncthreads();
 	for (uint32_t i0 = 0; i0 < size; i0 += NT * 4) {
 		uint2 v[4];
@@ -1260,9 +1282,10 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 			const uint32_t i = i0 + (uint32_t)(u * NT + tid);
 			if (i < size) {
 				const uint32_t hi = v[u].x >> 24;
-				if ((int)(hi & (uint32_t)(k - 1)) == j && s_cnt[hi] > (uint32_t)AREA) {
-					const uint32_t pos = atomicAdd(&s_cur[hi >> k_log2], 1u);   // LDS
-					big_keys[(size_t)beg + s_off[hi] + pos] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
+				const uint32_t L = hi >> k_log2;
+				if ((int)(hi & (uint32_t)(k - 1)) == j && s_cnt[L] > (uint32_t)AREA) {
+					const uint32_t pos = atomicAdd(&s_cur[L], 1u);   // LDS
+					big_keys[(size_t)tile_first((int)L) + pos] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
 				}
 			}
 		}
@@ -1271,10 +1294,9 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	__syncthreads();
 	const RawKeys raw{big_keys};
 	for (int L = 0; L < m; L++) {
-		const uint32_t hi = (uint32_t)(j + (L << k_log2));
-		const int n = (int)s_cnt[hi];
+		const int n = (int)s_cnt[L];
 		if (n <= AREA) continue;   // (uniform)
-		const uint32_t start = beg + s_off[hi];
+		const uint32_t start = tile_first(L);
 		if (n <= BSR_SORT_CHUNK)
 			sort_long_tile_lds<NT>(s_keys, start, n, tid, raw, point_list, force_int != 0);
 		else
@@ -1293,36 +1315,44 @@ void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, ui
 // Which second pass a forward call runs -- decided on the host from sizes alone, every plan is correct for every input:
 //   0  tile ids beyond 16 bits (stacked views, > 4096 x 4096): the remaining LSD radix passes + k_tile_ranges,
 //   1  tile-owned chain: k_tile_count -> k_tile_starts -> k_tile_scatter, then the per-tile sort launches,
-//   2  k_bucket_sort (one launch for the second pass AND the sort): up to 8192 tiles, Gaussian ids below 2^24, and a
-//      scratch capacity (>= the reference's num_rendered, + 25 % when guessed) of at most BSR_BUCKET_MAX_PER_TILE per
-//      tile -- a workgroup streams its whole bucket up to four times over, which pays while the lists are short (C3:
-//      670 per tile; the dense leg: 2800, C5: 3400).
-// The debug builds libbsr_chain_only.so / libbsr_bucket_always.so (csrc/Makefile) pin plan 1 / 2 for the tests.
+//   2  k_bucket_sort<1024, 1> (one launch for the second pass AND the sort): up to 8192 tiles, Gaussian ids below 2^24,
+//      and lists that are short on average -- a workgroup streams its whole bucket, up to four workgroups per bucket:
+//      that pays while an average tile holds well under the 1024 keys of a tile area (C3: 366 kept instances per tile;
+//      the dense leg: 1600, C5: 1850),
+//   3  k_bucket_sort<512, 2>: the same with 512-key areas, two tiles per wave (half the workgroups per bucket), where
+//      the average tile holds at most BSR_BKT_SMALL_PER_TILE.
+// kept_hint = the number of kept instances the caller expects (this frame's count when the host has read it, the
+// previous frame's while it guesses), 0 = unknown: 70 % of the scratch capacity then (the exact tile cull keeps ~2/3
+// of the reference's instances on the synthetic scenes).
+// The debug builds libbsr_chain_only.so / libbsr_bucket_always.so (csrc/Makefile) pin plan 1 / 2-3 for the tests.
 #ifndef BSR_BUCKET_MAX_PER_TILE
-#define BSR_BUCKET_MAX_PER_TILE 1280
+#define BSR_BUCKET_MAX_PER_TILE 700
 #endif
-int binning_plan(int P, int T, int capacity)
+#ifndef BSR_BKT_SMALL_PER_TILE
+#define BSR_BKT_SMALL_PER_TILE 400
+#endif
+int binning_plan(int P, int T, int capacity, long long kept_hint)
 {
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
 	const bool tile_owned = bits <= 2 * BSR_RADIX_BITS && 2 * (size_t)T <= (size_t)BSR_RADIX_BINS * BSR_HIST_BLOCKS_MAX;
 	if (!tile_owned) return 0;
-	if (P <= (1 << 24) && T <= BSR_BKT_NW * BSR_RADIX_BINS * 4 && (long long)capacity <= (long long)BSR_BUCKET_MAX_PER_TILE * T)
-		return 2;
+	const long long kept = kept_hint > 0 ? kept_hint : (long long)capacity * 7 / 10;
+	if (P <= (1 << 24) && T <= 8192 && kept <= (long long)BSR_BUCKET_MAX_PER_TILE * T)
+		return kept <= (long long)BSR_BKT_SMALL_PER_TILE * T ? 3 : 2;
 	return 1;
 }
 
 // Bins the kept instances (their number is read from *n_ptr on the device): emit -> second pass on the tile id -> tile
 // ranges (plan 2: the second pass is part of launch_sort_tiles).  elems_a / elems_b ping-pong; *elems_sorted is the
 // buffer the sort stage reads.  Grids are sized for `capacity` instances; workgroups beyond the real count exit.
-void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
+void launch_binning(int plan, int P, int T, int gx, const int* n_ptr, int capacity, const GeomState& geom, BinElem* elems_a,
                     BinElem* elems_b, uint32_t* hist, int hist_blocks_max, uint2* tile_range, uint32_t* big_tiles,
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s)
 {
 	// pass 1 (tile id bits 0..7) fused with the emit; geom.hist1 was row-scanned by launch_scans
 	int bits = 0;
 	while ((1 << bits) < T) bits++;
-	const int plan = binning_plan(P, T, capacity);
 	const bool tile_owned = plan != 0;
 	// 8-byte elements where the tile-owned pass runs and Gaussian ids fit 24 bits (common.h: load_elem_m)
 	const int compact = (tile_owned && P <= (1 << 24)) ? 1 : 0;
@@ -1331,7 +1361,7 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 	uint32_t* tile_cursor = hist + T;     // [T]
 	hipLaunchKernelGGL(k_emit_scatter, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, n_ptr, capacity, geom.rect,
 	                   geom.kept_mask, geom.depth, geom.hist1, elems_a, tile_count, plan == 1 ? 2 * T : 0, compact);
-	if (plan == 2) {   // the bucket-owned second pass is fused with the sort (launch_sort_tiles)
+	if (plan >= 2) {   // the bucket-owned second pass is fused with the sort (launch_sort_tiles)
 		*elems_sorted = elems_a;
 		*elems_free = elems_b;
 		return;
@@ -1383,18 +1413,26 @@ void launch_binning(int P, int T, int gx, const int* n_ptr, int capacity, const 
 // (k_sort_tiles_wide): (1024, 4096] sorted in 32 KB of LDS, longer segments hybrid in 4096-key chunks, one entry of a
 // work list per workgroup.  n instances can fill at most n / 1024 (n / 4096) such tiles, which bounds the grid: a frame
 // without long lists pays one near-empty launch, not 3 x T idle workgroups.
-void launch_sort_tiles(int P, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
+void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
                        const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
                        BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s)
 {
-	if (binning_plan(P, T, capacity) == 2) {
-		// second pass + sort in one launch: `elems` is still in pass-1 order; the free buffer holds the keys of long tiles
+	if (plan >= 2) {
+		// second pass + sort in one launch: `elems` is still in pass-1 order; the free buffer holds the keys of long tiles.
+		// 64 KB of LDS either way: 16 tile areas of 512 keys (two per wave) or 8 of 1024; a bucket has ceil(T / 256)
+		// tiles, split over k = 1, 2 or 4 workgroups.
 		const int nt_max = (T + BSR_RADIX_BINS - 1) / BSR_RADIX_BINS;
+		const bool small_areas = plan == 3;
+		const int per_wg = small_areas ? 2 * BSR_BKT_NW : BSR_BKT_NW;
 		int k_log2 = 0;
-		while ((BSR_BKT_NW << k_log2) < nt_max) k_log2++;
-		hipLaunchKernelGGL(k_bucket_sort, dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr, capacity,
-		                   digit_total1, elems, tile_range, reinterpret_cast<uint64_t*>(elems_free), point_list,
-		                   opt_sort_force_int());
+		while ((per_wg << k_log2) < nt_max) k_log2++;
+		uint64_t* const big_keys = reinterpret_cast<uint64_t*>(elems_free);
+		if (small_areas)
+			hipLaunchKernelGGL((k_bucket_sort<512, 2>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
+			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, opt_sort_force_int());
+		else
+			hipLaunchKernelGGL((k_bucket_sort<1024, 1>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
+			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, opt_sort_force_int());
 		return;
 	}
 	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,

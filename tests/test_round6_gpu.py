@@ -115,9 +115,9 @@ def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
 @pytest.mark.parametrize("name,bucket_form", [("sh3", True), ("c2_100k_800x800", True), ("cluster_lists_mixed", True),
                                                ("lists_gt_1024", False), ("lists_gt_8192", False)])
 def test_product_library_picks_the_binning_form_by_size(name, bucket_form):
-    """Sparse frames (scratch capacity <= 1280 instances per tile, <= 8192 tiles) take k_bucket_sort: their tile
-    segments lie in (low tile byte, high tile byte) order; dense frames take the chain: segments in tile order.  Either
-    way the lists are the oracle's (checked by _assert_forward_bit_exact)."""
+    """Sparse frames (at most 700 kept instances per tile on average, <= 8192 tiles) take k_bucket_sort: their tile
+    segments lie bucket by bucket (low tile byte), inside a bucket part by part; dense frames take the chain: segments
+    in tile order.  Either way the lists are the oracle's (checked by _assert_forward_bit_exact)."""
     import numpy as np
     from test_parity_gpu import _assert_forward_bit_exact
     from bloomscene_amd import numerics
@@ -129,9 +129,17 @@ def test_product_library_picks_the_binning_form_by_size(name, bucket_form):
     T = len(b.tile_lo)
     nz = np.nonzero(b.tile_count)[0]
     tile_order = bool((np.diff(b.tile_lo[nz]) > 0).all())
-    key = (nz & 255) * 65536 + (nz >> 8)
-    bucket_order = bool((np.diff(b.tile_lo[nz[np.argsort(key)]]) > 0).all())
-    assert R <= 1280 * T if bucket_form else R > 1280 * T
+    # bucket form: all segments of bucket d lie before those of bucket d + 1
+    by_bucket = nz[np.argsort(nz & 255, kind="stable")]
+    first_of_bucket = {}
+    last_of_bucket = {}
+    for t in by_bucket:
+        d = int(t) & 255
+        first_of_bucket[d] = min(first_of_bucket.get(d, 1 << 62), int(b.tile_lo[t]))
+        last_of_bucket[d] = max(last_of_bucket.get(d, -1), int(b.tile_hi[t]))
+    ds = sorted(first_of_bucket)
+    bucket_order = all(last_of_bucket[a] <= first_of_bucket[c] for a, c in zip(ds[:-1], ds[1:]))
+    assert b.kept <= 700 * T if bucket_form else b.kept > 700 * T
     if bucket_form:
         assert bucket_order and (T <= 256 or not tile_order)
     else:
