@@ -1127,6 +1127,10 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
                                                             int force_int)
 {
 	constexpr int NT = BSR_BKT_NT, NW = BSR_BKT_NW, NA = NW * TPW;
+	// TPW = 2: a wave sorts its two tiles side by side, one per 32-lane half, 16 keys per lane and round (slots swz_m<4>);
+	// TPW = 1: one tile per wave, 8 keys per lane and round (slots swz_m<3>)
+	constexpr int SM = TPW == 2 ? 4 : 3;
+	static_assert(TPW == 1 || (TPW == 2 && AREA == 512), "paired sort: two 512-key areas per wave");
 	static_assert(NA * AREA >= BSR_SORT_CHUNK, "the long-tile routines sort 4096-key chunks in this LDS");
 	__shared__ uint64_t s_keys[NA * AREA];          // one area per owned tile; the long-tile routines use the first 4096 slots
 	__shared__ uint32_t s_cnt[NA];                  // elements per owned tile (the fill counters of the pass)
@@ -1176,7 +1180,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		if (valid && (int)part == j) {
 			const uint32_t L = hi >> k_log2;
 			const uint32_t pos = atomicAdd(&s_cnt[L], 1u);   // LDS
-			if (pos < (uint32_t)AREA) s_keys[L * AREA + swz_m<3>((int)pos)] = ((uint64_t)w1 << 32) | (uint64_t)(w0 & 0x00ffffffu);
+			if (pos < (uint32_t)AREA) s_keys[L * AREA + swz_m<SM>((int)pos)] = ((uint64_t)w1 << 32) | (uint64_t)(w0 & 0x00ffffffu);
 		}
 	};
 	// ---- the pass over the bucket: two elements per 16-byte load, eight loads in flight
@@ -1219,25 +1223,69 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	// ---- every wave sorts its tiles
 	bool any_long = false;   // (workgroup-uniform: every thread looks at all of the part's counts)
 	for (int L = 0; L < m; L++) any_long = any_long || s_cnt[L] > (uint32_t)AREA;
+	// ranks by counting, tiles of up to 64 keys ((depth bits, id) pairs are unique within a tile): no network, no further
+	// LDS traffic
+	auto sort_by_ranks = [&](const uint64_t* keys, int n, uint32_t start) {
+		uint64_t key = ~0ull;
+		if (lane < n) key = keys[swz_m<SM>(lane)];
+		const uint32_t kh = (uint32_t)(key >> 32), kl = (uint32_t)key;
+		uint32_t rank = 0;
+		for (int q = 0; q < n; q++) {
+			const uint64_t kq = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kh, q) << 32) |
+			                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kl, q);
+			rank += kq < key ? 1u : 0u;
+		}
+		if (lane < n) point_list[start + rank] = kl;
+	};
 #ifdef BSR_BKT_SORT_TWICE   // (cost-attribution builds only)
 	for (int rep = 0; rep < 2; rep++)
 #endif
+	if constexpr (TPW == 2) {
+		// tiles L = wave (lanes 0..31) and wave + NW (lanes 32..63), the same schedule for both: n2 = the larger one's
+		const int LA = wave, LB = wave + NW;
+		int nA = LA < m ? (int)s_cnt[LA] : 0, nB = LB < m ? (int)s_cnt[LB] : 0;
+		if (nA > AREA) nA = 0;   // (long: sorted further down)
+		if (nB > AREA) nB = 0;
+		const uint32_t startA = tile_first(LA < m ? LA : 0), startB = tile_first(LB < m ? LB : 0);
+		if (nA <= 64 && nB <= 64) {
+			if (nA > 0) sort_by_ranks(s_keys + LA * AREA, nA, startA);
+			if (nB > 0) sort_by_ranks(s_keys + LB * AREA, nB, startB);
+		} else {
+			int n2 = 128;
+			while (n2 < nA || n2 < nB) n2 <<= 1;
+			const int half = lane >> 5, t = lane & 31;
+			const int n = half ? nB : nA;
+			const uint32_t start = half ? startB : startA;
+			uint64_t* const keys = s_keys + (half ? LB : LA) * AREA;
+			// pads, then runs of 16 sorted in registers, in place: a lane reads and writes the same sixteen slots
+			round_sync<false>();
+			for (int i = n + t; i < n2; i += 32) keys[swz_m<4>(i)] = BSR_PAD_KEY;
+			round_sync<false>();
+			bool plain = true;
+			for (int i = t * 16; i < n2; i += 32 * 16) {
+				uint64_t e[16];
+				const int p0 = swz_m<4>(i);
+#pragma unroll
+				for (int q = 0; q < 16; q++) {
+					e[q] = keys[p0 ^ swz_m<4>(q)];
+					plain = plain && (i + q >= n || key_is_plain_double(e[q]));
+				}
+				reg_sort<4, false>(e);
+#pragma unroll
+				for (int q = 0; q < 16; q++) keys[p0 ^ swz_m<4>(q)] = e[q];
+			}
+			if (wave_ballot(!(plain && !force_int)) == 0ull)
+				merge_loaded_runs<32, 4, false, true>(keys, n2, start, n, t, point_list);
+			else
+				merge_loaded_runs<32, 4, false, false>(keys, n2, start, n, t, point_list);
+		}
+	} else
 	for (int L = wave; L < m; L += NW) {
 		const int n = (int)s_cnt[L];
 		const uint32_t start = tile_first(L);
 		uint64_t* const keys = s_keys + L * AREA;
 		if (n > 0 && n <= 64) {
-			// ranks by counting ((depth bits, id) pairs are unique within a tile): no network, no further LDS traffic
-			uint64_t key = ~0ull;
-			if (lane < n) key = keys[swz_m<3>(lane)];
-			const uint32_t kh = (uint32_t)(key >> 32), kl = (uint32_t)key;
-			uint32_t rank = 0;
-			for (int q = 0; q < n; q++) {
-				const uint64_t kq = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kh, q) << 32) |
-				                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)kl, q);
-				rank += kq < key ? 1u : 0u;
-			}
-			if (lane < n) point_list[start + rank] = kl;
+			sort_by_ranks(keys, n, start);
 		} else if (n > 64 && n <= AREA) {
 			int n2 = 128;
 			while (n2 < n) n2 <<= 1;

@@ -13,6 +13,19 @@ K = 1 << M
 PAD = (1 << 64) - 1
 
 
+@pytest.fixture(params=[3, 4], autouse=True)
+def keys_per_thread(request):
+    """M = 3: 8 keys per lane and round (k_sort_tiles_small, the wide classes, k_bucket_sort<1024, 1>); M = 4: 16 keys per
+    lane, two tiles side by side in the two 32-lane halves of a wave (k_bucket_sort<512, 2>)."""
+    global M, K
+    old = M
+    M = request.param
+    K = 1 << M
+    yield M
+    M = old
+    K = 1 << M
+
+
 def swz(i):
     return i ^ ((i >> M) & 31)
 
@@ -96,6 +109,8 @@ def sort_segment(keys, n2):
 
 @pytest.mark.parametrize("n2", [8, 16, 32, 64, 128, 256, 512, 1024, 2048])
 def test_rounds_sort_every_input(n2):
+    if n2 < K:
+        pytest.skip("a segment holds at least one run")
     rng = random.Random(n2)
     for trial in range(6):
         n = n2 if trial == 0 else rng.randint(max(1, n2 // 2 + 1), n2)
@@ -160,8 +175,10 @@ def _conflict_cycles(n2, nt, layout):
     return extra
 
 
-@pytest.mark.parametrize("n2,nt", [(64, 64), (512, 64), (1024, 64), (4096, 512), (8192, 1024)])
+@pytest.mark.parametrize("n2,nt", [(64, 64), (512, 64), (1024, 64), (4096, 512), (8192, 1024), (128, 32), (512, 32)])
 def test_swizzled_slots_are_bank_conflict_free(n2, nt):
+    if (M == 4) != (nt == 32):
+        pytest.skip("M = 4 runs with 32 lanes per tile (one half of a wave), M = 3 with whole waves")
     assert _conflict_cycles(n2, nt, swz) == 0
     if n2 >= 512:
         assert _conflict_cycles(n2, nt, lambda i: i) > 0   # the natural layout is not
