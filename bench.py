@@ -578,12 +578,17 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     # ---- the MI355X-native distribution: every rank gets ONLY what its block of neighbouring views can see, over its
     # own xGMI link (views.scatter_visible_gaussians), instead of the 236 B/Gaussian broadcast on every link ----
     def distribute(form):
-        fn = {"batched": lambda: views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0,
-                                                                 assignment="contiguous", device=dev, pipelined=False),
-              "pipelined": lambda: views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0,
-                                                                   assignment="contiguous", device=dev, pipelined=True),
-              "blockwise": lambda: views.scatter_visible_gaussians_blockwise(bufs if D.rank == 0 else None, pack, src=0,
-                                                                             device=dev)}[form]
+        if form == "batched":
+            def fn():
+                return views.scatter_visible_gaussians(bufs if D.rank == 0 else None, pack, src=0, assignment="contiguous",
+                                                       device=dev)
+        else:   # --experimental --c4-forms all
+            from bloomscene_amd.experimental import view_distribution as XD
+            fn = {"pipelined": lambda: XD.scatter_visible_gaussians_pipelined(bufs if D.rank == 0 else None, pack, src=0,
+                                                                              assignment="contiguous", device=dev,
+                                                                              pipelined=True),
+                  "blockwise": lambda: XD.scatter_visible_gaussians_blockwise(bufs if D.rank == 0 else None, pack, src=0,
+                                                                              device=dev)}[form]
         for _ in range(2):   # first pass: code-object loads, allocator growth, RCCL's peer connections; second: measured
             D.fence()
             t0 = time.perf_counter()
@@ -628,6 +633,7 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
     # Evaluated for even view blocks and for the best UNEVEN split (the source, busy distributing, takes fewer views);
     # broadcast path: 236 B P / link rate + ceil(views / N) views per rank.
     if D.rank == 0 and args.experimental:
+        from bloomscene_amd.experimental import view_distribution as XD
         LINK_GBS = 153.0   # xGMI, one link (MI355X guide); point-to-point mesh: the N - 1 sends run on their own links
         row_bytes = (3 + 3 + 4 + 1 + 3 * M) * 4
         per_view_ms = sc_out["views_per_call_16"]["ms_per_view_per_rank"]
@@ -657,10 +663,10 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
             return e0.elapsed_time(e1) / 3
         for w in (1, 2, 4, 8):
             def model(sizes, pipelined=True):
-                rr = views.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", sizes=sizes)[w]
+                rr = XD.visible_rows_per_rank(bufs, pack, worlds=(w,), assignment="contiguous", sizes=sizes)[w]
                 fb = [filter_block_ms(views.assign_views(n_views, r, w, "contiguous", sizes=sizes)) for r in range(w)] \
                     if pipelined == "blocks" else None
-                return rr, views.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
+                return rr, XD.modelled_scatter_sweep(n_views, w, rr, sizes, info["filter_ms"], pack_per_row, row_bytes,
                                                         per_view_ms, LINK_GBS, pipelined=pipelined, filter_block_ms=fb)
             even_sizes = views.staggered_block_sizes(n_views, w)
             rows_even, even = model(even_sizes)
@@ -674,7 +680,7 @@ def c4_sweep(D, args, P=1_000_000, W=1920, H=1080, deg=3, n_views=64, repeats=5)
                 pk = [rows_b[r] * pack_per_row for r in range(w)]
                 leave = [info["filter_ms"] + sum(pk)] + [info["filter_ms"] + sum(pk[1:r + 1]) + rows_b[r] * row_bytes /
                                                          (LINK_GBS * 1e6) for r in range(1, w)]
-                cand = views.balanced_block_sizes(n_views, w, leave, per_view_ms)
+                cand = XD.balanced_block_sizes(n_views, w, leave, per_view_ms)
                 rows_c, m = model(cand)
                 if m["sweep_ms"] < bal["sweep_ms"]:
                     sizes, rows_b, bal = cand, rows_c, m

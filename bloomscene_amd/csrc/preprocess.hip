@@ -279,8 +279,12 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 			const int w = rmax[0] - rmin[0];
 			for (int y = y0; y < y1; y++)
 				for (int x = x0; x < x1; x++) {
+#ifdef BSR_PRE_KNOCK_CULL   // (cost attribution only: every tile of the clipped rect is kept)
+					if (true) {
+#else
 					if (box_may_hit<15>(pix_x, pix_y, conic_a, conic_b, conic_c, power_cut, rb_c, rb_a, pd,
 					                    (float)(x * BSR_TILE), (float)(y * BSR_TILE))) {
+#endif
 						kept_mask |= (1ull << (uint32_t)((y - rmin[1]) * w + (x - rmin[0])));
 						atomicAdd(&s_hist[(uint32_t)((y + ty_off) * a.gx + x) & 255u], 1u);
 					}

@@ -182,6 +182,16 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	// instead the wave copies the run into LDS with coalesced 16-byte loads (all in flight at once) and every thread
 	// adds its rows from there, in the same order: same sums bit for bit.  The staging area is the SH tile, which is
 	// not in use yet (its own few KB in the instantiations without one).
+#ifdef BSR_BWD_HOIST   // (A/B: the per-Gaussian inputs of the chain requested before the slab gather, not behind it)
+	const int li_h = in_range ? idx : 0;
+	const float3 m_h = make_float3(a.means3D[3 * li_h], a.means3D[3 * li_h + 1], a.means3D[3 * li_h + 2]);
+	float sc_h[3] = {0.f, 0.f, 0.f};
+	float4 q_h = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (a.scales) {
+		sc_h[0] = a.scales[3 * li_h]; sc_h[1] = a.scales[3 * li_h + 1]; sc_h[2] = a.scales[3 * li_h + 2];
+		q_h = reinterpret_cast<const float4*>(a.rotations)[li_h];
+	}
+#endif
 	constexpr int STAGE_F4 = ROW_F4 > 0 ? 64 * (ROW_F4 + 1) : 192;   // float4 per wave
 	__shared__ float4 s_stage[4][STAGE_F4];   // ROW_F4 > 0: reinterpreted as ShTile<ROW_F4> by the SH part below
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -264,7 +274,11 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
 	const int li = in_range ? idx : 0;
+#ifdef BSR_BWD_HOIST
+	const float3 m = m_h;
+#else
 	const float3 m = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
+#endif
 	if (visible) {
 		const float* vm = a.viewmatrix;
 
@@ -277,8 +291,13 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 			for (int k = 0; k < 6; k++) V[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
 		} else {
 			// the forward's cov3D again (same function, same operands: same bits) instead of 24 B of scratch per Gaussian
+#ifdef BSR_BWD_HOIST
+			sc_in[0] = sc_h[0]; sc_in[1] = sc_h[1]; sc_in[2] = sc_h[2];
+			q_in = q_h;
+#else
 			sc_in[0] = a.scales[3 * idx]; sc_in[1] = a.scales[3 * idx + 1]; sc_in[2] = a.scales[3 * idx + 2];
 			q_in = reinterpret_cast<const float4*>(a.rotations)[idx];
+#endif
 			cov3d_from_scale_rot(sc_in, a.scale_modifier, q_in, V);
 		}
 		const float dcx = g[2], dcy = g[3], dcw = g[4];

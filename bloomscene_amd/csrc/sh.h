@@ -299,7 +299,14 @@ __device__ __forceinline__ void sh_tile_store(const ShTile<ROW_F4>& t, float* __
 		const int n = i * 64 + lane;
 		if (n < n_f4) {
 			const int g = n / ROW_F4, part = n - g * ROW_F4;
+#ifdef BSR_NT_SH_STORE   // (A/B: write-once gradient rows as nontemporal stores)
+			{
+				const float4 v = t.rows[g * ShTile<ROW_F4>::STRIDE + part];
+				__builtin_nontemporal_store(bsr_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<bsr_f32x4*>(&dst[n]));
+			}
+#else
 			dst[n] = t.rows[g * ShTile<ROW_F4>::STRIDE + part];
+#endif
 		}
 	}
 }

@@ -59,22 +59,34 @@ def test_bench_rccl_path_on_one_rank():
     assert "secondary" not in d                                  # not the headline workload
 
 
-def test_bench_two_ranks_control_flow_on_one_gpu():
-    """The N = 2 control flow of bench.py -- scene generated on rank 0 only, packed broadcast into rank 1's empty
-    buffers, per-rank cameras, views dealt round-robin, barrier + max-over-ranks timing, rank 0 printing -- with both
-    ranks on the one GPU of this box over gloo (RCCL refuses two ranks on one device; the RCCL calls themselves are
-    exercised by test_bench_rccl_path_on_one_rank).  A reduced Gaussian count keeps it short."""
-    d = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "200000", "--allreduce-grads",
-                    "--no-cpu-baseline", "--experimental", "--c4-forms", "all"],
-                   env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=2)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_several_ranks_control_flow_on_one_gpu(world):
+    """The N > 1 control flow of bench.py -- scene generated on rank 0 only, packed broadcast into the other ranks' empty
+    buffers, per-rank cameras, views dealt round-robin, barrier + max-over-ranks timing, rank 0 printing the compact line
+    with world_size and every rank's device -- with all ranks on the one GPU of this box over gloo (RCCL refuses two
+    ranks on one device; the RCCL calls themselves are exercised by test_bench_rccl_path_on_one_rank).  Four ranks is
+    what a one-GPU box allows comfortably (at most six processes may hold the card); the driver's N = 8 run differs
+    only in the number of ranks.  A reduced Gaussian count keeps it short.  With two ranks also the experimental
+    distribution forms (--experimental --c4-forms all)."""
+    extra = ["--experimental", "--c4-forms", "all"] if world == 2 else []
+    line, d = _run_bench(["--gpus", str(world), "--steps", "6", "--warmup", "2", "--gaussians", "200000", "--allreduce-grads",
+                          "--no-cpu-baseline"] + extra,
+                         env_extra={"BSR_BENCH_SINGLE_DEVICE": "1", "BSR_BENCH_BACKEND": "gloo"}, nproc=world, want_line=True)
     sv = d["c4"]["scatter_visible"]
-    assert sv["distribution_ms_pipelined"] > 0 and sv["distribution_ms_blockwise"] > 0
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    if world == 2:
+        assert sv["distribution_ms_pipelined"] > 0 and sv["distribution_ms_blockwise"] > 0 and "predicted" in d["c4"]
+    else:
+        assert "distribution_ms_pipelined" not in sv and "predicted" not in d["c4"]
+    assert d["n_gpus"] == world and d["scaling"] == "weak"
+    assert line["world_size"] == world and line["devices"] == [0] * world
     assert d["value"] > 0 and d["config"]["visible"] > 150_000          # rank 0 rendered the broadcast scene
     assert d["config"]["broadcast_ms"] > 0 and d["config"]["allreduce_ms_per_step"] > 0
     c4 = d["c4"]
-    assert c4["n_gpus"] == 2 and c4["views_per_rank"] == [32, 32] and c4["broadcast_ms"] > 0
+    assert c4["n_gpus"] == world and c4["views_per_rank"] == [64 // world] * world and c4["broadcast_ms"] > 0
     assert c4["views_per_call_16"]["value_including_broadcast"] > 0
+    s4 = line["c4"]
+    assert s4["views_per_rank"] == [64 // world] * world and s4["sweep_ms_cold"] > s4["sweep_ms_resident"] > 0
+    assert s4["scatter_visible"]["distribution_ms"] > 0
     assert "secondary" not in d and "cpu_baseline" not in d
 
 

@@ -10,6 +10,7 @@ import torch.multiprocessing as mp
 
 import helpers  # noqa: F401  (sys.path)
 from bloomscene_amd import views
+from bloomscene_amd.experimental import view_distribution as XD   # the forms kept out of the product path (gloo-tested only)
 
 
 def _free_port():
@@ -69,7 +70,7 @@ def test_broadcast_and_view_sharding_world2():
     assert sorted(results) == [(0, True), (1, True)]
 
 
-def _scatter_worker(rank, world, port, q, pipelined=True, src_fewer=0):
+def _scatter_worker(rank, world, port, q, pipelined=False, src_fewer=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,9 +82,15 @@ def _scatter_worker(rank, world, port, q, pipelined=True, src_fewer=0):
                "shs": torch.randn(P, M, 3, generator=g)}
         masks = torch.rand(world, P, generator=g) < torch.tensor([[0.1], [0.3], [0.0], [0.2]])[:world]   # rank 2: nothing visible
         cams = [helpers.scene_b(1, 64, 48, 0, n_views=10).cameras[i] for i in range(10)]
-        local, mine, info = views.scatter_visible_gaussians(src if rank == 0 else None, cams, src=0,
-                                                            assignment="contiguous", masks=masks if rank == 0 else None,
-                                                            pipelined=pipelined, src_fewer=src_fewer)
+        if pipelined:   # the experimental form: the source packs and sends rank by rank
+            local, mine, info = XD.scatter_visible_gaussians_pipelined(src if rank == 0 else None, cams, src=0,
+                                                                       assignment="contiguous",
+                                                                       masks=masks if rank == 0 else None, pipelined=True,
+                                                                       src_fewer=src_fewer)
+        else:           # the product form: one pack, all sends posted as one group
+            local, mine, info = views.scatter_visible_gaussians(src if rank == 0 else None, cams, src=0,
+                                                                assignment="contiguous",
+                                                                masks=masks if rank == 0 else None, src_fewer=src_fewer)
         ok = mine == views.assign_views(10, rank, world, "contiguous", 0, src_fewer)
         if rank == 0 and pipelined:   # remote ranks in rank order (a rank that sees nothing gets no message), own block last
             ok = ok and info["send_order"] == [r for r in range(1, world) if int(masks[r].sum()) > 0]
@@ -117,7 +124,7 @@ def test_pipelined_scatter_world4_and_the_batched_form():
     """The pipelined distribution (one pack + one send per rank, posted as soon as that rank's rows are packed, the
     source's own block last) over gloo with FOUR ranks, uneven view blocks (the source takes two views fewer), and the
     round-3 form (one pack, all sends together) beside it: same rows on every rank either way."""
-    for world, pipelined, src_fewer in ((4, True, 2), (4, False, 0), (2, True, 1)):
+    for world, pipelined, src_fewer in ((4, True, 2), (4, False, 0), (4, False, 2), (2, True, 1)):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
@@ -144,7 +151,7 @@ def _blockwise_worker(rank, world, port, q, src_fewer, with_layout):
         masks = torch.rand(world, P, generator=g) < torch.tensor([[0.1], [0.3], [0.0], [0.2]])[:world]   # rank 2: nothing visible
         cams = [helpers.scene_b(1, 64, 48, 0, n_views=10).cameras[i] for i in range(10)]
         layout = {k: tuple(v.shape[1:]) for k, v in src.items()} if with_layout else None
-        local, mine, info = views.scatter_visible_gaussians_blockwise(
+        local, mine, info = XD.scatter_visible_gaussians_blockwise(
             src if rank == 0 else None, cams, src=0, masks=masks if rank == 0 else None, src_fewer=src_fewer, layout=layout)
         ok = mine == views.assign_views(10, rank, world, "contiguous", 0, src_fewer)
         if rank == 0:   # every peer gets its header (also the one that sees nothing), in rank order; own block last
@@ -180,7 +187,7 @@ def test_blockwise_scatter_world4():
 def test_modelled_blockwise_sweep():
     """The stated critical path of the blockwise pipeline: F(1) F(2) P(1) F(3) P(2) ... on the source's stream."""
     rows, sizes = [100, 200, 300], [2, 3, 3]
-    m = views.modelled_scatter_sweep(8, 3, rows, sizes, filter_ms=9.0, pack_ms_per_row=0.01, row_bytes=100, per_view_ms=1.0,
+    m = XD.modelled_scatter_sweep(8, 3, rows, sizes, filter_ms=9.0, pack_ms_per_row=0.01, row_bytes=100, per_view_ms=1.0,
                                      link_GBs=0.1, pipelined="blocks", filter_block_ms=[0.5, 0.25, 0.125])
     # order 1, 2, 0: t = F1 + F2 = 0.375; + P1 = 2.375 -> rank 1 leaves; + F0 = 2.875; + P2 = 5.875 -> rank 2 leaves; + P0 = 6.875
     wire = [r * 100 / (0.1 * 1e6) for r in rows]
@@ -219,26 +226,26 @@ def test_modelled_scatter_sweep_critical_path():
     """views.modelled_scatter_sweep (the model bench.py states for a multi-GPU record to falsify) on numbers small enough
     to follow by hand: filter 1.0; packs 0.1 per 1000 rows; 1000 rows = 1 MB on a 1 GB/s link = 1.0; 0.5 per view."""
     kw = dict(filter_ms=1.0, pack_ms_per_row=1e-4, row_bytes=1000, per_view_ms=0.5, link_GBs=1.0)
-    one = views.modelled_scatter_sweep(8, 1, [5000], [8], **kw)
+    one = XD.modelled_scatter_sweep(8, 1, [5000], [8], **kw)
     assert one["sweep_ms"] == 4.0
     rows, sizes = [1000, 2000, 1000, 3000], [2, 2, 2, 2]
-    m = views.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=True, **kw)
+    m = XD.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=True, **kw)
     # rank 1 leaves at 1.0 + 0.2, rank 2 at + 0.1, rank 3 at + 0.3; wire 2.0 / 1.0 / 3.0; render 1.0 each; the source:
     # 1.0 + 0.7 + 1.0
     assert [round(x, 6) for x in m["finish_ms"]] == [2.7, 4.2, 3.3, 5.6] and m["critical_rank"] == 3
-    b = views.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=False, **kw)
+    b = XD.modelled_scatter_sweep(8, 4, rows, sizes, pipelined=False, **kw)
     assert [round(x, 6) for x in b["finish_ms"]] == [2.7, 4.7, 3.7, 5.7]      # every message leaves after ALL packs
     # fewer views for the rank on the critical path shortens it
-    m2 = views.modelled_scatter_sweep(8, 4, rows, [3, 2, 2, 1], pipelined=True, **kw)
+    m2 = XD.modelled_scatter_sweep(8, 4, rows, [3, 2, 2, 1], pipelined=True, **kw)
     assert round(m2["sweep_ms"], 6) == 5.1
 
 
 def test_balanced_block_sizes_deal_fewer_views_to_ranks_that_start_late():
-    sizes = views.balanced_block_sizes(64, 8, [0.53, 0.41, 0.45, 0.48, 0.51, 0.55, 0.58, 0.62], 0.05)
+    sizes = XD.balanced_block_sizes(64, 8, [0.53, 0.41, 0.45, 0.48, 0.51, 0.55, 0.58, 0.62], 0.05)
     assert sum(sizes) == 64 and sizes[1] == max(sizes) and sizes[7] == min(sizes) and max(sizes) - min(sizes) >= 3
     finish = [t + 0.05 * v for t, v in zip([0.53, 0.41, 0.45, 0.48, 0.51, 0.55, 0.58, 0.62], sizes)]
     assert max(finish) - min(finish) <= 0.05 + 1e-9          # all ranks finish within one view of each other
-    assert views.balanced_block_sizes(10, 2, [0.0, 0.0], 1.0) == [5, 5]
+    assert XD.balanced_block_sizes(10, 2, [0.0, 0.0], 1.0) == [5, 5]
     parts = [views.assign_views(64, r, 8, "contiguous", sizes=sizes) for r in range(8)]
     assert [i for p in parts for i in p] == list(range(64)) and [len(p) for p in parts] == sizes
     import pytest

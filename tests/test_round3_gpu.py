@@ -534,7 +534,8 @@ def test_group_visibility_equals_any_over_the_per_view_filter():
         want = per_view[members].any(dim=0) if members else torch.zeros(P, dtype=torch.bool, device=dev)
         assert torch.equal(got[g], want), g
     assert 0 < int(got[0].sum()) < P and not got[2].any()
-    rows = views.visible_rows_per_rank(dict(means3D=means, scales=scales, rotations=rots), cams, worlds=(1, 2))
+    from bloomscene_amd.experimental import view_distribution as XD
+    rows = XD.visible_rows_per_rank(dict(means3D=means, scales=scales, rotations=rots), cams, worlds=(1, 2))
     assert rows[1] == [int(per_view.any(dim=0).sum())] and len(rows[2]) == 2
     # the counts the kernel accumulates beside the masks
     got2, counts = views.group_visibility(cams, means, scales, rots, groups, return_counts=True)
