@@ -85,69 +85,88 @@ __device__ __forceinline__ void sh_bwd_deg(const BwdArgs& a, int idx, const floa
 	dmean[2] += (-ox * oz * dL_ddir[0] - oy * oz * dL_ddir[1] + (sum2 - oz * oz) * dL_ddir[2]) * invsum32;
 }
 
-// Wave-cooperative variant of sh_bwd_deg for M = 4 / 16 (ROW_F4 = 3 / 12): every lane of the wave
-// takes part; dL_dsh rows (zeros for culled Gaussians) leave through the LDS tile as contiguous
-// 1-KiB stores, and the coefficients come in the same way unless most of the wave is culled.
+// Wave-cooperative variant of sh_bwd_deg for M = 4 / 16 (ROW_F4 = 3 / 12): every lane of the wave takes part; dL_dsh
+// rows (zeros for culled Gaussians) leave through an LDS tile as contiguous wave stores and the coefficients come in
+// the same way -- in two halves of 32 Gaussians, through a tile of 32 rows (6.6 KB per wave at M = 16), and neither the
+// 48 coefficient gradients nor the 48 coefficients are ever held in registers: the gradients are formed from 16 basis
+// factors as their row is written (sh_coef_basis), the view-direction gradient reads the coefficients from the LDS row
+// channel by channel (sh_dir_grad_channel).  Same products, same sums in the same order as sh_bwd_deg.  Until round 6 a
+// 64-row tile and both 48-float sets in registers: 168 VGPRs + 53 KB of LDS = 3 waves per SIMD for a kernel that waits
+// for loads in 76 % of its wave cycles; now 78 VGPRs + 27 KB = 6 waves (C3: 130 -> 109 us, the dense leg 187 -> 158).
 template <int DEG, int ROW_F4>
-__device__ __forceinline__ void sh_bwd_coop(const BwdArgs& a, int idx, bool visible, const float3 m, const float* dcolor,
-                                            float* dmean, ShTile<ROW_F4>& tile, int lane, int g0, int n_valid)
+__device__ __forceinline__ void sh_bwd_coop_half(const BwdArgs& a, int idx, bool visible, const float3 m, const float* dcolor,
+                                                 float* dmean, ShTile<ROW_F4, 32>& tile, int lane, int g0, int n_valid)
 {
 	constexpr int NC = (DEG + 1) * (DEG + 1);
 	constexpr int N = NC * 3;
-	constexpr int STRIDE = ShTile<ROW_F4>::STRIDE;
+	constexpr int STRIDE = ShTile<ROW_F4, 32>::STRIDE;
 	const float ox = m.x - a.campos[0], oy = m.y - a.campos[1], oz = m.z - a.campos[2];
 	const float len = sqrtf((ox * ox + oy * oy) + oz * oz);
 	// culled lanes use direction 0 and gradient 0: their row is exactly zero
 	const float x = visible ? ox / len : 0.f, y = visible ? oy / len : 0.f, z = visible ? oz / len : 0.f;
 	const uint8_t cl = visible ? a.geom.clamped[idx] : (uint8_t)7;
-	float dL_dRGB[3];
-	dL_dRGB[0] = (visible && !(cl & 1)) ? dcolor[0] : 0.f;
-	dL_dRGB[1] = (visible && !(cl & 2)) ? dcolor[1] : 0.f;
-	dL_dRGB[2] = (visible && !(cl & 4)) ? dcolor[2] : 0.f;
-	if (visible) {   // same product as the reference's dL_dRGB *= clamped ? 0 : 1 (backward.cu:32-34)
+	float dL_dRGB[3] = {0.f, 0.f, 0.f};
+	if (visible) {   // the reference's dL_dRGB *= clamped ? 0 : 1 (backward.cu:32-34)
 		dL_dRGB[0] = dcolor[0] * ((cl & 1) ? 0.f : 1.f);
 		dL_dRGB[1] = dcolor[1] * ((cl & 2) ? 0.f : 1.f);
 		dL_dRGB[2] = dcolor[2] * ((cl & 4) ? 0.f : 1.f);
 	}
-	{   // phase 1: coefficient gradients -> own LDS row -> contiguous global stores
-		float dsh[N];
-		sh_coef_grad<DEG>(x, y, z, dL_dRGB, dsh);
-		float4* row = &tile.rows[lane * STRIDE];
+	const int half = lane >> 5;
+	float4* const row = &tile.rows[(lane & 31) * STRIDE];
+	// phase 1: coefficient gradients -> own LDS row -> contiguous global stores, 32 Gaussians at a time
+	{
+		float b[NC];
+		sh_coef_basis<DEG>(x, y, z, b);
 #pragma unroll
-		for (int i = 0; i < ROW_F4; i++) {
-			float4 o;
-			o.x = (i * 4 + 0 < N) ? dsh[(i * 4 + 0 < N) ? i * 4 + 0 : 0] : 0.f;
-			o.y = (i * 4 + 1 < N) ? dsh[(i * 4 + 1 < N) ? i * 4 + 1 : 0] : 0.f;
-			o.z = (i * 4 + 2 < N) ? dsh[(i * 4 + 2 < N) ? i * 4 + 2 : 0] : 0.f;
-			o.w = (i * 4 + 3 < N) ? dsh[(i * 4 + 3 < N) ? i * 4 + 3 : 0] : 0.f;
-			row[i] = o;
+		for (int h = 0; h < 2; h++) {
+			if (half == h) {
+#pragma unroll
+				for (int i = 0; i < ROW_F4; i++) {
+					float4 o;
+					o.x = (i * 4 + 0 < N) ? b[(i * 4 + 0 < N) ? (i * 4 + 0) / 3 : 0] * dL_dRGB[(i * 4 + 0) % 3] : 0.f;
+					o.y = (i * 4 + 1 < N) ? b[(i * 4 + 1 < N) ? (i * 4 + 1) / 3 : 0] * dL_dRGB[(i * 4 + 1) % 3] : 0.f;
+					o.z = (i * 4 + 2 < N) ? b[(i * 4 + 2 < N) ? (i * 4 + 2) / 3 : 0] * dL_dRGB[(i * 4 + 2) % 3] : 0.f;
+					o.w = (i * 4 + 3 < N) ? b[(i * 4 + 3 < N) ? (i * 4 + 3) / 3 : 0] * dL_dRGB[(i * 4 + 3) % 3] : 0.f;
+					row[i] = o;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			sh_tile_store<ROW_F4, 32>(tile, a.dL_dsh, g0 + 32 * h, min(32, max(0, n_valid - 32 * h)), lane);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
-		__builtin_amdgcn_wave_barrier();
-		sh_tile_store<ROW_F4>(tile, a.dL_dsh, g0, n_valid, lane);
-		__builtin_amdgcn_wave_barrier();
 	}
 	// phase 2: coefficients in, view-direction gradient
-	const int n_vis = __popcll(__ballot(visible));
-	if (n_vis == 0) return;
-	float c[N];
-	if (n_vis >= 24) {
-		sh_tile_load<ROW_F4>(tile, a.shs, g0, n_valid, lane);
-		__builtin_amdgcn_wave_barrier();
-		const float4* row = &tile.rows[lane * STRIDE];
+	const uint64_t vis_mask = __ballot(visible);
+	if (vis_mask == 0ull) return;
+	float dL_ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-		for (int i = 0; i < (N + 3) / 4; i++) {
-			const float4 v = row[i];
-			if (i * 4 + 0 < N) c[i * 4 + 0] = v.x;
-			if (i * 4 + 1 < N) c[i * 4 + 1] = v.y;
-			if (i * 4 + 2 < N) c[i * 4 + 2] = v.z;
-			if (i * 4 + 3 < N) c[i * 4 + 3] = v.w;
+	for (int h = 0; h < 2; h++) {
+		if (((vis_mask >> (32 * h)) & 0xffffffffull) == 0ull) continue;   // (wave-uniform)
+		sh_tile_load<ROW_F4, 32>(tile, a.shs, g0 + 32 * h, min(32, max(0, n_valid - 32 * h)), lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (visible && half == h) {
+			const float* const c = reinterpret_cast<const float*>(row);
+			float dx0, dy0, dz0, dx1, dy1, dz1, dx2, dy2, dz2;
+			sh_dir_grad_channel<DEG, 0>(c, x, y, z, dx0, dy0, dz0);
+			__builtin_amdgcn_sched_barrier(0);
+			sh_dir_grad_channel<DEG, 1>(c, x, y, z, dx1, dy1, dz1);
+			__builtin_amdgcn_sched_barrier(0);
+			sh_dir_grad_channel<DEG, 2>(c, x, y, z, dx2, dy2, dz2);
+			dL_ddir[0] = (dx0 * dL_dRGB[0] + dx1 * dL_dRGB[1]) + dx2 * dL_dRGB[2];
+			dL_ddir[1] = (dy0 * dL_dRGB[0] + dy1 * dL_dRGB[1]) + dy2 * dL_dRGB[2];
+			dL_ddir[2] = (dz0 * dL_dRGB[0] + dz1 * dL_dRGB[1]) + dz2 * dL_dRGB[2];
 		}
-	} else if (visible) {
-		load_sh<NC>(a.shs + (size_t)idx * a.M * 3, a.M, c);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();   // the other half's coefficients overwrite the tile
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
 	if (visible) {
-		float dL_ddir[3];
-		sh_dir_grad<DEG>(c, x, y, z, dL_dRGB, dL_ddir);
 		const float sum2 = ox * ox + oy * oy + oz * oz;
 		const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
 		dmean[0] += ((+sum2 - ox * ox) * dL_ddir[0] - oy * ox * dL_ddir[1] - oz * ox * dL_ddir[2]) * invsum32;
@@ -160,7 +179,7 @@ __device__ __forceinline__ void sh_bwd_coop(const BwdArgs& a, int idx, bool visi
 // -1: no SH at all (precomputed colours, BloomScene's call shape): without the SH code the kernel needs 40 % fewer
 // registers and nothing spills
 template <int ROW_F4>
-__global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(const BwdArgs a)
+__global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 6 : 4)) k_preprocess_bwd(const BwdArgs a)
 {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	const bool in_range = idx < a.P;
@@ -182,18 +201,8 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	// instead the wave copies the run into LDS with coalesced 16-byte loads (all in flight at once) and every thread
 	// adds its rows from there, in the same order: same sums bit for bit.  The staging area is the SH tile, which is
 	// not in use yet (its own few KB in the instantiations without one).
-#ifdef BSR_BWD_HOIST   // (A/B: the per-Gaussian inputs of the chain requested before the slab gather, not behind it)
-	const int li_h = in_range ? idx : 0;
-	const float3 m_h = make_float3(a.means3D[3 * li_h], a.means3D[3 * li_h + 1], a.means3D[3 * li_h + 2]);
-	float sc_h[3] = {0.f, 0.f, 0.f};
-	float4 q_h = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (a.scales) {
-		sc_h[0] = a.scales[3 * li_h]; sc_h[1] = a.scales[3 * li_h + 1]; sc_h[2] = a.scales[3 * li_h + 2];
-		q_h = reinterpret_cast<const float4*>(a.rotations)[li_h];
-	}
-#endif
-	constexpr int STAGE_F4 = ROW_F4 > 0 ? 64 * (ROW_F4 + 1) : 192;   // float4 per wave
-	__shared__ float4 s_stage[4][STAGE_F4];   // ROW_F4 > 0: reinterpreted as ShTile<ROW_F4> by the SH part below
+	constexpr int STAGE_F4 = (ROW_F4 > 0 && 32 * (ROW_F4 + 1) > 192) ? 32 * (ROW_F4 + 1) : 192;   // float4 per wave
+	__shared__ float4 s_stage[4][STAGE_F4];   // ROW_F4 > 0: reinterpreted as ShTile<ROW_F4, 32> by the SH part below
 	float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 	float g_z = 0.f;   // dL/d(view z): written only by the depth-gradient variant of k_render_bwd (else 0)
 	{
@@ -274,11 +283,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
 	const int li = in_range ? idx : 0;
-#ifdef BSR_BWD_HOIST
-	const float3 m = m_h;
-#else
 	const float3 m = make_float3(a.means3D[3 * li], a.means3D[3 * li + 1], a.means3D[3 * li + 2]);
-#endif
 	if (visible) {
 		const float* vm = a.viewmatrix;
 
@@ -291,13 +296,8 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 			for (int k = 0; k < 6; k++) V[k] = a.cov3D_precomp[(size_t)idx * 6 + k];
 		} else {
 			// the forward's cov3D again (same function, same operands: same bits) instead of 24 B of scratch per Gaussian
-#ifdef BSR_BWD_HOIST
-			sc_in[0] = sc_h[0]; sc_in[1] = sc_h[1]; sc_in[2] = sc_h[2];
-			q_in = q_h;
-#else
 			sc_in[0] = a.scales[3 * idx]; sc_in[1] = a.scales[3 * idx + 1]; sc_in[2] = a.scales[3 * idx + 2];
 			q_in = reinterpret_cast<const float4*>(a.rotations)[idx];
-#endif
 			cov3d_from_scale_rot(sc_in, a.scale_modifier, q_in, V);
 		}
 		const float dcx = g[2], dcy = g[3], dcw = g[4];
@@ -431,19 +431,35 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 		zero_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M);
 	}
 
+	// the covariance-side gradients are final here: out they go, before the SH part (13 registers it need not carry)
+	if (in_range) {
+		if (a.dL_dcov3D) {
+#pragma unroll
+			for (int k = 0; k < 6; k++) a.dL_dcov3D[(size_t)idx * 6 + k] = dcov[k];
+		}
+		if (a.scales) {
+			a.dL_dscale[3 * idx] = dscale[0];
+			a.dL_dscale[3 * idx + 1] = dscale[1];
+			a.dL_dscale[3 * idx + 2] = dscale[2];
+			reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+		}
+	}
+
+	__builtin_amdgcn_sched_barrier(0);   // (nothing of the SH part is scheduled into the chain above: registers)
 	if (ROW_F4 > 0) {
 		// SH part for the whole wave at once (the reference adds it to dL_dmean after the projection
 		// part, backward.cu:387-391; the cov3D part above does not touch dL_dmean, so the order holds)
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 		const int g0 = blockIdx.x * 256 + wave * 64;
 		const int n_valid = min(64, max(0, a.P - g0));
-		static_assert(sizeof(ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>) <= sizeof(s_stage[0]), "the SH tile lives in the staging area");
-		ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>& tile = *reinterpret_cast<ShTile<(ROW_F4 > 0 ? ROW_F4 : 1)>*>(&s_stage[wave][0]);
-		if (a.D <= 0) sh_bwd_coop<0, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
-		else if (a.D == 1) sh_bwd_coop<1, (ROW_F4 > 0 ? ROW_F4 : 1)>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		constexpr int RF = ROW_F4 > 0 ? ROW_F4 : 1, RF12 = ROW_F4 >= 12 ? ROW_F4 : 12;
+		static_assert(sizeof(ShTile<RF, 32>) <= sizeof(s_stage[0]), "the SH tile lives in the staging area");
+		ShTile<RF, 32>& tile = *reinterpret_cast<ShTile<RF, 32>*>(&s_stage[wave][0]);
+		if (a.D <= 0) sh_bwd_coop_half<0, RF>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
+		else if (a.D == 1) sh_bwd_coop_half<1, RF>(a, idx, visible, m, &g[6], dmean, tile, lane, g0, n_valid);
 		else if (ROW_F4 < 12) { /* degree > 1 needs M >= 9: not reachable with M = 4 (checked by the host) */ }
-		else if (a.D == 2) sh_bwd_coop<2, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
-		else sh_bwd_coop<3, (ROW_F4 >= 12 ? ROW_F4 : 12)>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<(ROW_F4 >= 12 ? ROW_F4 : 12)>*>(&tile), lane, g0, n_valid);
+		else if (a.D == 2) sh_bwd_coop_half<2, RF12>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<RF12, 32>*>(&tile), lane, g0, n_valid);
+		else sh_bwd_coop_half<3, RF12>(a, idx, visible, m, &g[6], dmean, *reinterpret_cast<ShTile<RF12, 32>*>(&tile), lane, g0, n_valid);
 	}
 	if (!in_range) return;
 
@@ -456,16 +472,6 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 3 : 4)) k_preprocess_bwd(
 	a.dL_dmean3D[3 * idx] = dmean[0];
 	a.dL_dmean3D[3 * idx + 1] = dmean[1];
 	a.dL_dmean3D[3 * idx + 2] = dmean[2];
-	if (a.dL_dcov3D) {
-#pragma unroll
-		for (int k = 0; k < 6; k++) a.dL_dcov3D[(size_t)idx * 6 + k] = dcov[k];
-	}
-	if (a.scales) {
-		a.dL_dscale[3 * idx] = dscale[0];
-		a.dL_dscale[3 * idx + 1] = dscale[1];
-		a.dL_dscale[3 * idx + 2] = dscale[2];
-		reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
-	}
 }
 
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s)

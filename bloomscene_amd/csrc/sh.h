@@ -258,55 +258,116 @@ __device__ __forceinline__ void sh_dir_grad(const float* c, float x, float y, fl
 	dL_ddir[2] = (dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1]) + dRGBdz[2] * dL_dRGB[2];
 }
 
+// The factors of sh_coef_grad alone: dL_dsh[k][ch] = b[k] * dL_dRGB[ch] (one multiply each, as DSH above), so a caller
+// can form the 3 * (DEG + 1)^2 products when it writes them out and never holds them all (16 instead of 48 registers).
+template <int DEG>
+__device__ __forceinline__ void sh_coef_basis(float x, float y, float z, float* b)
+{
+	b[0] = SH_C0;
+	if (DEG > 0) {
+		b[1] = -SH_C1 * y;
+		b[2] = SH_C1 * z;
+		b[3] = -SH_C1 * x;
+		if (DEG > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			b[4] = SH_C2[0] * xy;
+			b[5] = SH_C2[1] * yz;
+			b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+			b[7] = SH_C2[3] * xz;
+			b[8] = SH_C2[4] * (xx - yy);
+			if (DEG > 2) {
+				b[9] = SH_C3[0] * y * (3.f * xx - yy);
+				b[10] = SH_C3[1] * xy * z;
+				b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+				b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+				b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+				b[14] = SH_C3[5] * z * (xx - yy);
+				b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+			}
+		}
+	}
+}
+
+// sh_dir_grad for ONE colour channel, its coefficients read where they lie (c[k * 3 + CH]: an LDS row): the same
+// expressions in the same order as sh_dir_grad, so that a caller looping over the channels holds 15 coefficients at a
+// time instead of 45.
+template <int DEG, int CH>
+__device__ __forceinline__ void sh_dir_grad_channel(const float* c, float x, float y, float z, float& dRGBdx, float& dRGBdy,
+                                                    float& dRGBdz)
+{
+	dRGBdx = 0.f; dRGBdy = 0.f; dRGBdz = 0.f;
+#define SH(k) c[(k) * 3 + CH]
+	if (DEG > 0) {
+		dRGBdx = -SH_C1 * SH(3);
+		dRGBdy = -SH_C1 * SH(1);
+		dRGBdz = SH_C1 * SH(2);
+		if (DEG > 1) {
+			const float xx = x * x, yy = y * y, zz = z * z;
+			const float xy = x * y, yz = y * z, xz = x * z;
+			dRGBdx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+			dRGBdy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+			dRGBdz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+			if (DEG > 2) {
+				dRGBdx += (SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz +
+				           SH_C3[2] * SH(11) * -2.f * xy + SH_C3[3] * SH(12) * -3.f * 2.f * xz +
+				           SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) + SH_C3[5] * SH(14) * 2.f * xz +
+				           SH_C3[6] * SH(15) * 3.f * (xx - yy));
+				dRGBdy += (SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+				           SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+				           SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz +
+				           SH_C3[6] * SH(15) * -3.f * 2.f * xy);
+				dRGBdz += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+				           SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+				           SH_C3[5] * SH(14) * (xx - yy));
+			}
+		}
+	}
+#undef SH
+}
+
 // ---- wave-cooperative, LDS-transposed access to the [P][M][3] coefficient arrays ---------------
 // A lane reading or writing its own 12*M-byte block touches 64 different cache lines per wave
 // instruction with 16 B each.  Instead the wave's 64 blocks (contiguous in memory, 12 KiB at M = 16)
 // move with full 1-KiB wave instructions and are transposed through a padded LDS tile, one row
 // per Gaussian.  ROW_F4 = 3*M/4 float4 per Gaussian (3 for M = 4, 12 for M = 16); the row stride is
 // ROW_F4 + 1 float4 (52 dwords at M = 16: conflict-free for ds_read/write_b128).
-template <int ROW_F4>
+template <int ROW_F4, int ROWS = 64>
 struct ShTile {
 	static constexpr int STRIDE = ROW_F4 + 1;
-	float4 rows[64 * STRIDE];
+	float4 rows[ROWS * STRIDE];
 };
 
 // global -> LDS rows of the wave's Gaussians [g0, g0 + n_valid)
-template <int ROW_F4>
-__device__ __forceinline__ void sh_tile_load(ShTile<ROW_F4>& t, const float* __restrict__ base, int g0, int n_valid,
+template <int ROW_F4, int ROWS>
+__device__ __forceinline__ void sh_tile_load(ShTile<ROW_F4, ROWS>& t, const float* __restrict__ base, int g0, int n_valid,
                                              int lane)
 {
 	const float4* src = reinterpret_cast<const float4*>(base) + (size_t)g0 * ROW_F4;
 	const int n_f4 = n_valid * ROW_F4;
 #pragma unroll
-	for (int i = 0; i < ROW_F4; i++) {
+	for (int i = 0; i < (ROW_F4 * ROWS + 63) / 64; i++) {
 		const int n = i * 64 + lane;
 		if (n < n_f4) {
 			const int g = n / ROW_F4, part = n - g * ROW_F4;
-			t.rows[g * ShTile<ROW_F4>::STRIDE + part] = src[n];
+			t.rows[g * ShTile<ROW_F4, ROWS>::STRIDE + part] = src[n];
 		}
 	}
 }
 
 // LDS rows -> global
-template <int ROW_F4>
-__device__ __forceinline__ void sh_tile_store(const ShTile<ROW_F4>& t, float* __restrict__ base, int g0, int n_valid,
+template <int ROW_F4, int ROWS>
+__device__ __forceinline__ void sh_tile_store(const ShTile<ROW_F4, ROWS>& t, float* __restrict__ base, int g0, int n_valid,
                                               int lane)
 {
 	float4* dst = reinterpret_cast<float4*>(base) + (size_t)g0 * ROW_F4;
 	const int n_f4 = n_valid * ROW_F4;
 #pragma unroll
-	for (int i = 0; i < ROW_F4; i++) {
+	for (int i = 0; i < (ROW_F4 * ROWS + 63) / 64; i++) {
 		const int n = i * 64 + lane;
 		if (n < n_f4) {
 			const int g = n / ROW_F4, part = n - g * ROW_F4;
-#ifdef BSR_NT_SH_STORE   // (A/B: write-once gradient rows as nontemporal stores)
-			{
-				const float4 v = t.rows[g * ShTile<ROW_F4>::STRIDE + part];
-				__builtin_nontemporal_store(bsr_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<bsr_f32x4*>(&dst[n]));
-			}
-#else
-			dst[n] = t.rows[g * ShTile<ROW_F4>::STRIDE + part];
-#endif
+			dst[n] = t.rows[g * ShTile<ROW_F4, ROWS>::STRIDE + part];
 		}
 	}
 }

@@ -58,6 +58,8 @@ def main():
         st, g = Hh.run_oracle(c)
         t_or = time.time() - t0
         out = Hh.run_hip(c)
+        # the strict mode beside the default (BSR_FLAG_EXACT_GRAD: the reference's per-pair operations in the backward walk)
+        out_strict = Hh.run_hip(c, strict_gradients=True)
         rec = {"case": name, **{k: v for k, v in CASES[name].items()}, "num_rendered": int(st.num_rendered),
                "oracle_s": round(t_or, 1), "lib": os.path.basename(lib) if lib else "product",
                "exact_exp": bool(exact),
@@ -79,6 +81,10 @@ def main():
             rec["tensors"]["dL_d" + k] = {"max_rel_8d": float("%.3g" % m), "frac_above_1e-4": float("%.3g" % frac),
                                           "max_err_over_scale": float("%.3g" % Hh.max_err_over_scale(got, ref)),
                                           "elements": int(np.asarray(ref).size)}
+            ms, fracs = Hh.rel_err(getattr(out_strict.grads, k), ref)
+            rec["tensors"]["dL_d" + k]["strict_gradients"] = {
+                "max_rel_8d": float("%.3g" % ms), "frac_above_1e-4": float("%.3g" % fracs),
+                "max_err_over_scale": float("%.3g" % Hh.max_err_over_scale(getattr(out_strict.grads, k), ref))}
             m32, frac32 = Hh.rel_err(getattr(og32, k), ref)
             rec["tensors"]["dL_d" + k]["reference_f32_order_vs_f64"] = {
                 "max_rel_8d": float("%.3g" % m32), "frac_above_1e-4": float("%.3g" % frac32),
@@ -89,6 +95,12 @@ def main():
                 rec["tensors"]["dL_d" + k]["reference_contracted_vs_source_order"] = {
                     "max_rel_8d": float("%.3g" % mc), "frac_above_1e-4": float("%.3g" % fracc),
                     "max_err_over_scale": float("%.3g" % Hh.max_err_over_scale(getattr(ogc, k), ref))}
+        # side by side, per tensor: share of elements beyond 1e-4 relative in the default mode | in the strict mode | between
+        # two legal evaluations of the reference itself (contraction on / off: the floor); and the default's multiple of it
+        rec["frac_above_1e-4_default_strict_floor"] = {
+            k: [t["frac_above_1e-4"], t["strict_gradients"]["frac_above_1e-4"],
+                t.get("reference_contracted_vs_source_order", {}).get("frac_above_1e-4")]
+            for k, t in rec["tensors"].items()}
         print(json.dumps(rec), flush=True)
 
 
