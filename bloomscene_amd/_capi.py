@@ -18,8 +18,10 @@ CSRC = os.path.join(_HERE, "csrc")
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 _F = C.c_void_p  # device pointer
-ABI_VERSION = 3  # BSR_VERSION of include/bloomscene_rast.h this binding was written against
-OLDER_ABI_ACCEPTED = frozenset({2})   # use_library(..., allow_older_abi=True): 2 -> 3 only added entry points
+ABI_VERSION = 4  # BSR_VERSION of include/bloomscene_rast.h this binding was written against
+# use_library(..., allow_older_abi=True): 2 -> 3 only added entry points; 3 -> 4 dropped bsr_set_option / bsr_get_option (not
+# bound here any more) and added flag bits -- every entry point bound below has the same signature in all three
+OLDER_ABI_ACCEPTED = frozenset({2, 3})
 
 
 class StageProfile(C.Structure):
@@ -73,8 +75,6 @@ SIGNATURES = {
     "bsr_binning_bytes": (C.c_size_t, [C.c_int]),
     "bsr_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "bsr_transmittance_offset": (C.c_size_t, [C.c_void_p]),
-    "bsr_set_option": (C.c_int, [C.c_char_p, C.c_int]),
-    "bsr_get_option": (C.c_int, [C.c_char_p]),
     "bsr_profile_enable": (C.c_int, [C.c_int]),
     "bsr_profile_only": (C.c_int, [C.c_char_p]),
     "bsr_profile_reset": (C.c_int, []),
@@ -144,16 +144,6 @@ def use_library(path: str, allow_older_abi: bool = False):
         raise RuntimeError("use_library() must be called before the library is first used")
     LIB_PATH = os.path.abspath(path)
     _allow_older_abi = bool(allow_older_abi)
-
-
-def set_option(name: str, value) -> None:
-    """bsr_set_option (include/bloomscene_rast.h): the test hooks "sort_force_int", "sort_small_grids", "no_half_masks".  Numerics are per call:
-    bloomscene_amd.numerics / GaussianRasterizer(exact_exp=, strict_gradients=)."""
-    check(lib().bsr_set_option(name.encode(), int(bool(value))), "bsr_set_option")
-
-
-def get_option(name: str) -> int:
-    return int(lib().bsr_get_option(name.encode()))
 
 
 def last_error() -> str:

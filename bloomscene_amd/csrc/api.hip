@@ -191,7 +191,7 @@ void launch_binning(int plan, int P, int T, int gx, const int* n_ptr, int capaci
                     int* flags, BinElem** elems_sorted, BinElem** elems_free, int* compact_out, hipStream_t s);
 void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
                        const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
-                       BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s);
+                       BinElem* elems_free, uint32_t* point_list, int compact, int force_int, int small_grids, hipStream_t s);
 void launch_render_fwd(int gx, int gy, int n_views, int W, int H, const int* n_ptr, int capacity, const uint2* tile_range,
                        uint32_t* point_list, int* masks_flag,
                        const float4* rec, const float* bg, float* final_T, uint32_t* n_contrib, float* out_color,
@@ -201,23 +201,6 @@ void launch_render_bwd(int gx, int gy, int W, int H, const uint2* tile_range, co
                        const uint32_t* n_contrib, const float* dL_dpix, const float* out_depth, const float* dL_depths,
                        int* masks_flag, float4* slab, bool strict, int num_rendered, hipStream_t s);
 void launch_preprocess_bwd(const BwdArgs& a, hipStream_t s);
-
-// ---------------------------------------------------------------- options (bsr_set_option)
-// Numerics are per call (the `flags` of bsr_forward_ex / bsr_backward_ex); the one process-wide switch left is a test
-// hook that changes no result.
-static std::atomic<int> g_opt_sort_force_int{0};
-static std::atomic<int> g_opt_sort_small_grids{0};  // the wide sort classes on grids of 2 / 1 / 1 workgroups (their striding loops)
-static std::atomic<int> g_opt_no_half_masks{0};   // the forward keeps its per-half box tests to itself: the backward tests again
-int opt_sort_force_int() { return g_opt_sort_force_int.load(std::memory_order_relaxed); }
-int opt_sort_small_grids() { return g_opt_sort_small_grids.load(std::memory_order_relaxed); }
-static std::atomic<int>* find_option(const char* name)
-{
-	if (!name) return nullptr;
-	if (!strcmp(name, "sort_force_int")) return &g_opt_sort_force_int;
-	if (!strcmp(name, "no_half_masks")) return &g_opt_no_half_masks;
-	if (!strcmp(name, "sort_small_grids")) return &g_opt_sort_small_grids;
-	return nullptr;
-}
 
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -362,9 +345,10 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	// (BSR_FLAG_EXACT_GRAD concerns the backward alone: accepted here so that a caller can hand one word to both)
-	if (flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD | BSR_FLAG_NO_READBACK)) {
+	const unsigned known_flags = BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD | BSR_FLAG_NO_READBACK | BSR_FLAG_TEST_MASK;
+	if (flags & ~known_flags) {
 		if (num_rendered) *num_rendered = 0;
-		return fail("forward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_EXP | BSR_FLAG_EXACT_GRAD | BSR_FLAG_NO_READBACK));
+		return fail("forward: unknown flag bits 0x%x", flags & ~known_flags);
 	}
 	const bool no_readback = (flags & BSR_FLAG_NO_READBACK) != 0;
 	const long long given_capacity = (no_readback && num_rendered) ? (long long)*num_rendered : 0;
@@ -508,15 +492,15 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			// (the 256 digit totals of pass 1 lie behind the rows of hist1)
 			const uint32_t* digit_total1 = geom.hist1 + (size_t)256 * (((size_t)n_wg + 7) / 8 * 8);
 			launch_sort_tiles(plan, T, (int)capacity, n_ptr, (int)capacity, img.tile_range, img.big_tiles, img.flags,
-			                  digit_total1, elems_sorted, elems_free, bin.point_list, elems_compact, s);
+			                  digit_total1, elems_sorted, elems_free, bin.point_list, elems_compact,
+			                  (flags & BSR_FLAG_TEST_SORT_INT) != 0, (flags & BSR_FLAG_TEST_SMALL_GRIDS) != 0, s);
 		}
 		STAGE_CHECK("sort_tiles", debug, s);
 		{
 			StageTimer t("render_fwd", s);
 			// one view of at most 2^24 Gaussians: the forward's split-list staging hands its per-half box tests to the
 			// backward in the top byte of the point_list words (flags[6] says whether it did)
-			int* const masks_flag = (V == 1 && P <= (1 << 24) && !g_opt_no_half_masks.load(std::memory_order_relaxed))
-			                            ? img.flags + 6 : nullptr;
+			int* const masks_flag = (V == 1 && P <= (1 << 24) && !(flags & BSR_FLAG_TEST_NO_HALF_MASKS)) ? img.flags + 6 : nullptr;
 			launch_render_fwd(gx, gy, V, width, height, n_ptr, (int)capacity, img.tile_range, bin.point_list, masks_flag, geom.rec,
 			                  background, V > 1 ? nullptr : img.final_T, V > 1 ? nullptr : img.n_contrib, out_color, out_depth,
 			                  (flags & BSR_FLAG_EXACT_EXP) != 0, no_readback, img.flags + BSR_POOL_FWD, s);
@@ -611,22 +595,6 @@ int bsr_read_counts(const char* image_buffer, int width, int height, void* strea
 	if (kept) *kept = (int)k;
 	if (num_rendered) *num_rendered = (int)r;
 	return 0;
-}
-
-int bsr_set_option(const char* name, int value)
-{
-	std::atomic<int>* o = find_option(name);
-	if (!o) {
-		g_err[0] = 0;
-		return fail("bsr_set_option: unknown option '%s'", name ? name : "(null)");
-	}
-	o->store(value != 0, std::memory_order_relaxed);
-	return 0;
-}
-int bsr_get_option(const char* name)
-{
-	std::atomic<int>* o = find_option(name);
-	return o ? o->load(std::memory_order_relaxed) : -1;
 }
 
 int bsr_profile_enable(int on)
@@ -905,8 +873,9 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 	g_err[0] = 0;
 	hipStream_t s = (hipStream_t)stream;
 	// (the forward's flags are accepted and ignored, so that a caller can hand one word to both calls)
-	if (flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK))
-		return fail("backward: unknown flag bits 0x%x", flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK));
+	if (flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK | BSR_FLAG_TEST_MASK))
+		return fail("backward: unknown flag bits 0x%x",
+		            flags & ~(unsigned)(BSR_FLAG_EXACT_GRAD | BSR_FLAG_EXACT_EXP | BSR_FLAG_NO_READBACK | BSR_FLAG_TEST_MASK));
 	if (P == 0) return 0;
 	if (check_common(P, width, height, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix)) return 1;
 	if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("scratch buffer is null");

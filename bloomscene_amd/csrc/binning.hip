@@ -845,7 +845,8 @@ __device__ __forceinline__ void lds_stride_rounds(uint64_t* keys, int n2, int re
 }
 
 // Ascending sort of n2 (a power of two >= 2^M) keys in LDS whose aligned runs of 2^M are sorted already; pads
-// (BSR_PAD_KEY) are ordinary keys.  Ends with a sync.
+// (BSR_PAD_KEY) are ordinary keys.  Ends with a sync.  (Skipping the work items of blocks that hold pads only -- 20 % of
+// the items of a 1200-key segment in 2048 slots -- was measured in round 6: no change in either sort kernel.)
 template <int NT, int M, bool BLOCK, bool F64>
 __device__ __forceinline__ void lds_sort_rounds(uint64_t* keys, int n2, int t)
 {
@@ -1463,8 +1464,12 @@ void launch_binning(int plan, int P, int T, int gx, const int* n_ptr, int capaci
 // without long lists pays one near-empty launch, not 3 x T idle workgroups.
 void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capacity, uint2* tile_range,
                        const uint32_t* big_tiles, const int* flags, const uint32_t* digit_total1, const BinElem* elems,
-                       BinElem* elems_free, uint32_t* point_list, int compact, hipStream_t s)
+                       BinElem* elems_free, uint32_t* point_list, int compact, int force_int, int small_grids_flag,
+                       hipStream_t s)
 {
+	// force_int / small_grids_flag: BSR_FLAG_TEST_SORT_INT / BSR_FLAG_TEST_SMALL_GRIDS of the call (test-only, no result
+	// changes): every segment through the integer compare-exchange flavour, which real inputs reach only with NaN /
+	// non-positive depth bits; the wide classes on grids of 2 / 1 workgroups
 	if (plan >= 2) {
 		// second pass + sort in one launch: `elems` is still in pass-1 order; the free buffer holds the keys of long tiles.
 		// 64 KB of LDS either way: 16 tile areas of 512 keys (two per wave) or 8 of 1024; a bucket has ceil(T / 256)
@@ -1477,15 +1482,12 @@ void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capac
 		uint64_t* const big_keys = reinterpret_cast<uint64_t*>(elems_free);
 		if (small_areas)
 			hipLaunchKernelGGL((k_bucket_sort<512, 2>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
-			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, opt_sort_force_int());
+			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, force_int);
 		else
 			hipLaunchKernelGGL((k_bucket_sort<1024, 1>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
-			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, opt_sort_force_int());
+			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, force_int);
 		return;
 	}
-	// test hook: bsr_set_option("sort_force_int", 1) sends every segment through the integer compare-exchange flavour,
-	// which real inputs reach only with NaN / non-positive depth bits
-	const int force_int = opt_sort_force_int();
 	// sparse frames (the views of a camera sweep: every tile a few dozen entries) get the tiny class its own kernel;
 	// where tiles average 128 entries or more the few short ones stay with the small class (one launch fewer)
 	const bool tiny = (long long)n_bound < 128ll * T;
@@ -1496,9 +1498,9 @@ void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capac
 	                   force_int, tiny ? 64 : 0, compact);
 	// n instances can fill at most n / 1025 tiles of the first wide class and n / 4097 of the two longer ones: the grid
 	// covers both work lists (n_bound >= the real count), capped -- the workgroups stride over their lists
-	// (test hook "sort_small_grids": caps of 2 / 1, so that ordinary test frames drive several tiles through one
+	// (BSR_FLAG_TEST_SMALL_GRIDS: caps of 2 / 1, so that ordinary test frames drive several tiles through one
 	// workgroup's striding loop -- with the product caps that takes > 2560 / 512 long tiles in one frame)
-	const bool small_grids = opt_sort_small_grids() != 0;
+	const bool small_grids = small_grids_flag != 0;
 	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), small_grids ? 2 : 2560),
 	          gw = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
 	if (g1 + gw > 0)

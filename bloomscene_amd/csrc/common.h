@@ -188,10 +188,6 @@ int fail(const char* fmt, ...);
 // One blocking 4-byte device->host read through the calling thread's pinned landing buffer.  api.hip
 int read_u32_blocking(const uint32_t* dev, uint32_t* out, hipStream_t s);
 
-// Process-wide test hook of bsr_set_option (include/bloomscene_rast.h), read by the sort launcher.  api.hip
-int opt_sort_force_int();
-int opt_sort_small_grids();
-
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
 
 // ---- pinned exp: identical algorithm to bsro_expf in oracle/bsr_oracle.c (<= 1 ulp) ----

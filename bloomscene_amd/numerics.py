@@ -12,6 +12,10 @@ import threading
 
 FLAG_EXACT_EXP = 1    # BSR_FLAG_EXACT_EXP: pinned exp on every evaluation of the forward blend (bit-equal to the oracle)
 FLAG_EXACT_GRAD = 2   # BSR_FLAG_EXACT_GRAD: the reference's per-pair operations in the backward tile walk
+# test-only flags (include/bloomscene_rast.h BSR_FLAG_TEST_*): no result changes, they steer a call through rare code paths
+FLAG_TEST_SORT_INT = 0x100
+FLAG_TEST_SMALL_GRIDS = 0x200
+FLAG_TEST_NO_HALF_MASKS = 0x400
 
 _tls = threading.local()
 
@@ -34,13 +38,17 @@ class numerics:
     """``with numerics(exact_exp=True, strict_gradients=True): ...`` -- the default mode of every rasterizer call the
     calling THREAD issues inside the block (nestable; ``None`` keeps the enclosing block's choice)."""
 
-    def __init__(self, exact_exp=None, strict_gradients=None):
+    def __init__(self, exact_exp=None, strict_gradients=None, test_flags=None):
         self._args = (exact_exp, strict_gradients)
+        self._test_flags = test_flags   # tests only: FLAG_TEST_* bits, replacing the enclosing block's (None keeps them)
         self._saved = 0
 
     def __enter__(self):
         self._saved = _current()
-        _tls.flags = resolve_flags(*self._args)
+        f = resolve_flags(*self._args)
+        if self._test_flags is not None:
+            f = (f & ~0x700) | (int(self._test_flags) & 0x700)
+        _tls.flags = f
         return self
 
     def __exit__(self, *exc):

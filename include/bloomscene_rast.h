@@ -15,7 +15,7 @@
  * calls (per host thread: a pinned 32-byte HOST landing buffer -- which also receives the error word of a
  * prefiltered = 1 call to bsr_visible_filter straight from the kernel --, an event and the previous call's shape /
  * num_rendered -- and, for the fused anchor front end, its selection count -- as size hints; process-wide: the
- * opt-in stage profiler and one test hook, bsr_set_option); the three scratch buffers handed from forward to backward
+ * opt-in stage profiler); the three scratch buffers handed from forward to backward
  * are opaque, as in the reference (__init__.py:97,106).
  * NUMERICS ARE PER CALL: the `flags` argument of bsr_forward_ex / bsr_backward_ex (BSR_FLAG_*).  There is no
  * process-wide numerics switch; two host threads may run different modes side by side (the reference interface has
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define BSR_VERSION 3
+#define BSR_VERSION 4
 
 /* ---- per-call numerics flags (bsr_forward_ex, bsr_backward_ex, bsr_forward_views, the fused anchor front end) ------
  * BSR_FLAG_EXACT_EXP   forward: 0 (default) = the blend takes exp(power) from the hardware's v_exp_f32 (1 ulp) wherever
@@ -74,6 +74,23 @@ extern "C" {
  *   bsr_read_counts.
  *   Not for prefiltered calls (their violation flag is part of the read-back). */
 #define BSR_FLAG_NO_READBACK 4u
+/* TEST-ONLY flags of bsr_forward_ex (no reference counterpart).  They change NO result: they steer ONE call through code
+ * the tests must reach and real inputs reach rarely -- per call, like every other flag (until round 6 these were
+ * process-wide switches behind bsr_set_option; the library now keeps no switch between calls at all).
+ *   BSR_FLAG_TEST_SORT_INT       every per-tile sort takes the integer compare-exchange flavour, which real inputs
+ *                                reach only with NaN / non-positive depth bits (same order either way),
+ *   BSR_FLAG_TEST_SMALL_GRIDS    the grids of the wide per-tile sort classes are capped at 2 / 1 workgroups (product:
+ *                                2560 / 512), so that a frame with a handful of long tiles exercises the loops in which
+ *                                one workgroup sorts several tiles in turn (same order either way),
+ *   BSR_FLAG_TEST_NO_HALF_MASKS  the forward keeps the per-half box tests of its tile walk to itself (by default it
+ *                                leaves them in the top byte of the sorted id list -- one view of at most 2^24
+ *                                Gaussians -- and the backward's waves build their lists from that byte instead of
+ *                                testing every record again).
+ * Accepted and ignored by the backward. */
+#define BSR_FLAG_TEST_SORT_INT      0x100u
+#define BSR_FLAG_TEST_SMALL_GRIDS   0x200u
+#define BSR_FLAG_TEST_NO_HALF_MASKS 0x400u
+#define BSR_FLAG_TEST_MASK          0x700u
 
 /* Resize callback for an opaque scratch buffer: must return a device pointer to at least
  * `bytes` bytes (256-byte aligned) that stays valid until the matching backward call.
@@ -465,20 +482,6 @@ size_t bsr_image_bytes(int width, int height);
  * accum_alpha in its opaque ImageState (rasterizer_impl.h:45-53, forward.cu:459) and exposes no alpha output;
  * used by the host's opt-in return_alpha extension. */
 size_t bsr_transmittance_offset(const void* image_buffer);
-
-/* ---- process-wide test hook (no reference counterpart; changes no result) -----------------------
- * bsr_set_option(name, value) -> 0, or 1 for an unknown name; bsr_get_option(name) -> value, or -1.
- *   "sort_force_int"  default 0: 1 sends every per-tile sort through the integer compare-exchange flavour
- *                     that real inputs reach only with NaN / non-positive depth bits (same order either way).
- *   "sort_small_grids" default 0: 1 caps the grids of the three wide per-tile sort classes at 2 / 1 / 1 workgroups (product:
- *                     2560 / 512 / 512), so that a frame with a handful of long tiles exercises the loops in which one
- *                     workgroup sorts several tiles in turn (same order either way).
- *   "no_half_masks"   default 0: 1 makes the forward keep the per-half box tests of its tile walk to itself (by default
- *                     it leaves them in the top byte of the sorted id list -- one view of at most 2^24 Gaussians -- and
- *                     the backward's waves build their lists from that byte instead of testing every record again).
- * Numerics are NOT options: see BSR_FLAG_* above.  Read at every launch (atomic). */
-int bsr_set_option(const char* name, int value);
-int bsr_get_option(const char* name);
 
 /* ---- measurement hooks (no reference counterpart; used by bench.py only) ------------------
  * bsr_profile_enable(1) makes every kernel stage of subsequent calls be bracketed by hipEvents

@@ -517,6 +517,15 @@ static int g_sum_f32 = 0;
 void bsro_set_sum_mode(int f32) { g_sum_f32 = f32; }
 #define ACC(dst, v) do { if (g_sum_f32) (dst) = (double)((float)(dst) + (float)(v)); else (dst) += (v); } while (0)
 
+/* Measurement only (docs/EXPERIMENTS.md, round 6: "could a long tile's backward be cut into segments?"): with
+ * seg > 0 every pixel's back-to-front recurrences are RESTARTED wherever the list position is a multiple of seg, from
+ * what a forward pass could have checkpointed there -- T before the entry and the colour accumulated before it -- plus
+ * the pixel's final colour: T <- T_ck, accum_rec <- (C_final - C_ck) / T_ck (a subtraction instead of the reference's
+ * recurrence, :527-536).  Not the reference's arithmetic; used to measure how far such a walk would land from it. */
+static int g_bwd_seg = 0;
+void bsro_set_backward_segment(int seg) { g_bwd_seg = seg; }
+#define BSRO_MAX_CK 4096
+
 /* -DBSRO_CONTRACT_RENDER_BWD (make fma -> libbsr_oracle_fma.so, measurement only): THIS function alone is compiled with
  * floating-point contraction, i.e. the compiler may fuse a * b + c into one FMA wherever it likes -- what nvcc does to
  * the reference by default (RAST/setup.py passes no -fmad=false).  Both builds are legal evaluations of backward.cu:
@@ -559,10 +568,40 @@ void bsro_render_backward(int P, int R, const uint32_t* ranges, const uint32_t* 
 				for (int i = 0; i < NUM_CHANNELS; i++) dL_dpixel[i] = dL_dpixels[(size_t)i * H * W + pix_id];
 				float last_alpha = 0;
 				float last_color[NUM_CHANNELS] = {0};
+				/* (measurement mode) forward checkpoints of this pixel at the list positions that are multiples of seg */
+				float ckT[BSRO_MAX_CK], ckC[BSRO_MAX_CK][NUM_CHANNELS], Cfin[NUM_CHANNELS] = {0};
+				const int seg = g_bwd_seg;
+				if (seg > 0) {
+					float Tf = 1.0f, Cf[NUM_CHANNELS] = {0};
+					for (uint32_t q = 0; q < (uint32_t)last_contributor; q++) {
+						if (q % (uint32_t)seg == 0 && q / (uint32_t)seg < BSRO_MAX_CK) {
+							ckT[q / seg] = Tf;
+							for (int ch = 0; ch < NUM_CHANNELS; ch++) ckC[q / seg][ch] = Cf[ch];
+						}
+						const uint32_t idf = point_list[r0 + q];
+						const float dxf = points_xy_image[2 * idf] - pixf[0], dyf = points_xy_image[2 * idf + 1] - pixf[1];
+						const float* cf = conic_opacity + 4 * (size_t)idf;
+						const float pw = -0.5f * (cf[0] * dxf * dxf + cf[2] * dyf * dyf) - cf[1] * dxf * dyf;
+						if (pw > 0.0f) continue;
+						const float af = fminf(0.99f, cf[3] * bsro_expf(pw));
+						if (af < 1.0f / 255.0f) continue;
+						for (int ch = 0; ch < NUM_CHANNELS; ch++) Cf[ch] = fmaf(colors[idf * NUM_CHANNELS + ch] * af, Tf, Cf[ch]);
+						Tf = Tf * (1 - af);
+					}
+					for (int ch = 0; ch < NUM_CHANNELS; ch++) Cfin[ch] = Cf[ch];
+				}
 				for (uint32_t k = 0; k < r1 - r0; k++) {
 					const uint32_t slot = r1 - k - 1; /* back to front, :485 */
 					contributor--;
 					if (contributor >= (uint32_t)last_contributor) continue;
+					if (seg > 0 && (contributor + 1) % (uint32_t)seg == 0 && contributor + 1 < (uint32_t)last_contributor &&
+					    (contributor + 1) / (uint32_t)seg < BSRO_MAX_CK) {
+						/* first entry of a segment (walking backwards): restart from the checkpoint behind it */
+						const uint32_t b = (contributor + 1) / (uint32_t)seg;
+						T = ckT[b];
+						for (int ch = 0; ch < NUM_CHANNELS; ch++) accum_rec[ch] = (Cfin[ch] - ckC[b][ch]) / ckT[b];
+						last_alpha = 0;
+					}
 					const uint32_t id = point_list[slot];
 					const float dx = points_xy_image[2 * id] - pixf[0];
 					const float dy = points_xy_image[2 * id + 1] - pixf[1];

@@ -197,7 +197,7 @@ def forward(rs, means3D, opacities, shs=None, colors_precomp=None, scales=None, 
     return st
 
 
-def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradient=False, f32_sums=False):
+def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradient=False, f32_sums=False, segment=0):
     """Rasterizer::backward (rasterizer_impl.cu:403-504) + RasterizeGaussiansBackwardCUDA
     (rasterize_points.cu:119-200).  ``grad_depth`` is accepted and ignored, like the reference --
     unless ``depth_gradient=True``, the opt-in EXTENSION that adds the true
@@ -229,6 +229,9 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradien
     # f32_sums: the pair sums added in binary32 in one fixed order (one legal outcome of the reference's float
     # atomicAdds) instead of the order-free binary64 definition; only to measure the spread between legal outcomes
     L.bsro_set_sum_mode(C.c_int(1 if f32_sums else 0))
+    # segment > 0: measurement only -- the recurrences restarted from forward checkpoints every `segment` list entries
+    # (bsr_oracle.c: bsro_set_backward_segment; docs/EXPERIMENTS.md round 6)
+    L.bsro_set_backward_segment(C.c_int(int(segment)))
     try:
         L.bsro_render_backward(
             C.c_int(P), C.c_int(R), _p(st.ranges), _p(plist), C.c_int(W), C.c_int(H), _p(rs.bg), _p(st.means2D),
@@ -237,6 +240,7 @@ def backward(st, grad_color, grad_depth=None, want_abs_sums=False, depth_gradien
             _p(g.abs_sums) if want_abs_sums else None)
     finally:
         L.bsro_set_sum_mode(C.c_int(0))
+        L.bsro_set_backward_segment(C.c_int(0))
     if not depth_gradient:
         return backward_chain(st, g)
     g.dL_dz = np.zeros((P,), dtype=np.float32)

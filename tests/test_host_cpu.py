@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bloomscene_rast.h but not exported"
     assert declared == set(_capi.SIGNATURES), "ctypes table and header disagree"
-    assert lib.bsr_version() == 3
+    assert lib.bsr_version() == 4
     assert lib.bsr_last_error() == b""
     # scratch sizing (reference required<T>(n), rasterizer_impl.h:68-73): monotone, 256-B granular
     assert lib.bsr_geometry_bytes(0) < lib.bsr_geometry_bytes(1000) < lib.bsr_geometry_bytes(2000)
@@ -314,15 +314,20 @@ def test_camera_pack_and_multi_view_helpers_on_cpu():
     with pytest.raises(RuntimeError, match="GPU"):
         render_anchors(torch.zeros(2, 3), torch.ones(2, 6), torch.zeros(2, 5, 3), torch.ones(10, 1), torch.zeros(10, 3),
                        torch.zeros(10, 7), _settings())
-    # the process-wide test hook round-trips; numerics are NOT options (per call: BSR_FLAG_*), unknown names are an error
-    assert _capi.get_option("sort_force_int") == 0
-    _capi.set_option("sort_force_int", 1)
-    assert _capi.get_option("sort_force_int") == 1
-    _capi.set_option("sort_force_int", 0)
-    assert _capi.get_option("exact_exp") == -1
-    assert _capi.get_option("no_such_option") == -1
-    with pytest.raises(RuntimeError, match="unknown option"):
-        _capi.set_option("no_such_option", 1)
+    # the library keeps no switch between calls: the former process-wide test hooks are per-call flags now (round 6),
+    # and the python context that carries them is thread-local and nestable
+    assert "bsr_set_option" not in _capi.SIGNATURES and not hasattr(_capi, "set_option")
+    from bloomscene_amd import numerics
+    from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS, FLAG_TEST_SORT_INT, resolve_flags
+    assert resolve_flags() == 0
+    with numerics(exact_exp=True, test_flags=FLAG_TEST_SORT_INT):
+        assert resolve_flags() == 1 | FLAG_TEST_SORT_INT
+        with numerics(test_flags=FLAG_TEST_NO_HALF_MASKS):        # replaces the enclosing block's test bits, keeps its numerics
+            assert resolve_flags() == 1 | FLAG_TEST_NO_HALF_MASKS
+        with numerics(strict_gradients=True):                      # None keeps the test bits
+            assert resolve_flags(exact_exp=False) == 2 | FLAG_TEST_SORT_INT
+        assert resolve_flags() == 1 | FLAG_TEST_SORT_INT
+    assert resolve_flags() == 0
 
 
 def test_bench_refuses_more_ranks_than_gpus_with_a_message():

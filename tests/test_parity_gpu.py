@@ -972,15 +972,16 @@ def test_a_few_optimiser_steps_reduce_the_loss():
 def test_integer_flavour_of_the_tile_sort():
     """The tile sort compares keys as binary64 (v_min_f64 / v_max_f64) when every depth of a segment is a positive,
     normal, finite float, and as integers otherwise -- which real inputs only reach with NaN or non-positive depth
-    bits (such Gaussians are culled before).  bsr_set_option("sort_force_int", 1) sends every segment through the
-    integer flavour: the forward results of all three size classes must stay bit-exact."""
-    from bloomscene_amd import _capi
-    _capi.set_option("sort_force_int", 1)
-    try:
-        assert _capi.get_option("sort_force_int") == 1
-        for name in ("sh3", "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "c2_100k_800x800", "huge_splats"):
+    bits (such Gaussians are culled before).  The test-only flag BSR_FLAG_TEST_SORT_INT sends every segment of a call
+    through the integer flavour: the forward results of all size classes -- in both forms of the second binning pass --
+    must stay bit-exact."""
+    from bloomscene_amd import numerics
+    from bloomscene_amd.numerics import FLAG_TEST_SORT_INT, resolve_flags
+    with numerics(exact_exp=True, test_flags=FLAG_TEST_SORT_INT):
+        assert resolve_flags() & FLAG_TEST_SORT_INT
+        for name in ("sh3", "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "cluster_lists_mixed",
+                     "c2_100k_800x800", "huge_splats"):
             c = Hh.make_case(**CASES[name])
             st, _ = Hh.run_oracle(c, backward=False)
             _assert_forward_bit_exact(c, st)
-    finally:
-        _capi.set_option("sort_force_int", 0)
+    assert not resolve_flags() & FLAG_TEST_SORT_INT

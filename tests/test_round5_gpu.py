@@ -3,7 +3,7 @@
 * the forward's hand-over of its per-half box tests to the backward (the top byte of the sorted id list,
   csrc/render_fwd.hip -> render_bwd.hip): every (entry, 8 x 4 half) pair in which a pixel can blend has its bit set
   (checked per pixel in float64), and the backward produces the SAME BITS with the hand-over as without it (the test
-  hook "no_half_masks" makes every wave of the backward test the records again, as before round 5).
+  flag BSR_FLAG_TEST_NO_HALF_MASKS makes every wave of the backward test the records again, as before round 5).
 """
 import numpy as np
 import pytest
@@ -15,18 +15,15 @@ from test_parity_gpu import CASES, _dev, _native_forward, _raw_backward
 pytestmark = pytest.mark.gpu
 
 
-class _option:
-    def __init__(self, name, value):
-        self.name, self.value = name, value
-
-    def __enter__(self):
-        from bloomscene_amd import _capi
-        self.old = _capi.get_option(self.name)
-        _capi.set_option(self.name, self.value)
-
-    def __exit__(self, *exc):
-        from bloomscene_amd import _capi
-        _capi.set_option(self.name, self.old)
+def _option(name, value):
+    """The test-only per-call flags of the C ABI (include/bloomscene_rast.h BSR_FLAG_TEST_*; until round 6 process-wide
+    switches behind bsr_set_option), through the calling thread's numerics context: they change no result."""
+    from bloomscene_amd import numerics
+    from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS, FLAG_TEST_SMALL_GRIDS, FLAG_TEST_SORT_INT, resolve_flags
+    bit = {"no_half_masks": FLAG_TEST_NO_HALF_MASKS, "sort_small_grids": FLAG_TEST_SMALL_GRIDS,
+           "sort_force_int": FLAG_TEST_SORT_INT}[name]
+    cur = resolve_flags() & 0x700
+    return numerics(test_flags=(cur | bit) if value else (cur & ~bit))
 
 
 HANDOVER_CASES = ["sh3", "sh1_near_ragged", "precomp_color", "lists_gt_1024", "clustered_84k_list", "free_camera_sh3",

@@ -283,11 +283,10 @@ def main():
         # mode (BSR_FLAG_NO_READBACK: caller-sized scratch, no host wait), or both
         route = int(rng.integers(0, 4))
         cap = None if route in (0, 1) else int(st.num_rendered) + int(rng.integers(1, 5000))
-        _capi.set_option("no_half_masks", route in (1, 3))
-        try:
+        from bloomscene_amd import numerics
+        from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS
+        with numerics(test_flags=FLAG_TEST_NO_HALF_MASKS if route in (1, 3) else 0):
             out2 = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact, capacity=cap)
-        finally:
-            _capi.set_option("no_half_masks", 0)
         if cap is not None:
             from bloomscene_amd.rasterizer import check_deferred
             check_deferred()
