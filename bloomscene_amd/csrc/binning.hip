@@ -489,7 +489,12 @@ __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restri
 			const uint32_t first = s_tot[j * 16 + wave] + c[j];
 			tile_range[(j << 10) + tid] = make_uint2(first, first + tile_count[(j << 10) + tid]);   // (the count: an L2 hit)
 		}
-	if (__syncthreads_or(any_big)) {   // rare: the filing re-reads the counts
+	if (__syncthreads_or(any_big)) {   // the filing re-reads the counts
+		// list positions from LDS counters (this is the only workgroup): a returning GLOBAL atomic per wave, chunk and
+		// class was 8 us of this kernel's 12 on the dense leg, where most tiles are long
+		__shared__ int s_cls[3];
+		if (tid < 3) s_cls[tid] = 0;
+		__syncthreads();
 		for (int j = 0; j < chunks; j++) {
 			const int t = (j << 10) + tid;
 			const uint32_t cc = t < T ? tile_count[t] : 0u;
@@ -499,11 +504,13 @@ __global__ void __launch_bounds__(1024) k_tile_starts(int T, const int* __restri
 				const uint64_t b = wave_ballot(cls == c3);
 				if (b == 0ull) continue;
 				int base = 0;
-				if (lane == 0) base = atomicAdd(&flags[c3 == 0 ? 1 : 3 + c3], __popcll(b));
+				if (lane == 0) base = atomicAdd(&s_cls[c3], __popcll(b));   // LDS
 				base = __shfl(base, 0);
 				if (cls == c3) big_tiles[(size_t)c3 * T + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)t;
 			}
 		}
+		__syncthreads();
+		if (tid < 3) flags[tid == 0 ? 1 : 3 + tid] = s_cls[tid];   // (zero until now: k_scans / the re-run's memset)
 	}
 }
 
@@ -1375,7 +1382,8 @@ void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, ui
 // of the reference's instances on the synthetic scenes).
 // The debug builds libbsr_chain_only.so / libbsr_bucket_always.so (csrc/Makefile) pin plan 1 / 2-3 for the tests.
 #ifndef BSR_BUCKET_MAX_PER_TILE
-#define BSR_BUCKET_MAX_PER_TILE 700
+#define BSR_BUCKET_MAX_PER_TILE 850   // (A/B on one box, both forms forced: 512 x 512 with ~750 per tile +2.8 % of the step with
+                                      // the bucket form; the dense leg, 1200 per tile -- most tiles past their area -- -21 %)
 #endif
 #ifndef BSR_BKT_SMALL_PER_TILE
 #define BSR_BKT_SMALL_PER_TILE 400
