@@ -144,3 +144,117 @@ def test_product_library_picks_the_binning_form_by_size(name, bucket_form):
         assert bucket_order and (T <= 256 or not tile_order)
     else:
         assert tile_order
+
+
+# ------------------------------------------------------------------ the product's pure device functions, as compiled
+def _pure():
+    """tests/native/libbsr_pure_functions.so: box_may_hit, the element packing and pooled_tile compiled from the
+    product's own headers (csrc/common.h, tile_common.h) -- what the python restatements of test_box_test_cpu.py,
+    test_bin_elem_cpu.py and test_tile_pool_cpu.py are restatements OF."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "libbsr_pure_functions.so")
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    return C.CDLL(path)
+
+
+def _stream():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("ext,exty", [(15, 15), (7, 7), (7, 3)])
+def test_compiled_box_test_never_drops_a_pair_that_can_blend(ext, exty):
+    """box_may_hit as the kernels execute it (fp32, v_med3_f32 clamps) against float64: a (splat, box) pair it drops
+    reaches `power >= cut` at NO pixel centre of the box; it agrees with the float64 restatement of
+    test_box_test_cpu.py wherever that one is not within its slack of the cut; and it does drop a good share."""
+    import ctypes as C
+    import numpy as np
+    from test_box_test_cpu import _edges
+    L = _pure()
+    dev = _dev()
+    rng = np.random.default_rng(ext * 31 + exty)
+    n = 400_000
+    X, Y = rng.uniform(-40, 60, n), rng.uniform(-40, 60, n)
+    s1, s2, th = 10 ** rng.uniform(-0.5, 1.3, n), 10 ** rng.uniform(-0.5, 1.3, n), rng.uniform(0, np.pi, n)
+    ca, sa = np.cos(th), np.sin(th)
+    a = ca * ca / s1 ** 2 + sa * sa / s2 ** 2
+    c = sa * sa / s1 ** 2 + ca * ca / s2 ** 2
+    b = ca * sa * (1 / s1 ** 2 - 1 / s2 ** 2)
+    cut = -np.log(255.0 * rng.uniform(0.005, 1.0, n)) - 1e-3          # power_cut of k_preprocess
+    bx, by = rng.integers(0, 4, n) * 16.0, rng.integers(0, 4, n) * 16.0
+    f = [torch.from_numpy(v.astype(np.float32)).to(dev) for v in (X, Y, a, b, c, cut, bx, by)]
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    rc = L.pt_box_may_hit(ext, exty, n, *[C.c_void_p(t.data_ptr()) for t in f], C.c_void_p(out.data_ptr()), _stream())
+    torch.cuda.synchronize()
+    assert rc == 0
+    kept = out.cpu().numpy().astype(bool)
+    # the fp32 inputs, in float64
+    Xf, Yf, af, bf, cf, cutf, bxf, byf = [t.cpu().numpy().astype(np.float64) for t in f]
+    best = np.full(n, -np.inf)
+    for px in range(ext + 1):
+        for py in range(exty + 1):
+            dx, dy = Xf - (bxf + px), Yf - (byf + py)
+            best = np.maximum(best, -(0.5 * (af * dx * dx + cf * dy * dy) + bf * dx * dy))
+    assert not (~kept & (best >= cutf)).any()                          # never drops a pair some pixel can blend
+    pd = (af > 0) & (cf > 0) & (af * cf - bf * bf > 0)
+    _, _, qmin = _edges(Xf, Yf, af, bf, cf, bxf, byf, float(ext), float(exty))
+    slack = 1.0e-3 + 1.0e-4 * np.abs(cutf)
+    clear_miss = pd & (-qmin < cutf - 3 * slack)
+    clear_hit = ~pd | (-qmin > cutf + slack)
+    assert not kept[clear_miss].any() and kept[clear_hit].all()
+    assert 0.2 < (~kept).mean() < 0.98
+
+
+@pytest.mark.parametrize("compact", [0, 1])
+def test_compiled_element_packing_round_trips(compact):
+    """store_elem_m -> load_elem_m / elem_tile_m / elem_key_m on the device, both element forms: what a reader gets back
+    is what test_bin_elem_cpu.py restates (8-byte form: the tile's high byte, the id, the depth bits)."""
+    import ctypes as C
+    import numpy as np
+    L = _pure()
+    dev = _dev()
+    rng = np.random.default_rng(compact)
+    n = 100_000
+    tile = rng.integers(0, 1 << (16 if compact else 30), n, dtype=np.uint64)
+    gid = rng.integers(0, 1 << (24 if compact else 32), n, dtype=np.uint64)
+    depth = rng.integers(0, 1 << 32, n, dtype=np.uint64)
+    tile[:4] = [0, 65535, 255, 256]
+    gid[:4] = [0, (1 << 24) - 1, 1, (1 << 24) - 2]
+    ins = [torch.from_numpy(v.astype(np.uint32).view(np.int32)).to(dev) for v in (tile, gid, depth)]
+    scratch = torch.zeros(3 * n, dtype=torch.int32, device=dev)
+    o = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4)]
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    rc = L.pt_elem_roundtrip(n, compact, *[C.c_void_p(t.data_ptr()) for t in ins], C.c_void_p(scratch.data_ptr()),
+                             *[C.c_void_p(t.data_ptr()) for t in o], C.c_void_p(key.data_ptr()), _stream())
+    torch.cuda.synchronize()
+    assert rc == 0
+    o_tile, o_id, o_depth, o_tile_only = [t.cpu().numpy().view(np.uint32).astype(np.uint64) for t in o]
+    want_tile = (tile & 0xff00) if compact else tile
+    assert np.array_equal(o_tile, want_tile) and np.array_equal(o_tile_only, want_tile)
+    assert np.array_equal(o_id, gid) and np.array_equal(o_depth, depth)
+    assert np.array_equal(key.cpu().numpy().view(np.uint64), (depth << np.uint64(32)) | gid)
+
+
+@pytest.mark.parametrize("n_tiles", [1, 9, 1024, 2500, 4095, 4096, 8160, 8167, 65536])
+def test_compiled_pooled_tile_hands_out_every_tile_once(n_tiles):
+    """pooled_tile / pooled_grid as compiled: a launch of pooled_grid(n_tiles) workgroups renders every tile exactly
+    once, the grid and the pool size are the ones test_tile_pool_cpu.py restates, and the draw that empties the pool
+    leaves the counter at zero for the next launch (two launches on one counter)."""
+    import ctypes as C
+    import numpy as np
+    from test_tile_pool_cpu import _assignment
+    L = _pure()
+    dev = _dev()
+    _, grid_want, _, _, k_want = _assignment(n_tiles, 0)
+    grid = int(L.pt_pooled_grid(n_tiles))
+    assert grid == grid_want and int(L.pt_pool_tiles_per_band(n_tiles)) == k_want
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        got = torch.full((grid,), -7, dtype=torch.int32, device=dev)
+        assert L.pt_pooled_tiles(n_tiles, C.c_void_p(ctr.data_ptr()), C.c_void_p(got.data_ptr()), _stream()) == 0
+        torch.cuda.synchronize()
+        t = got.cpu().numpy()
+        assert (t >= -1).all()
+        assert sorted(t[t >= 0].tolist()) == list(range(n_tiles))
+        assert int(ctr.item()) == 0
