@@ -9,19 +9,29 @@ Headline metric (BASELINE.json): Msplats/s forward+backward @ 1 M Gaussians, 192
 One "step" = one `GaussianRasterizer` forward + `torch.autograd.backward` through the C ABI, inputs
 resident in HBM.  N > 1: view-parallel -- rank 0 broadcasts the Gaussian buffers over RCCL once
 (outside the timed region), every rank then renders its own camera view; no data-path collective
-(weak scaling).  Rank 0 prints ONE JSON line with the bench contract keys plus
+(weak scaling).
 
+Rank 0 prints ONE compact JSON line (< 4 KB, the LAST line of stdout: what the driver parses) with the bench contract
+keys plus
+
+  "config":       the workload in words and numbers, the hash of the kernel sources, the mode flags, median / first /
+                  max step time and the host's slowest step
   "roofline":     dominant kernel, ALGORITHMIC bytes per launch / mean launch time (hipEvents recorded by the
                   library on the launch stream during the timed region) vs 8 TB/s; "traffic" = HBM bytes per
-                  launch from the committed rocprofv3 --pmc passes, only when those passes were taken on the
-                  same kernel sources as the library being timed ("traffic_source"), else null
+                  launch from the committed rocprofv3 --pmc passes ("traffic_profile"), only when those passes were
+                  taken on the same kernel sources as the library being timed, else null
+  "roofline_step", "stage_ms": the whole step against 8 TB/s; mean time of every stage (untimed pass, all stages bracketed)
   "cpu_baseline": the CPU oracle (a port of the reference algorithm, OpenMP) on the same workload, N = 1 only
-  "c4":           BASELINE config C4 -- the 64-view rotate360 sweep of scene B (1 M Gaussians, forward only),
-                  STRONG-scaled over the N ranks after one packed RCCL broadcast: Msplats/s = 64 P / t with and
-                  without the broadcast, one view per native call (the reference's loop) and 16 per call
-  "secondary":    N = 1 only, never the headline: a dense scene A (long tile lists), BloomScene's real call shape
-                  (512^2, anchors x 10 through the fused expansion, colors_precomp, sh_degree 1) and the headline
-                  workload with the camera changing every step (the scratch-size guess of the forward misses).
+  "c4":           summary of BASELINE config C4 -- the 64-view rotate360 sweep of scene B (1 M Gaussians, forward
+                  only), STRONG-scaled over the N ranks: sweep time with the Gaussians resident, and cold (one packed
+                  RCCL broadcast first); the visible-subset distribution beside it
+  "secondary_Msplats_per_s": N = 1 only, never the headline: a dense scene A (long tile lists), the camera changing
+                  every step, BloomScene's real call shape (512^2, anchors x 10 through the fused expansion,
+                  colors_precomp, sh_degree 1), and the headline workload in the two bit-for-bit modes
+                  (strict gradients, exact exp)
+  "detail":       path of the DETAIL record (JSON) holding everything else: per-step arrays, the whole C4 record, every
+                  secondary leg with its stage table.  --full adds the long legs (180 / 720-view presets, capacity-mode
+                  and HIP-graph legs) and echoes the detail record on stderr; --experimental adds the C4 latency model.
 """
 from __future__ import annotations
 
