@@ -493,7 +493,8 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			const uint32_t* digit_total1 = geom.hist1 + (size_t)256 * (((size_t)n_wg + 7) / 8 * 8);
 			launch_sort_tiles(plan, T, (int)capacity, n_ptr, (int)capacity, img.tile_range, img.big_tiles, img.flags,
 			                  digit_total1, elems_sorted, elems_free, bin.point_list, elems_compact,
-			                  (flags & BSR_FLAG_TEST_SORT_INT) != 0, (flags & BSR_FLAG_TEST_SMALL_GRIDS) != 0, s);
+			                  ((flags & BSR_FLAG_TEST_SORT_INT) ? 1 : 0) | ((flags & BSR_FLAG_TEST_SORT_NETWORK) ? 2 : 0),
+			                  (flags & BSR_FLAG_TEST_SMALL_GRIDS) != 0, s);
 		}
 		STAGE_CHECK("sort_tiles", debug, s);
 		{

@@ -931,6 +931,183 @@ __device__ __forceinline__ void merge_loaded_runs(uint64_t* keys, int n2, uint32
 	for (int i = t; i < n; i += NT) point_list[start + i] = (uint32_t)keys[swz_m<M>(i)];
 }
 
+// ---- bucket-and-rank sort of one segment (round 6; the network above stays as the fall-back) -----------------------
+// A segment's keys are (depth bits, id), and the depth bits of the splats over one tile spread over their range: instead
+// of n log^2 n compare-exchanges the keys are dealt into NB = 2^NBLOG buckets by a MONOTONE map of the depth
+// (common.h: rank_sort_bucket),
+//     b = min(int((z - z_min) * (NB - 0.5) / (z_max - z_min)), NB - 1),
+// (histogram with LDS atomics, one scan, one scatter: the keys then lie bucket by bucket, in arrival order inside a
+// bucket), and a key's final place is its bucket's first position + the number of smaller keys in its bucket, counted
+// against the bucket's members (keys are unique within a tile: ids are).  A key goes through LDS once (8-byte write,
+// 8-byte read) plus ~2 reads per fellow member; the ids are written to point_list straight from the count.  The result is
+// THE ascending order of the keys -- the same bits as the network's -- for every input; what depends on the input is
+// only the price: a segment with a bucket of more than BSR_RANK_CAP keys (depths piled on one value), or with a depth
+// word that is not a positive finite float (the reference orders those by raw bits too), is left untouched and the
+// caller sorts it with the network.  Counters are 16 bits wide, two per dword (counts and offsets <= 4096): the
+// low one cannot carry into the high one.
+//   NT threads (t = index) share the segment; thread t holds keys i = t + NT q, q < KPT, in registers (valid: i < n) --
+//   `out` (n slots of LDS) may therefore be the very area the keys were read from; cnt: NB / 2 dwords of LDS;
+//   s_red (BLOCK only): 3 * NT / 64 dwords.  Ends without a sync: the caller syncs before `out` / `cnt` are reused.
+#ifndef BSR_RANK_CAP
+#define BSR_RANK_CAP 32
+#endif
+// maximum over the 64 lanes on the vector ALU (the steps of wave_inclusive_sum_dpp with max for +: lanes without a source
+// take 0, the identity of an unsigned max; lane 63 ends with the total).  (Six __shfl_xor steps are six dependent
+// ds_bpermute round trips: ~700 cycles per reduction, three reductions per sorted segment.)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+	x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+	return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+template <int NT, int KPT, int NBLOG, bool BLOCK>
+__device__ __forceinline__ bool rank_sort(const uint64_t (&e)[KPT], int n, int t, uint64_t* out, uint32_t* cnt,
+                                          uint32_t* s_red, uint32_t start, uint32_t* __restrict__ point_list)
+{
+	constexpr int NB = 1 << NBLOG, NDW = NB / 2, DPT = NDW / NT, NWV = NT / 64;
+	static_assert(NDW % NT == 0 && DPT >= 1 && DPT <= 8, "the scan takes up to 8 counter dwords per thread");
+	static_assert(KPT % 4 == 0, "the read-out takes four keys per thread and trip");
+	const int lane = t & 63, wave = t >> 6;
+	// ---- the range of the depth words
+	uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+	for (int q = 0; q < KPT; q++)
+		if (t + NT * q < n) {
+			const uint32_t h = (uint32_t)(e[q] >> 32);
+			lo = min(lo, h);
+			hi = max(hi, h);
+		}
+	lo = ~wave_max_u32(~lo);
+	hi = wave_max_u32(hi);
+	if (BLOCK) {
+		if (lane == 0) {
+			s_red[wave] = lo;
+			s_red[NWV + wave] = hi;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int w = 0; w < NWV; w++) {
+			lo = min(lo, s_red[w]);
+			hi = max(hi, s_red[NWV + w]);
+		}
+	}
+	if (lo == 0u || hi >= 0x7f800000u) return false;   // (uniform) not all positive finite floats: the network's integer flavour
+	const float zlo = __uint_as_float(lo), scale = rank_sort_scale(zlo, __uint_as_float(hi), NB);
+	// ---- histogram; the returning atomic also tells a key how many keys were in its bucket before it -- its place in the
+	// bucket's run (one byte each: a count past 255 wraps, and such a segment is declined below)
+#pragma unroll
+	for (int w = 0; w < DPT; w++) cnt[t * DPT + w] = 0u;
+	round_sync<BLOCK>();
+	uint32_t arrival[KPT / 4];
+#pragma unroll
+	for (int q = 0; q < KPT / 4; q++) arrival[q] = 0u;
+#pragma unroll
+	for (int q = 0; q < KPT; q++)
+		if (t + NT * q < n) {
+			const uint32_t b = rank_sort_bucket(__uint_as_float((uint32_t)(e[q] >> 32)), zlo, scale, NB), sh = (b & 1u) << 4;
+			const uint32_t before = (atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xffu;   // LDS
+			arrival[q >> 2] |= before << ((q & 3) << 3);
+		}
+	round_sync<BLOCK>();
+	// ---- exclusive scan of the NB counts: thread t owns buckets 2 DPT t .. 2 DPT (t + 1) - 1
+	uint32_t c[2 * DPT], total = 0u, cmax = 0u;
+#pragma unroll
+	for (int w = 0; w < DPT; w++) {
+		const uint32_t v = cnt[t * DPT + w];
+		c[2 * w] = v & 0xffffu;
+		c[2 * w + 1] = v >> 16;
+		total += c[2 * w] + c[2 * w + 1];
+		cmax = max(cmax, max(c[2 * w], c[2 * w + 1]));
+	}
+	const uint32_t incl = wave_inclusive_sum_dpp(total);
+	cmax = wave_max_u32(cmax);
+	uint32_t run = incl - total;
+	if (BLOCK) {
+		if (lane == 63) s_red[2 * NWV + wave] = incl;
+		__syncthreads();   // (also: every thread has read lo / hi above)
+		if (lane == 0) s_red[wave] = cmax;
+		for (int w = 0; w < wave; w++) run += s_red[2 * NWV + w];
+		__syncthreads();
+#pragma unroll
+		for (int w = 0; w < NWV; w++) cmax = max(cmax, s_red[w]);
+	}
+	if (cmax > (uint32_t)BSR_RANK_CAP) return false;   // (uniform over the NT threads; nothing but cnt was written)
+#pragma unroll
+	for (int w = 0; w < DPT; w++) {
+		const uint32_t o0 = run, o1 = run + c[2 * w];
+		run = o1 + c[2 * w + 1];
+		cnt[t * DPT + w] = o0 | (o1 << 16);
+	}
+	round_sync<BLOCK>();
+	// ---- scatter: the keys bucket by bucket (every thread holds its keys in registers: `out` may be their old place)
+	const uint16_t* const first = reinterpret_cast<const uint16_t*>(cnt);   // first position of every bucket
+#pragma unroll
+	for (int q = 0; q < KPT; q++)
+		if (t + NT * q < n) {
+			const uint32_t b = rank_sort_bucket(__uint_as_float((uint32_t)(e[q] >> 32)), zlo, scale, NB);
+			out[(uint32_t)first[b] + ((arrival[q >> 2] >> ((q & 3) << 3)) & 0xffu)] = e[q];
+		}
+	round_sync<BLOCK>();
+	// ---- a key's place = first position of its bucket + the number of smaller keys in the bucket
+	constexpr int CHQ = 4;   // keys per thread and trip (all KPT at once: 5 KPT live registers)
+#pragma unroll 1
+	for (int q0 = 0; q0 < KPT && NT * q0 < n; q0 += CHQ) {
+		uint64_t k[CHQ];
+		uint32_t beg[CHQ], len[CHQ], rank[CHQ];
+#pragma unroll
+		for (int q = 0; q < CHQ; q++) {
+			const int p = t + NT * (q0 + q);
+			k[q] = 0ull;
+			beg[q] = len[q] = rank[q] = 0u;
+			if (p < n) {
+				k[q] = out[p];
+				const uint32_t b = rank_sort_bucket(__uint_as_float((uint32_t)(k[q] >> 32)), zlo, scale, NB);
+				beg[q] = (uint32_t)first[b];
+				const uint32_t end = b + 1u < (uint32_t)NB ? (uint32_t)first[b + 1u] : (uint32_t)n;
+				len[q] = min(end - beg[q], (uint32_t)BSR_RANK_CAP);   // (<= the cap by the vote above: the clamp only bounds the
+				                                                      // loop below whatever LDS holds)
+			}
+		}
+		// JU members per key and trip: 4 JU independent LDS reads in flight (one member per trip left the loop at one
+		// LDS round trip per member of the fullest bucket); the wave stops when its longest bucket is through
+		uint32_t longest = max(max(len[0], len[1]), max(len[2], len[3]));
+#ifndef BSR_RANK_JU_BLOCK
+#define BSR_RANK_JU_BLOCK 2
+#endif
+		constexpr int JU = BLOCK ? BSR_RANK_JU_BLOCK : 4;   // (the workgroup-owned flavour runs in k_sort_tiles_wide's 80 VGPRs)
+		for (uint32_t j0 = 0; wave_ballot(j0 < longest) != 0ull; j0 += JU) {
+			uint64_t mem[CHQ][JU];
+#pragma unroll
+			for (int q = 0; q < CHQ; q++)
+#pragma unroll
+				for (int u = 0; u < JU; u++) mem[q][u] = out[min(beg[q] + j0 + u, (uint32_t)(n - 1))];   // (unconditional reads)
+#pragma unroll
+			for (int q = 0; q < CHQ; q++)
+#pragma unroll
+				for (int u = 0; u < JU; u++) rank[q] += (j0 + u < len[q] && mem[q][u] < k[q]) ? 1u : 0u;
+		}
+#pragma unroll
+		for (int q = 0; q < CHQ; q++)
+			if (t + NT * (q0 + q) < n) point_list[start + beg[q] + rank[q]] = (uint32_t)k[q];
+	}
+	return true;
+}
+
+// the same with the keys read from global memory (thread t: positions start + t + NT q, coalesced)
+template <int NT, int KPT, int NBLOG, bool BLOCK, typename Src>
+__device__ __forceinline__ bool rank_sort_from(const Src src, int n, int t, uint64_t* out, uint32_t* cnt, uint32_t* s_red,
+                                               uint32_t start, uint32_t* __restrict__ point_list)
+{
+	uint64_t e[KPT];
+#pragma unroll
+	for (int q = 0; q < KPT; q++) e[q] = t + NT * q < n ? src((size_t)start + (size_t)(t + NT * q)) : 0ull;
+	return rank_sort<NT, KPT, NBLOG, BLOCK>(e, n, t, out, cnt, s_red, start, point_list);
+}
+
 // Wave-owned segment: load, pick the compare-exchange flavour, sort.  No workgroup barrier anywhere.
 template <int M>
 __device__ __forceinline__ void sort_segment_wave(uint64_t* keys, int n2, uint32_t start, int n, int lane,
@@ -990,10 +1167,11 @@ __global__ void __launch_bounds__(256) k_sort_tiles_tiny(int T, const int* __res
 __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __restrict__ n_ptr, int capacity,
                                                           const uint2* __restrict__ tile_range,
                                                           const BinElem* __restrict__ elems,
-                                                          uint32_t* __restrict__ point_list, int force_int, int min_n,
+                                                          uint32_t* __restrict__ point_list, int sort_mode, int min_n,
                                                           int compact)
 {
 	__shared__ uint64_t s_keys[4][BSR_SORT_SMALL];
+	__shared__ uint32_t s_rank[4][512];   // rank_sort's counters: up to 1024 buckets per wave
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * 4 + wave;
 	if (tile >= T || *n_ptr > capacity) return;   // (more instances than the scratch was sized for: stage is re-run)
@@ -1001,9 +1179,18 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 	const uint32_t start = range.x;
 	const int n = (int)(range.y - range.x);
 	if (n > BSR_SORT_SMALL || n <= min_n) return;   // on the big-tile list / sorted by k_sort_tiles_tiny (min_n = 64) or empty
+	// bucket-and-rank sort first (sort_mode 0); a segment it declines -- depths piled on one value -- goes to the network
+	if (sort_mode == 0 && n > 64) {
+		if (n <= 512) {
+			if (rank_sort_from<64, 8, 9, false>(ElemKeys{elems, compact}, n, lane, s_keys[wave], s_rank[wave], nullptr, start, point_list)) return;
+		} else {
+			if (rank_sort_from<64, 16, 10, false>(ElemKeys{elems, compact}, n, lane, s_keys[wave], s_rank[wave], nullptr, start, point_list)) return;
+		}
+		round_sync<false>();
+	}
 	int n2 = 8;
 	while (n2 < n) n2 <<= 1;
-	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, force_int != 0, compact);   // (> 512 keys: two runs per lane)
+	sort_segment_wave<3>(s_keys[wave], n2, start, n, lane, elems, point_list, (sort_mode & 1) != 0, compact);   // (> 512 keys: two runs per lane)
 }
 
 // One long segment, 1024 < n <= BSR_SORT_CHUNK keys, sorted in `s_keys` (BSR_SORT_CHUNK slots) by the NT threads of
@@ -1011,12 +1198,21 @@ __global__ void __launch_bounds__(256) k_sort_tiles_small(int T, const int* __re
 // loads the next segment).
 #define BSR_SORT_CHUNK 4096
 template <int NT, typename Src>
-__device__ __forceinline__ void sort_long_tile_lds(uint64_t* s_keys, uint32_t start, int n, int tid, const Src src,
-                                                   uint32_t* __restrict__ point_list, bool force_int)
+__device__ __forceinline__ void sort_long_tile_lds(uint64_t* s_keys, uint32_t* s_rank, uint32_t start, int n, int tid,
+                                                   const Src src, uint32_t* __restrict__ point_list, int sort_mode)
 {
+	// bucket-and-rank sort first (sort_mode 0: 8 keys per thread = up to 8 NT keys, 4 NT buckets: s_rank holds 2 NT counter
+	// dwords + the reduction words); declined segments go to the network
+	if (sort_mode == 0) {
+		constexpr int NBLOG = NT == 512 ? 11 : 10;
+		static_assert(NT == 512 || NT == 256, "4096- or 2048-key segments");
+		const bool done = rank_sort_from<NT, 8, NBLOG, true>(src, n, tid, s_keys, s_rank, s_rank + 2 * NT, start, point_list);
+		__syncthreads();
+		if (done) return;
+	}
 	int n2 = 1024;
 	while (n2 < n) n2 <<= 1;
-	sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, src, point_list, force_int);
+	sort_segment_block<NT, 3>(s_keys, n2, start, n, tid, src, point_list, (sort_mode & 1) != 0);
 	__syncthreads();
 }
 // One segment of n > BSR_SORT_CHUNK keys, hybrid: every 4096-key chunk sorted in LDS into the global scratch k[0 .. n)
@@ -1070,15 +1266,88 @@ __device__ __forceinline__ void sort_long_tile_hybrid(uint64_t* s_keys, uint64_t
 #define BSR_SORT_NT 512
 // (64 VGPRs: with 33 KB of LDS a CU holds four workgroups = 8 waves per SIMD; the hybrid path alone would take 70 and
 // cost the common (1024, 4096] class its fourth workgroup: C5's tile sort 0.184 -> 0.206 ms)
-__global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) k_sort_tiles_wide(int T, int g1, const int* __restrict__ n_ptr, int capacity,
+#ifndef BSR_WIDE_WAVES
+#define BSR_WIDE_WAVES 6
+#endif
+// The lower half of the first wide class, (1024, 2048] keys, in a launch of its own (round 6): 256 threads, 16 KB of keys +
+// 2 KB of counters.  A segment's sort is short (~3 us); what a workgroup of k_sort_tiles_wide spends per segment is
+// mostly the chain of dependent loads ahead of it (list entry -> range -> keys) and the drain of its stores behind it.
+// Here the workgroups are few enough to be resident all at once and stride over the work list (big_tiles[0..flags[1]))
+// with the loads of the NEXT segments in flight under the sort of the current one: the range two entries ahead, the keys
+// (8 per thread, in registers) one entry ahead.  k_sort_tiles_wide skips what is sorted here.
+#define BSR_SORT_MID 2048
+#ifndef BSR_SORT_MID_WGS
+#define BSR_SORT_MID_WGS 1280   // five workgroups per CU
+#endif
+#ifndef BSR_MID_NBLOG
+#define BSR_MID_NBLOG 11   // 2048 buckets for up to 2048 keys (1024: +2 us on the dense leg)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) k_sort_tiles_mid(int g1, const int* __restrict__ n_ptr, int capacity,
+                                                                 const uint2* __restrict__ tile_range,
+                                                                 const uint32_t* __restrict__ big_tiles,
+                                                                 const int* __restrict__ flags,
+                                                                 const BinElem* __restrict__ elems,
+                                                                 uint32_t* __restrict__ point_list, int sort_mode, int compact)
+{
+	__shared__ uint64_t s_keys[BSR_SORT_MID];
+	__shared__ uint32_t s_rank[(1 << BSR_MID_NBLOG) / 2 + 16];   // rank_sort's counters + its reduction words
+	const int tid = threadIdx.x;
+	if (*n_ptr > capacity) return;
+	const ElemKeys src{elems, compact};
+	const int count = flags[1];
+	// the segment of list entry b if it belongs to this class, else an empty one
+	auto segment = [&](int b) {
+		if (b >= count) return make_uint2(0u, 0u);
+		const uint2 r = tile_range[big_tiles[b]];
+		const int n = (int)(r.y - r.x);
+		return (n > BSR_SORT_SMALL && n <= BSR_SORT_MID) ? r : make_uint2(0u, 0u);
+	};
+	auto load_keys = [&](const uint2 r, uint64_t (&e)[8]) {
+		const int n = (int)(r.y - r.x);
+#pragma unroll
+		for (int q = 0; q < 8; q++) e[q] = tid + 256 * q < n ? src((size_t)r.x + (size_t)(tid + 256 * q)) : 0ull;
+	};
+	uint2 cur = segment((int)blockIdx.x), nxt = segment((int)blockIdx.x + g1);
+	uint64_t e[8];
+	load_keys(cur, e);
+	for (int b = blockIdx.x; b < count; b += g1) {
+		const uint2 nxt2 = segment(b + 2 * g1);
+		uint64_t en[8];
+		load_keys(nxt, en);
+		const int n = (int)(cur.y - cur.x);
+		if (n > 0) {   // (uniform over the workgroup)
+			bool done = false;
+			if (sort_mode == 0) {   // bucket-and-rank sort; a declined segment goes through the network (which loads it again)
+				done = rank_sort<256, 8, BSR_MID_NBLOG, true>(e, n, tid, s_keys, s_rank, s_rank + (1 << BSR_MID_NBLOG) / 2, cur.x, point_list);
+				__syncthreads();
+#ifdef BSR_MID_TWICE   // (cost attribution: the sort a second time, same keys, same result)
+				done = rank_sort<256, 8, BSR_MID_NBLOG, true>(e, n, tid, s_keys, s_rank, s_rank + (1 << BSR_MID_NBLOG) / 2, cur.x, point_list);
+				__syncthreads();
+#endif
+			}
+			if (!done) {
+				sort_segment_block<256, 3>(s_keys, BSR_SORT_MID, cur.x, n, tid, src, point_list, (sort_mode & 1) != 0);
+				__syncthreads();
+			}
+		}
+		cur = nxt;
+		nxt = nxt2;
+#pragma unroll
+		for (int q = 0; q < 8; q++) e[q] = en[q];
+	}
+}
+
+__global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_eu(BSR_WIDE_WAVES, 8))) k_sort_tiles_wide(int T, int g1, const int* __restrict__ n_ptr, int capacity,
                                                                  const uint2* __restrict__ tile_range,
                                                                  const uint32_t* __restrict__ big_tiles,
                                                                  const int* __restrict__ flags,
                                                                  const BinElem* __restrict__ elems, uint64_t* keys,
-                                                                 uint32_t* __restrict__ point_list, int force_int, int compact)
+                                                                 uint32_t* __restrict__ point_list, int sort_mode, int compact,
+                                                                 int lds_min)   // segments of up to lds_min keys: another kernel's
 {
 	constexpr int NT = BSR_SORT_NT, CH = BSR_SORT_CHUNK;
 	__shared__ uint64_t s_keys[CH];
+	__shared__ uint32_t s_rank[1024 + 32];   // rank_sort's counters (2048 buckets) + its reduction words
 	const int tid = threadIdx.x;
 	if (*n_ptr > capacity) return;
 	const ElemKeys src{elems, compact};
@@ -1089,8 +1358,8 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 			const uint2 range = tile_range[tile];
 			const uint32_t start = range.x;
 			const int n = (int)(range.y - range.x);
-			if (n <= BSR_SORT_SMALL || n > CH) continue;   // another class (uniform over the workgroup)
-			sort_long_tile_lds<NT>(s_keys, start, n, tid, src, point_list, force_int != 0);
+			if (n <= lds_min || n > CH) continue;   // another class (uniform over the workgroup)
+			sort_long_tile_lds<NT>(s_keys, s_rank, start, n, tid, src, point_list, sort_mode);
 		}
 		return;
 	}
@@ -1132,8 +1401,9 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
                                                             const uint32_t* __restrict__ digit_total1,
                                                             const BinElem* __restrict__ elems, uint2* __restrict__ tile_range,
                                                             uint64_t* big_keys, uint32_t* __restrict__ point_list,
-                                                            int force_int)
+                                                            int sort_mode)
 {
+	const int force_int = sort_mode & 1;
 	constexpr int NT = BSR_BKT_NT, NW = BSR_BKT_NW, NA = NW * TPW;
 	// TPW = 2: a wave sorts its two tiles side by side, one per 32-lane half, 16 keys per lane and round (slots swz_m<4>);
 	// TPW = 1: one tile per wave, 8 keys per lane and round (slots swz_m<3>)
@@ -1146,6 +1416,8 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	__shared__ uint32_t s_scan[NW];
 	__shared__ uint32_t s_base[2];
 	__shared__ uint32_t s_cur[NA];                  // second pass: fill counters of this part's long tiles
+	__shared__ uint32_t s_rank[NW][256];            // rank_sort's counters: 512 buckets per wave (the long-tile routine: all of it)
+	static_assert(NW * 256 >= 1024 + 32, "sort_long_tile_lds takes 2048 buckets + its reduction words");
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int k = 1 << k_log2;                      // 1, 2 or 4
 	// parts of one bucket are neighbours on one XCD: workgroups b, b + 8, b + 16, ... share an XCD
@@ -1255,6 +1527,22 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		if (nA > AREA) nA = 0;   // (long: sorted further down)
 		if (nB > AREA) nB = 0;
 		const uint32_t startA = tile_first(LA < m ? LA : 0), startB = tile_first(LB < m ? LB : 0);
+		// bucket-and-rank sort, one tile after the other with all 64 lanes (sort_mode 0); a tile it declines stays as it
+		// is and goes through the network below
+		if (sort_mode == 0) {
+			auto by_ranks = [&](int L, int& n, uint32_t start) {
+				if (n <= 64) return;
+				uint64_t* const keys = s_keys + L * AREA;
+				uint64_t e[AREA / 64];
+#pragma unroll
+				for (int q = 0; q < AREA / 64; q++) e[q] = lane + 64 * q < n ? keys[swz_m<SM>(lane + 64 * q)] : 0ull;
+				round_sync<false>();
+				if (rank_sort<64, AREA / 64, 9, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list)) n = 0;
+				round_sync<false>();
+			};
+			by_ranks(LA, nA, startA);
+			by_ranks(LB, nB, startB);
+		}
 		if (nA <= 64 && nB <= 64) {
 			if (nA > 0) sort_by_ranks(s_keys + LA * AREA, nA, startA);
 			if (nB > 0) sort_by_ranks(s_keys + LB * AREA, nB, startB);
@@ -1295,6 +1583,15 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		if (n > 0 && n <= 64) {
 			sort_by_ranks(keys, n, start);
 		} else if (n > 64 && n <= AREA) {
+			if (sort_mode == 0) {   // bucket-and-rank sort; a tile it declines goes through the network
+				uint64_t e[AREA / 64];
+#pragma unroll
+				for (int q = 0; q < AREA / 64; q++) e[q] = lane + 64 * q < n ? keys[swz_m<SM>(lane + 64 * q)] : 0ull;
+				round_sync<false>();
+				const bool done = rank_sort<64, AREA / 64, 9, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list);
+				round_sync<false>();
+				if (done) continue;
+			}
 			int n2 = 128;
 			while (n2 < n) n2 <<= 1;
 			// pads, then runs of 8 sorted in registers, in place: a lane reads and writes the same eight slots
@@ -1354,7 +1651,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		if (n <= AREA) continue;   // (uniform)
 		const uint32_t start = tile_first(L);
 		if (n <= BSR_SORT_CHUNK)
-			sort_long_tile_lds<NT>(s_keys, start, n, tid, raw, point_list, force_int != 0);
+			sort_long_tile_lds<NT>(s_keys, &s_rank[0][0], start, n, tid, raw, point_list, sort_mode);
 		else
 			sort_long_tile_hybrid<NT>(s_keys, big_keys + start, start, n, tid, raw, point_list);
 	}
@@ -1475,7 +1772,8 @@ void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capac
                        BinElem* elems_free, uint32_t* point_list, int compact, int force_int, int small_grids_flag,
                        hipStream_t s)
 {
-	// force_int / small_grids_flag: BSR_FLAG_TEST_SORT_INT / BSR_FLAG_TEST_SMALL_GRIDS of the call (test-only, no result
+	// force_int = the call's sort mode: bit 0 BSR_FLAG_TEST_SORT_INT, bit 1 BSR_FLAG_TEST_SORT_NETWORK (0: bucket-and-rank
+	// sort first, the network for the segments it declines); small_grids_flag: BSR_FLAG_TEST_SMALL_GRIDS (test-only, no result
 	// changes): every segment through the integer compare-exchange flavour, which real inputs reach only with NaN /
 	// non-positive depth bits; the wide classes on grids of 2 / 1 workgroups
 	if (plan >= 2) {
@@ -1511,9 +1809,21 @@ void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capac
 	const bool small_grids = small_grids_flag != 0;
 	const int g1 = min(min(T, n_bound / (BSR_SORT_SMALL + 1)), small_grids ? 2 : 2560),
 	          gw = min(min(T, n_bound / (BSR_SORT_CHUNK + 1)), small_grids ? 1 : 512);
-	if (g1 + gw > 0)
-		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1 + gw), dim3(BSR_SORT_NT), 0, s, T, g1, n_ptr, capacity, tile_range,
-		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int, compact);
+	// (1024, 2048] in a launch of its own where the frame can hold a fair number of such tiles (a dense frame); a frame
+	// of short lists pays no second near-empty launch.  The first wide class then starts at 2049 keys: at most
+	// n / 2049 such tiles, and its near-empty launch is kept small (2560 workgroups of 512 that find nothing: 10 us).
+	const bool mid = g1 >= 64 || small_grids;
+	int g1w = g1;
+	if (mid) {
+		const int gm = small_grids ? 2 : min(g1, BSR_SORT_MID_WGS);
+		hipLaunchKernelGGL(k_sort_tiles_mid, dim3(gm), dim3(256), 0, s, gm, n_ptr, capacity, tile_range, big_tiles, flags, elems,
+		                   point_list, force_int, compact);
+		g1w = min(min(T, n_bound / (BSR_SORT_MID + 1)), small_grids ? 2 : 640);
+	}
+	if (g1w + gw > 0)
+		hipLaunchKernelGGL(k_sort_tiles_wide, dim3(g1w + gw), dim3(BSR_SORT_NT), 0, s, T, g1w, n_ptr, capacity, tile_range,
+		                   big_tiles, flags, elems, reinterpret_cast<uint64_t*>(elems_free), point_list, force_int, compact,
+		                   mid ? BSR_SORT_MID : BSR_SORT_SMALL);
 }
 
 }  // namespace bsr

@@ -251,6 +251,24 @@ __device__ __forceinline__ uint32_t kept_count(uint32_t area, uint64_t mask)
 	return area > 64u ? area : (uint32_t)__popcll(mask);
 }
 
+// The bucket map of the per-tile bucket-and-rank sort (binning.hip: rank_sort): the depth word read as the float it is,
+//     b = min(int((z - z_min) * scale), nb - 1),   scale = (nb - 0.5) / (z_max - z_min)   (0 when all depths are equal or the quotient overflows).
+// Monotone in z whatever the roundings (a - c, x * s with s >= 0 and float -> int are all non-decreasing), and for
+// positive finite floats z is monotone in the depth WORD: buckets in ascending order hold ascending keys.  Linear in
+// the depth itself: a shift of the raw bits would be logarithmic, 8x denser at the far end of a 1 .. 10 range than at
+// the near end.  Segments holding other depth patterns are not offered to this sort.
+// (Host-callable: tests/native/pure_functions.hip checks both against tests/test_rank_sort_cpu.py.)
+__host__ __device__ __forceinline__ float rank_sort_scale(float zmin, float zmax, int nb)
+{
+	const float s = zmax > zmin ? ((float)nb - 0.5f) / (zmax - zmin) : 0.0f;
+	return s < 3.0e38f ? s : 0.0f;   // (a range of a few denormals: the quotient overflows -- one bucket, i.e. declined or trivial)
+}
+__host__ __device__ __forceinline__ uint32_t rank_sort_bucket(float z, float zmin, float scale, int nb)
+{
+	const uint32_t b = (uint32_t)((z - zmin) * scale);
+	return b < (uint32_t)nb ? b : (uint32_t)(nb - 1);
+}
+
 // Column of preprocess workgroup `wg` in the digit-major pass-1 histogram: workgroups that run on the
 // same XCD (wg, wg + 8, wg + 16, ...) are neighbours, so the 4-byte entries they write into one 64-byte
 // sector merge in that XCD's L2.  (Any fixed order works: it only decides in which order the workgroups'

@@ -16,6 +16,8 @@ FLAG_EXACT_GRAD = 2   # BSR_FLAG_EXACT_GRAD: the reference's per-pair operations
 FLAG_TEST_SORT_INT = 0x100
 FLAG_TEST_SMALL_GRIDS = 0x200
 FLAG_TEST_NO_HALF_MASKS = 0x400
+FLAG_TEST_SORT_NETWORK = 0x800
+FLAG_TEST_MASK = 0xf00
 
 _tls = threading.local()
 
@@ -47,7 +49,7 @@ class numerics:
         self._saved = _current()
         f = resolve_flags(*self._args)
         if self._test_flags is not None:
-            f = (f & ~0x700) | (int(self._test_flags) & 0x700)
+            f = (f & ~FLAG_TEST_MASK) | (int(self._test_flags) & FLAG_TEST_MASK)
         _tls.flags = f
         return self
 

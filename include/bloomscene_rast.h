@@ -79,6 +79,9 @@ extern "C" {
  * process-wide switches behind bsr_set_option; the library now keeps no switch between calls at all).
  *   BSR_FLAG_TEST_SORT_INT       every per-tile sort takes the integer compare-exchange flavour, which real inputs
  *                                reach only with NaN / non-positive depth bits (same order either way),
+ *   BSR_FLAG_TEST_SORT_NETWORK   every per-tile sort of more than 64 keys runs the compare-exchange network; by default
+ *                                a segment is first offered to the bucket-and-rank sort, which declines segments whose
+ *                                depths pile up on one value (same order either way; implied by _SORT_INT),
  *   BSR_FLAG_TEST_SMALL_GRIDS    the grids of the wide per-tile sort classes are capped at 2 / 1 workgroups (product:
  *                                2560 / 512), so that a frame with a handful of long tiles exercises the loops in which
  *                                one workgroup sorts several tiles in turn (same order either way),
@@ -90,7 +93,8 @@ extern "C" {
 #define BSR_FLAG_TEST_SORT_INT      0x100u
 #define BSR_FLAG_TEST_SMALL_GRIDS   0x200u
 #define BSR_FLAG_TEST_NO_HALF_MASKS 0x400u
-#define BSR_FLAG_TEST_MASK          0x700u
+#define BSR_FLAG_TEST_SORT_NETWORK  0x800u
+#define BSR_FLAG_TEST_MASK          0xf00u
 
 /* Resize callback for an opaque scratch buffer: must return a device pointer to at least
  * `bytes` bytes (256-byte aligned) that stays valid until the matching backward call.

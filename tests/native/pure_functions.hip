@@ -68,6 +68,12 @@ int pt_elem_roundtrip(int n, int compact, const uint32_t* tile, const uint32_t* 
 	return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+// (host side: no GPU) the bucket of every depth of a segment, as rank_sort computes it
+void pt_rank_sort_buckets(int n, const float* z, float zmin, float zmax, int nb, unsigned int* out)
+{
+	const float scale = rank_sort_scale(zmin, zmax, nb);
+	for (int i = 0; i < n; i++) out[i] = rank_sort_bucket(z[i], zmin, scale, nb);
+}
 int pt_pooled_grid(int n_tiles) { return pooled_grid(n_tiles); }
 int pt_pool_tiles_per_band(int n_tiles) { return pool_tiles_per_band(n_tiles); }
 

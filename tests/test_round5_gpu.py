@@ -22,7 +22,7 @@ def _option(name, value):
     from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS, FLAG_TEST_SMALL_GRIDS, FLAG_TEST_SORT_INT, resolve_flags
     bit = {"no_half_masks": FLAG_TEST_NO_HALF_MASKS, "sort_small_grids": FLAG_TEST_SMALL_GRIDS,
            "sort_force_int": FLAG_TEST_SORT_INT}[name]
-    cur = resolve_flags() & 0x700
+    cur = resolve_flags() & 0xf00
     return numerics(test_flags=(cur | bit) if value else (cur & ~bit))
 
 

@@ -258,3 +258,55 @@ def test_compiled_pooled_tile_hands_out_every_tile_once(n_tiles):
         assert (t >= -1).all()
         assert sorted(t[t >= 0].tolist()) == list(range(n_tiles))
         assert int(ctr.item()) == 0
+
+
+# ------------------------------------------------------------------ the per-tile sort: bucket-and-rank first, the network behind it
+SORT_CASES = ["sh3", "lists_gt_1024", "lists_gt_8192", "clustered_84k_list", "cluster_lists_1k_4k", "cluster_lists_mixed",
+              "c2_100k_800x800", "huge_splats"]
+
+
+@pytest.mark.parametrize("name", SORT_CASES)
+def test_network_sort_behind_the_rank_sort_gives_the_same_lists(name):
+    """By default a tile's segment is first offered to the bucket-and-rank sort (csrc/binning.hip: rank_sort), which
+    every other forward test therefore exercises; BSR_FLAG_TEST_SORT_NETWORK sends every segment of the call through the
+    compare-exchange network it falls back to (binary64 flavour where the depths allow).  Both must produce the oracle's
+    lists -- every size class, both forms of the second binning pass -- and the same point_list words."""
+    import numpy as np
+    from test_parity_gpu import _assert_forward_bit_exact
+    from bloomscene_amd import numerics
+    from bloomscene_amd.numerics import FLAG_TEST_SORT_NETWORK, resolve_flags
+    c = Hh.make_case(**CASES[name])
+    st, _ = Hh.run_oracle(c, backward=False)
+    with numerics(exact_exp=True, test_flags=FLAG_TEST_SORT_NETWORK):
+        assert resolve_flags() & FLAG_TEST_SORT_NETWORK
+        rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+        net = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    with numerics(exact_exp=True):
+        assert not resolve_flags() & FLAG_TEST_SORT_NETWORK
+        rs, t, R, radii, gb, bb, ib = _assert_forward_bit_exact(c, st)
+        rank = Hh.decode_buffers(c.P, c.W, c.H, R, gb, bb, ib)
+    assert np.array_equal(net.tile_lo, rank.tile_lo) and np.array_equal(net.tile_hi, rank.tile_hi)
+    assert np.array_equal(net.point_list, rank.point_list)
+
+
+@pytest.mark.parametrize("name,levels", [("sh3", 1), ("lists_gt_1024", 2), ("cluster_lists_1k_4k", 3),
+                                          ("cluster_lists_mixed", 0), ("c2_100k_800x800", 0)])
+def test_depths_piled_on_few_values_fall_back_to_the_network(name, levels):
+    """The bucket-and-rank sort declines a segment with more than BSR_RANK_CAP keys in one bucket.  levels > 0: every
+    Gaussian sits on one of `levels` depth values (scene A's camera looks down +z from the origin: view depth = z), so
+    a tile's keys differ in the id alone and every segment of more than 32 x levels keys is declined; levels = 0: half
+    of the Gaussians on one depth value, the others spread -- declined and accepted segments side by side.  The lists
+    must be the oracle's either way (ties in depth are ordered by id, as the reference's stable sort leaves them)."""
+    from test_parity_gpu import _assert_forward_bit_exact
+    from bloomscene_amd import numerics
+    c = Hh.make_case(**CASES[name])
+    z = c.means3D[:, 2]
+    if levels > 0:
+        vals = torch.linspace(float(z.median()) * 0.8, float(z.median()) * 1.2, levels)
+        c.means3D[:, 2] = vals[torch.arange(c.P) % levels]
+    else:
+        c.means3D[::2, 2] = float(z.median())
+    st, _ = Hh.run_oracle(c, backward=False)
+    assert st.num_rendered > 0
+    with numerics(exact_exp=True):
+        _assert_forward_bit_exact(c, st)
