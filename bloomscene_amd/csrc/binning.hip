@@ -1396,7 +1396,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 #define BSR_BKT_NT 512
 #define BSR_BKT_NW (BSR_BKT_NT / 64)
 typedef uint32_t bsr_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-template <int AREA, int TPW>   // keys per tile area (512 / 1024); tiles per wave
+template <int AREA, int TPW>   // keys per tile area (512 / 1024 / 2048); tiles per wave
 __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, const int* __restrict__ n_ptr, int capacity,
                                                             const uint32_t* __restrict__ digit_total1,
                                                             const BinElem* __restrict__ elems, uint2* __restrict__ tile_range,
@@ -1416,8 +1416,10 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	__shared__ uint32_t s_scan[NW];
 	__shared__ uint32_t s_base[2];
 	__shared__ uint32_t s_cur[NA];                  // second pass: fill counters of this part's long tiles
-	__shared__ uint32_t s_rank[NW][256];            // rank_sort's counters: 512 buckets per wave (the long-tile routine: all of it)
-	static_assert(NW * 256 >= 1024 + 32, "sort_long_tile_lds takes 2048 buckets + its reduction words");
+	// rank_sort's counters: 512 buckets per wave, 1024 where an area holds 2048 keys (the long-tile routine: all of it)
+	constexpr int RNBLOG = AREA > 1024 ? 10 : 9, RDW = (1 << RNBLOG) / 2;
+	__shared__ uint32_t s_rank[NW][RDW];
+	static_assert(NW * RDW >= 1024 + 32, "sort_long_tile_lds takes 2048 buckets + its reduction words");
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int k = 1 << k_log2;                      // 1, 2 or 4
 	// parts of one bucket are neighbours on one XCD: workgroups b, b + 8, b + 16, ... share an XCD
@@ -1517,9 +1519,6 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		}
 		if (lane < n) point_list[start + rank] = kl;
 	};
-#ifdef BSR_BKT_SORT_TWICE   // (cost-attribution builds only)
-	for (int rep = 0; rep < 2; rep++)
-#endif
 	if constexpr (TPW == 2) {
 		// tiles L = wave (lanes 0..31) and wave + NW (lanes 32..63), the same schedule for both: n2 = the larger one's
 		const int LA = wave, LB = wave + NW;
@@ -1537,7 +1536,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 #pragma unroll
 				for (int q = 0; q < AREA / 64; q++) e[q] = lane + 64 * q < n ? keys[swz_m<SM>(lane + 64 * q)] : 0ull;
 				round_sync<false>();
-				if (rank_sort<64, AREA / 64, 9, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list)) n = 0;
+				if (rank_sort<64, AREA / 64, RNBLOG, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list)) n = 0;
 				round_sync<false>();
 			};
 			by_ranks(LA, nA, startA);
@@ -1588,7 +1587,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 #pragma unroll
 				for (int q = 0; q < AREA / 64; q++) e[q] = lane + 64 * q < n ? keys[swz_m<SM>(lane + 64 * q)] : 0ull;
 				round_sync<false>();
-				const bool done = rank_sort<64, AREA / 64, 9, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list);
+				const bool done = rank_sort<64, AREA / 64, RNBLOG, false>(e, n, lane, keys, s_rank[wave], nullptr, start, point_list);
 				round_sync<false>();
 				if (done) continue;
 			}
@@ -1673,7 +1672,11 @@ void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, ui
 //      that pays while an average tile holds well under the 1024 keys of a tile area (C3: 366 kept instances per tile;
 //      the dense leg: 1600, C5: 1850),
 //   3  k_bucket_sort<512, 2>: the same with 512-key areas, two tiles per wave (half the workgroups per bucket), where
-//      the average tile holds at most BSR_BKT_SMALL_PER_TILE.
+//      the average tile holds at most BSR_BKT_SMALL_PER_TILE,
+//   4  k_bucket_sort<2048, 1>: 2048-key areas (128 KB of keys: one workgroup per CU, four workgroups per bucket of a
+//      1080p frame) for dense frames, up to BSR_BKT_BIG_PER_TILE per tile on average: against the chain it saves the
+//      count, the global scan and the scatter (the elements written and read once more) for three more reads of the
+//      bucket from the L2.
 // kept_hint = the number of kept instances the caller expects (this frame's count when the host has read it, the
 // previous frame's while it guesses), 0 = unknown: 70 % of the scratch capacity then (the exact tile cull keeps ~2/3
 // of the reference's instances on the synthetic scenes).
@@ -1685,6 +1688,11 @@ void launch_scans(int n_wg, uint32_t* wg_kept, uint32_t* wg_area, int* flags, ui
 #ifndef BSR_BKT_SMALL_PER_TILE
 #define BSR_BKT_SMALL_PER_TILE 400
 #endif
+#ifndef BSR_BKT_BIG_PER_TILE
+#define BSR_BKT_BIG_PER_TILE 1400   // up to here: 2048-key areas (plan 4), one workgroup of 144 KB per CU.  (A/B, all forms forced:
+                                    // dense leg, 1213 per tile: second pass + sorts 216 us against the chain's 240; 925 per tile:
+                                    // even; C5, 1830 per tile with tiles past 2048: even, and 20 % slower at 2000 per tile)
+#endif
 int binning_plan(int P, int T, int capacity, long long kept_hint)
 {
 	int bits = 0;
@@ -1694,6 +1702,7 @@ int binning_plan(int P, int T, int capacity, long long kept_hint)
 	const long long kept = kept_hint > 0 ? kept_hint : (long long)capacity * 7 / 10;
 	if (P <= (1 << 24) && T <= 8192 && kept <= (long long)BSR_BUCKET_MAX_PER_TILE * T)
 		return kept <= (long long)BSR_BKT_SMALL_PER_TILE * T ? 3 : 2;
+	if (P <= (1 << 24) && T <= 8192 && BSR_BUCKET_MAX_PER_TILE > 0 && kept <= (long long)BSR_BKT_BIG_PER_TILE * T) return 4;
 	return 1;
 }
 
@@ -1781,13 +1790,16 @@ void launch_sort_tiles(int plan, int T, int n_bound, const int* n_ptr, int capac
 		// 64 KB of LDS either way: 16 tile areas of 512 keys (two per wave) or 8 of 1024; a bucket has ceil(T / 256)
 		// tiles, split over k = 1, 2 or 4 workgroups.
 		const int nt_max = (T + BSR_RADIX_BINS - 1) / BSR_RADIX_BINS;
-		const bool small_areas = plan == 3;
+		const bool small_areas = plan == 3, big_areas = plan == 4;
 		const int per_wg = small_areas ? 2 * BSR_BKT_NW : BSR_BKT_NW;
 		int k_log2 = 0;
 		while ((per_wg << k_log2) < nt_max) k_log2++;
 		uint64_t* const big_keys = reinterpret_cast<uint64_t*>(elems_free);
 		if (small_areas)
 			hipLaunchKernelGGL((k_bucket_sort<512, 2>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
+			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, force_int);
+		else if (big_areas)
+			hipLaunchKernelGGL((k_bucket_sort<2048, 1>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,
 			                   capacity, digit_total1, elems, tile_range, big_keys, point_list, force_int);
 		else
 			hipLaunchKernelGGL((k_bucket_sort<1024, 1>), dim3(BSR_RADIX_BINS << k_log2), dim3(BSR_BKT_NT), 0, s, T, k_log2, n_ptr,

@@ -86,8 +86,9 @@ def test_forward_during_capture_with_a_pending_overflow_check_fails_loudly():
 
 
 def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
-    """libbsr_chain_only.so pins the tile-owned chain, libbsr_bucket_always.so k_bucket_sort (wherever it is eligible:
-    up to 8192 tiles); the product library chooses by size.  Every output and gradient of nine frames: three identical
+    """libbsr_chain_only.so pins the tile-owned chain, libbsr_bucket_always.so k_bucket_sort with 512- / 1024-key areas,
+    libbsr_bucket_big.so k_bucket_sort<2048, 1> (wherever they are eligible: up to 8192 tiles); the product library
+    chooses by size.  Every output and gradient of nine frames: three identical
     digests.  (The order of the tile segments inside point_list differs between the forms; nothing visible may.)"""
     import json
     import os
@@ -101,14 +102,15 @@ def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
         assert r.returncode == 0, r.stderr[-2000:]
         return json.loads(r.stdout.strip().splitlines()[-1])
     libs = {}
-    for name in ("chain_only", "bucket_always"):
+    for name in ("chain_only", "bucket_always", "bucket_big"):
         path = os.path.join(root, "bloomscene_amd", f"libbsr_{name}.so")
         assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
         libs[name] = digest(["--lib", path])
     product = digest([])
-    assert len(product) == 9 and product.keys() == libs["chain_only"].keys() == libs["bucket_always"].keys()
+    assert len(product) == 9 and product.keys() == libs["chain_only"].keys() == libs["bucket_always"].keys() == libs["bucket_big"].keys()
     for case in product:
         assert libs["chain_only"][case] == libs["bucket_always"][case], case
+        assert libs["chain_only"][case] == libs["bucket_big"][case], case
         assert product[case] == libs["chain_only"][case], case
 
 

@@ -2,9 +2,10 @@
 # Where does the bucket form of the second binning pass stop paying?  Step time of the product library (host-side choice,
 # binning.hip: binning_plan) against the two pinned builds on frames of growing density (C3's scene, scales multiplied):
 #   bash tools/plan_sweep.sh "1.0 1.5 2.0 2.5 3.0"        (one GPU box; make debug_variants first)
+#   bash tools/plan_sweep.sh "1.0" "--config c5"          (extra bench arguments)
 for sm in ${1:-1.0 1.5 2.0 2.5 3.0}; do
-  for L in libbloomscene_rast.so libbsr_chain_only.so libbsr_bucket_always.so; do
-    python bench.py --lib $PWD/bloomscene_amd/$L --no-cpu-baseline --no-c4 --no-secondary --steps 30 --warmup 8 --scale-mul $sm 2>/dev/null | python -c "
+  for L in libbloomscene_rast.so libbsr_chain_only.so libbsr_bucket_always.so libbsr_bucket_big.so; do
+    python bench.py --lib $PWD/bloomscene_amd/$L --no-cpu-baseline --no-c4 --no-secondary --steps 30 --warmup 8 --scale-mul $sm ${2:-} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1])
 s=d['stage_ms']
