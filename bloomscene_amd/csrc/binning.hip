@@ -1385,9 +1385,10 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 //   workgroup (bucket d, part j of k = 2^k_log2): owns the bucket's tiles whose high byte hi = j (mod k) -- at most
 //   NW * TPW of them, tile L = hi / k in LDS area L -- and streams the WHOLE bucket once (8-byte elements; the k parts
 //   of a bucket run on one XCD back to back: one HBM read, k - 1 L2 hits).  An element of one of its tiles takes its
-//   slot in the tile's area from an LDS counter (= the tile's count in the end); the others are only counted per PART
-//   (wave ballots, no LDS traffic), which is all the layout needs: the bucket's range holds part 0's tiles, then part
-//   1's, ..., inside a part in order of L -- every part computes the same part totals, so the segments tile the range.
+//   slot in the tile's area from an LDS counter (= the tile's count in the end); of the others only those of EARLIER
+//   parts are counted (one wave ballot per element, no LDS traffic), which is all the layout needs: the bucket's range
+//   holds part 0's tiles, then part 1's, ..., inside a part in order of L -- part j begins behind the elements of the
+//   parts before it, which every workgroup of the bucket counts alike, so the segments tile the range.
 //   Then the ranges are written and every wave sorts its TPW tiles in place (the wave-owned network of
 //   k_sort_tiles_small, from LDS instead of global memory; up to 64 keys: ranks by counting) and writes the ids.
 //   A tile of more than AREA instances (rare where this kernel is chosen) is staged as plain keys in global scratch
@@ -1412,7 +1413,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	static_assert(NA * AREA >= BSR_SORT_CHUNK, "the long-tile routines sort 4096-key chunks in this LDS");
 	__shared__ uint64_t s_keys[NA * AREA];          // one area per owned tile; the long-tile routines use the first 4096 slots
 	__shared__ uint32_t s_cnt[NA];                  // elements per owned tile (the fill counters of the pass)
-	__shared__ uint32_t s_part[4];                  // elements of the bucket per part
+	__shared__ uint32_t s_part[4];                  // [0]: elements of the bucket in earlier parts
 	__shared__ uint32_t s_scan[NW];
 	__shared__ uint32_t s_base[2];
 	__shared__ uint32_t s_cur[NA];                  // second pass: fill counters of this part's long tiles
@@ -1451,14 +1452,14 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	}
 	const uint32_t beg = s_base[0], size = s_base[1];
 	const uint2* const src = reinterpret_cast<const uint2*>(elems) + beg;
-	// one element of the pass: counted for its part; if it belongs to a tile of this part, stored in the tile's area
-	uint32_t part_cnt[4] = {0u, 0u, 0u, 0u};   // (wave-uniform: scalar registers)
+	// one element of the pass: counted if it belongs to an EARLIER part (all the layout needs of the other parts: where
+	// this part's tiles begin -- one vote per element; until the 2048-key areas every part was counted, k votes); if it
+	// belongs to a tile of this part, stored in the tile's area
+	uint32_t before = 0u;   // (wave-uniform: a scalar register)
 	auto take = [&](bool valid, uint32_t w0, uint32_t w1) {
 		const uint32_t hi = w0 >> 24;
 		const uint32_t part = hi & (uint32_t)(k - 1);
-#pragma unroll
-		for (int q = 0; q < 4; q++)
-			if (q < k) part_cnt[q] += (uint32_t)__popcll(wave_ballot(valid && part == (uint32_t)q));
+		if (j > 0) before += (uint32_t)__popcll(wave_ballot(valid && part < (uint32_t)j));   // (j: workgroup-uniform)
 		if (valid && (int)part == j) {
 			const uint32_t L = hi >> k_log2;
 			const uint32_t pos = atomicAdd(&s_cnt[L], 1u);   // LDS
@@ -1466,8 +1467,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		}
 	};
 	// ---- the pass over the bucket: two elements per 16-byte load, eight loads in flight
-	for (uint32_t i0 = 0; i0 < size; i0 += NT * 16) {
-		bsr_u32x4_a8 v[8];
+	auto request = [&](uint32_t i0, bsr_u32x4_a8 (&v)[8]) {
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
 			const uint32_t i = i0 + 2u * (uint32_t)(u * NT + tid);
@@ -1475,6 +1475,8 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 			else if (i < size) { const uint2 e = src[i]; v[u] = bsr_u32x4_a8{e.x, e.y, 0u, 0u}; }
 			else v[u] = bsr_u32x4_a8{0u, 0u, 0u, 0u};
 		}
+	};
+	auto consume = [&](uint32_t i0, const bsr_u32x4_a8 (&v)[8]) {
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
 			const uint32_t i = i0 + 2u * (uint32_t)(u * NT + tid);
@@ -1483,16 +1485,18 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 				take(i + 1 < size, v[u].z, v[u].w);
 			}
 		}
+	};
+	// (k_bucket_sort<2048, 1>, one workgroup per CU: requesting the next trip's loads before this one's elements are taken
+	// -- two register sets -- was measured: 130 us against 117; sixteen waves of which eight sort: 128)
+	for (uint32_t i0 = 0; i0 < size; i0 += NT * 16) {
+		bsr_u32x4_a8 v[8];
+		request(i0, v);
+		consume(i0, v);
 	}
-	if (lane == 0) {
-#pragma unroll
-		for (int q = 0; q < 4; q++)
-			if (q < k && part_cnt[q] != 0u) atomicAdd(&s_part[q], part_cnt[q]);   // LDS
-	}
+	if (lane == 0 && before != 0u) atomicAdd(&s_part[0], before);   // LDS
 	__syncthreads();
 	// ---- layout: part-major inside the bucket's range, tiles of a part in order of L
-	uint32_t part_beg = beg;
-	for (int q = 0; q < j; q++) part_beg += s_part[q];
+	const uint32_t part_beg = beg + s_part[0];
 	auto tile_first = [&](int L) {   // first position of owned tile L
 		uint32_t f = part_beg;
 		for (int q = 0; q < L; q++) f += s_cnt[q];
