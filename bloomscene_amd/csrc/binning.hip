@@ -1452,18 +1452,36 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	}
 	const uint32_t beg = s_base[0], size = s_base[1];
 	const uint2* const src = reinterpret_cast<const uint2*>(elems) + beg;
-	// one element of the pass: counted if it belongs to an EARLIER part (all the layout needs of the other parts: where
+	// An element of the pass is counted if it belongs to an EARLIER part (all the layout needs of the other parts: where
 	// this part's tiles begin -- one vote per element; until the 2048-key areas every part was counted, k votes); if it
-	// belongs to a tile of this part, stored in the tile's area
+	// belongs to a tile of this part it takes its slot in the tile's area from the tile's LDS counter.  Eight elements at
+	// a time: first all eight returning atomics, then the eight stores -- element by element every atomic's round trip
+	// through the LDS was waited for before the next element was looked at (16 round trips per trip of a wave).
 	uint32_t before = 0u;   // (wave-uniform: a scalar register)
-	auto take = [&](bool valid, uint32_t w0, uint32_t w1) {
-		const uint32_t hi = w0 >> 24;
-		const uint32_t part = hi & (uint32_t)(k - 1);
-		if (j > 0) before += (uint32_t)__popcll(wave_ballot(valid && part < (uint32_t)j));   // (j: workgroup-uniform)
-		if (valid && (int)part == j) {
-			const uint32_t L = hi >> k_log2;
-			const uint32_t pos = atomicAdd(&s_cnt[L], 1u);   // LDS
-			if (pos < (uint32_t)AREA) s_keys[L * AREA + swz_m<SM>((int)pos)] = ((uint64_t)w1 << 32) | (uint64_t)(w0 & 0x00ffffffu);
+	auto take8 = [&](const bool full, const uint32_t i, const bsr_u32x4_a8 (&v)[8], const int u0) {
+		uint32_t pos[8];
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const bsr_u32x4_a8 q = v[u0 + (e >> 1)];
+			const uint32_t w0 = (e & 1) ? q.z : q.x;
+			const uint32_t ie = i + 2u * (uint32_t)((e >> 1) * NT) + (uint32_t)(e & 1);
+			const bool valid = full || ie < size;
+			const uint32_t hi = w0 >> 24;
+			const uint32_t part = hi & (uint32_t)(k - 1);
+			if (j > 0) {   // (j: workgroup-uniform.  Two votes AND-ed on the scalar side: a vote on `valid && ...` is a mask
+				           // materialised in a VGPR and compared again)
+				const uint64_t m = wave_ballot(part < (uint32_t)j);
+				before += (uint32_t)__popcll(full ? m : (m & wave_ballot(valid)));
+			}
+			pos[e] = 0xffffffffu;
+			if (valid && (int)part == j) pos[e] = atomicAdd(&s_cnt[hi >> k_log2], 1u);   // LDS
+		}
+#pragma unroll
+		for (int e = 0; e < 8; e++) {
+			const bsr_u32x4_a8 q = v[u0 + (e >> 1)];
+			const uint32_t w0 = (e & 1) ? q.z : q.x, w1 = (e & 1) ? q.w : q.y;
+			if (pos[e] < (uint32_t)AREA)
+				s_keys[(w0 >> (24 + k_log2)) * AREA + swz_m<SM>((int)pos[e])] = ((uint64_t)w1 << 32) | (uint64_t)(w0 & 0x00ffffffu);
 		}
 	};
 	// ---- the pass over the bucket: two elements per 16-byte load, eight loads in flight
@@ -1477,14 +1495,10 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		}
 	};
 	auto consume = [&](uint32_t i0, const bsr_u32x4_a8 (&v)[8]) {
-#pragma unroll
-		for (int u = 0; u < 8; u++) {
-			const uint32_t i = i0 + 2u * (uint32_t)(u * NT + tid);
-			if (i0 + 2u * (uint32_t)(u * NT) < size) {   // (wave-uniform bound: at least the wave's first lane is in range)
-				take(i < size, v[u].x, v[u].y);
-				take(i + 1 < size, v[u].z, v[u].w);
-			}
-		}
+		const bool full = i0 + (uint32_t)(NT * 16) <= size;   // (uniform) every element of the trip exists
+		const uint32_t i = i0 + 2u * (uint32_t)tid;
+		take8(full, i, v, 0);
+		if (i0 + 2u * (uint32_t)(4 * NT) < size) take8(full, i + 2u * (uint32_t)(4 * NT), v, 4);   // (uniform bound)
 	};
 	// (k_bucket_sort<2048, 1>, one workgroup per CU: requesting the next trip's loads before this one's elements are taken
 	// -- two register sets -- was measured: 130 us against 117; sixteen waves of which eight sort: 128)
