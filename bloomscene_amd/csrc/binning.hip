@@ -35,33 +35,55 @@ namespace bsr {
 #define BSR_RADIX_BINS 256
 #define BSR_SORT_SMALL_N 1024   // tiles with more instances go to the wide sort classes (== BSR_SORT_SMALL below)
 
+// Inclusive sum over the 64 lanes on the vector ALU alone (the sequence LLVM's atomic optimiser emits for wave64 on
+// GFX9): four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3 and lane 31
+// into rows 2 - 3.  (__shfl_up is a ds_bpermute round trip per step.)
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+	return x;
+}
+
 // Exclusive scan of n uint32 in place by ONE 1024-thread workgroup, 4 values per thread and step.
-// Returns the total to every thread.
+// Returns the total to every thread.  s_wave: 32 words (two sets of 16 wave totals, used in turn).
+// One barrier per step: every thread adds up the sixteen wave totals itself (the carry lives in a register), and the
+// totals of consecutive steps go to alternating sets, so that a step's writes are two barriers behind the last reads
+// of the set they overwrite.  The next step's four values are requested before this step's barrier.  (Until round 6:
+// three barriers per step, the carry through LDS, a step beginning with the wait for its own loads -- a row of C5's
+// pass-1 histogram is five steps long: k_scans 34 -> .. us.)
 struct AllValid { __device__ __forceinline__ bool operator()(int) const { return true; } };
 template <typename Valid = AllValid>
-__device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, uint32_t* s_wave, uint32_t* s_carry,
-                                                         bool write, Valid valid = Valid())
+__device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, uint32_t* s_wave, bool write, Valid valid = Valid())
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if (tid == 0) *s_carry = 0;
-	__syncthreads();
-	for (int base = 0; base < n; base += 4096) {
+	uint32_t carry = 0u;
+	uint32_t nx[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) nx[k] = (tid * 4 + k < n && valid(tid * 4 + k)) ? data[tid * 4 + k] : 0u;
+	int set = 0;
+	for (int base = 0; base < n; base += 4096, set ^= 16) {
 		const int i = base + tid * 4;
 		uint32_t v[4];
 #pragma unroll
-		for (int k = 0; k < 4; k++) v[k] = (i + k < n && valid(i + k)) ? data[i + k] : 0u;
-		const uint32_t mine = v[0] + v[1] + v[2] + v[3];
-		uint32_t incl = mine;
+		for (int k = 0; k < 4; k++) v[k] = nx[k];
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += t;
-		}
-		if (lane == 63) s_wave[wave] = incl;
+		for (int k = 0; k < 4; k++) nx[k] = (i + 4096 + k < n && valid(i + 4096 + k)) ? data[i + 4096 + k] : 0u;
+		const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+		const uint32_t incl = wave_inclusive_sum_dpp(mine);
+		if (lane == 63) s_wave[set + wave] = incl;
 		__syncthreads();
-		uint32_t wave_off = 0;
-		for (int w = 0; w < wave; w++) wave_off += s_wave[w];
-		const uint32_t carry = *s_carry;
+		uint32_t wave_off = 0u, total = 0u;
+#pragma unroll
+		for (int w = 0; w < 16; w++) {
+			const uint32_t t = s_wave[set + w];
+			wave_off += w < wave ? t : 0u;
+			total += t;
+		}
 		uint32_t run = carry + wave_off + incl - mine;
 		if (write) {
 #pragma unroll
@@ -70,11 +92,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int n, uint32_t* data, 
 				run += v[k];
 			}
 		}
-		__syncthreads();
-		if (tid == 1023) *s_carry = carry + wave_off + incl;
-		__syncthreads();
+		carry += total;
 	}
-	return *s_carry;
+	__syncthreads();   // (the caller may reuse s_wave at once)
+	return carry;
 }
 
 // The two scans between k_preprocess and the binning, in one launch:
@@ -91,12 +112,10 @@ __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__
                                                 uint32_t* __restrict__ wg_area, int* __restrict__ flags,
                                                 uint32_t* __restrict__ hist1, int* __restrict__ host_counts)
 {
-	__shared__ uint32_t s_w[16];
-	__shared__ uint32_t s_c;
+	__shared__ uint32_t s_w[32];
 	if (blockIdx.x == BSR_RADIX_BINS) {
-		const uint32_t kept = block_exclusive_scan(n_wg, wg_kept, s_w, &s_c, true);
-		__syncthreads();
-		const uint32_t area = block_exclusive_scan(n_wg, wg_area, s_w, &s_c, false);
+		const uint32_t kept = block_exclusive_scan(n_wg, wg_kept, s_w, true);
+		const uint32_t area = block_exclusive_scan(n_wg, wg_area, s_w, false);
 		if (threadIdx.x == 0) {
 			flags[2] = (int)kept;
 			flags[3] = (int)area;
@@ -117,7 +136,7 @@ __global__ void __launch_bounds__(1024) k_scans(int n_wg, uint32_t* __restrict__
 		return;
 	}
 	const int per = (n_wg + 7) >> 3, n_col = 8 * per;
-	const uint32_t total = block_exclusive_scan(n_col, hist1 + (size_t)blockIdx.x * n_col, s_w, &s_c, true,
+	const uint32_t total = block_exclusive_scan(n_col, hist1 + (size_t)blockIdx.x * n_col, s_w, true,
 	                                            Hist1ColumnValid{per, n_wg});
 	if (threadIdx.x == 0) hist1[(size_t)BSR_RADIX_BINS * n_col + blockIdx.x] = total;   // digit totals behind the rows
 }
@@ -414,20 +433,6 @@ __global__ void __launch_bounds__(256) k_tile_count(int T, int n_slices, const i
 	const uint32_t c = s_hist[tid];
 	const uint32_t t = ((uint32_t)tid << BSR_RADIX_BITS) | (uint32_t)d1;
 	if (c != 0u && t < (uint32_t)T) atomicAdd(&tile_count[t], c);
-}
-
-// Inclusive sum over the 64 lanes on the vector ALU alone (the sequence LLVM's atomic optimiser emits for wave64 on
-// GFX9): four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3 and lane 31
-// into rows 2 - 3.  (__shfl_up is a ds_bpermute round trip per step.)
-__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
-{
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-	return x;
 }
 
 // ONE workgroup of 1024: tile_count -> tile_start (exclusive scan in tile order, tile_start[T] = total) and the work

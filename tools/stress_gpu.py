@@ -284,8 +284,11 @@ def main():
         route = int(rng.integers(0, 4))
         cap = None if route in (0, 1) else int(st.num_rendered) + int(rng.integers(1, 5000))
         from bloomscene_amd import numerics
-        from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS
-        with numerics(test_flags=FLAG_TEST_NO_HALF_MASKS if route in (1, 3) else 0):
+        from bloomscene_amd.numerics import FLAG_TEST_NO_HALF_MASKS, FLAG_TEST_SORT_NETWORK
+        # (round 6) ... and, in half of the cases, with every per-tile sort through the compare-exchange network instead
+        # of the bucket-and-rank sort the first run took
+        net = FLAG_TEST_SORT_NETWORK if rng.random() < 0.5 else 0
+        with numerics(test_flags=(FLAG_TEST_NO_HALF_MASKS if route in (1, 3) else 0) | net):
             out2 = Hh.run_hip(c, depth_gradient=dg, exact_exp=exact, capacity=cap)
         if cap is not None:
             from bloomscene_amd.rasterizer import check_deferred
