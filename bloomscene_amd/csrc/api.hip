@@ -30,7 +30,7 @@ size_t GeomState::bytes(size_t P)
 	s += align_up(P * BSR_REC * sizeof(float4), 256);
 	s += align_up(P * sizeof(uint32_t), 256);
 	s += 2 * align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
-	s += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
+	s += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 512) * sizeof(uint32_t), 256);   // rows + digit totals + digit bases
 	s += align_up(P * sizeof(uint64_t), 256);
 	s += align_up(P * sizeof(ushort4), 256);
 	s += align_up(P * sizeof(uint8_t), 256);
@@ -45,7 +45,7 @@ GeomState GeomState::carve(char* p, size_t P)
 	g.inst_offset = (uint32_t*)p; p += align_up(P * sizeof(uint32_t), 256);
 	g.wg_kept = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
 	g.wg_area = (uint32_t*)p;     p += align_up(((P + 255) / 256) * sizeof(uint32_t), 256);
-	g.hist1 = (uint32_t*)p;       p += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 256) * sizeof(uint32_t), 256);
+	g.hist1 = (uint32_t*)p;       p += align_up((256 * (((P + 255) / 256 + 7) / 8 * 8) + 512) * sizeof(uint32_t), 256);
 	g.kept_mask = (uint64_t*)p;   p += align_up(P * sizeof(uint64_t), 256);
 	g.rect = (ushort4*)p;    p += align_up(P * sizeof(ushort4), 256);
 	g.clamped = (uint8_t*)p; p += align_up(P * sizeof(uint8_t), 256);

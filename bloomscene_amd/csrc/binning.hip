@@ -243,6 +243,9 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 		__syncthreads();
 		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
 		s_off[tid] = base + col;
+		// the 256 digit bases, once, behind the digit totals: k_bucket_sort takes its bucket's range from there instead
+		// of every one of its workgroups scanning the totals again (a load, a scan and two barriers at its start)
+		if (blockIdx.x == 0) const_cast<uint32_t*>(hist1)[(size_t)BSR_RADIX_BINS * n_col + BSR_RADIX_BINS + tid] = base;
 	}
 	__syncthreads();
 	if (!in_range) return;
@@ -1419,8 +1422,6 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	__shared__ uint64_t s_keys[NA * AREA];          // one area per owned tile; the long-tile routines use the first 4096 slots
 	__shared__ uint32_t s_cnt[NA];                  // elements per owned tile (the fill counters of the pass)
 	__shared__ uint32_t s_part[4];                  // [0]: elements of the bucket in earlier parts
-	__shared__ uint32_t s_scan[NW];
-	__shared__ uint32_t s_base[2];
 	__shared__ uint32_t s_cur[NA];                  // second pass: fill counters of this part's long tiles
 	// rank_sort's counters: 512 buckets per wave, 1024 where an area holds 2048 keys (the long-tile routine: all of it)
 	constexpr int RNBLOG = AREA > 1024 ? 10 : 9, RDW = (1 << RNBLOG) / 2;
@@ -1439,23 +1440,11 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 		if (tid < m) tile_range[(uint32_t)((j + (tid << k_log2)) << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(0u, 0u);
 		return;
 	}
-	// the bucket's range: exclusive scan of the 256 digit totals
-	{
-		const uint32_t v = tid < BSR_RADIX_BINS ? digit_total1[tid] : 0u;
-		if (tid < NA) s_cnt[tid] = 0u;
-		if (tid < 4) s_part[tid] = 0u;
-		const uint32_t incl = wave_inclusive_sum_dpp(v);
-		if (lane == 63) s_scan[wave] = incl;
-		__syncthreads();
-		uint32_t before = incl - v;
-		for (int w = 0; w < wave; w++) before += s_scan[w];
-		if (tid == d) {
-			s_base[0] = before;
-			s_base[1] = v;
-		}
-		__syncthreads();
-	}
-	const uint32_t beg = s_base[0], size = s_base[1];
+	// the bucket's range: its base among the 256 digits (written by k_emit_scatter behind the totals) and its total
+	if (tid < NA) s_cnt[tid] = 0u;
+	if (tid < 4) s_part[tid] = 0u;
+	__syncthreads();
+	const uint32_t beg = digit_total1[BSR_RADIX_BINS + d], size = digit_total1[d];   // (uniform: scalar loads)
 	const uint2* const src = reinterpret_cast<const uint2*>(elems) + beg;
 	// An element of the pass is counted if it belongs to an EARLIER part (all the layout needs of the other parts: where
 	// this part's tiles begin -- one vote per element; until the 2048-key areas every part was counted, k votes); if it
@@ -1516,18 +1505,22 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 	__syncthreads();
 	// ---- layout: part-major inside the bucket's range, tiles of a part in order of L
 	const uint32_t part_beg = beg + s_part[0];
-	auto tile_first = [&](int L) {   // first position of owned tile L
+	// every wave keeps the owned tiles' counts and first positions in its lanes (lane L <-> tile L): one LDS read and a
+	// DPP scan instead of a serial sum of up to 16 counters per look-up
+	static_assert(NA <= 64, "one lane per owned tile");
+	const uint32_t cnt_lane = lane < NA ? s_cnt[lane] : 0u;
+	const uint32_t first_lane = part_beg + wave_inclusive_sum_dpp(cnt_lane) - cnt_lane;
+	auto tile_first = [&](int L) {   // first position of owned tile L (L wave-uniform)
+		return (uint32_t)__builtin_amdgcn_readlane((int)first_lane, L);
+	};
+	auto tile_first_any = [&](int L) {   // the same for a lane's own L (the long-tile pass)
 		uint32_t f = part_beg;
 		for (int q = 0; q < L; q++) f += s_cnt[q];
 		return f;
 	};
-	if (tid < m) {
-		const uint32_t first = tile_first(tid);
-		tile_range[(uint32_t)((j + (tid << k_log2)) << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(first, first + s_cnt[tid]);
-	}
+	if (tid < m) tile_range[(uint32_t)((j + (tid << k_log2)) << BSR_RADIX_BITS) | (uint32_t)d] = make_uint2(first_lane, first_lane + cnt_lane);
 	// ---- every wave sorts its tiles
-	bool any_long = false;   // (workgroup-uniform: every thread looks at all of the part's counts)
-	for (int L = 0; L < m; L++) any_long = any_long || s_cnt[L] > (uint32_t)AREA;
+	const bool any_long = wave_ballot(lane < m && cnt_lane > (uint32_t)AREA) != 0ull;   // (workgroup-uniform: every wave sees all counts)
 	// ranks by counting, tiles of up to 64 keys ((depth bits, id) pairs are unique within a tile): no network, no further
 	// LDS traffic
 	auto sort_by_ranks = [&](const uint64_t* keys, int n, uint32_t start) {
@@ -1660,7 +1653,7 @@ __global__ void __launch_bounds__(BSR_BKT_NT) k_bucket_sort(int T, int k_log2, c
 				const uint32_t L = hi >> k_log2;
 				if ((int)(hi & (uint32_t)(k - 1)) == j && s_cnt[L] > (uint32_t)AREA) {
 					const uint32_t pos = atomicAdd(&s_cur[L], 1u);   // LDS
-					big_keys[(size_t)tile_first((int)L) + pos] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
+					big_keys[(size_t)tile_first_any((int)L) + pos] = ((uint64_t)v[u].y << 32) | (uint64_t)(v[u].x & 0x00ffffffu);
 				}
 			}
 		}

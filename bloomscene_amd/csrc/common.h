@@ -26,8 +26,9 @@ struct GeomState {
 	uint32_t* wg_kept;      // [ceil(P/256)] kept instances per preprocess workgroup; exclusive-scanned in place
 	                        //               into the workgroup's base by k_scan_tiles (-> "wg_base")
 	uint32_t* wg_area;      // [ceil(P/256)] rect tiles per preprocess workgroup (sum = reference num_rendered)
-	uint32_t* hist1;        // [256][8 * ceil(n_wg / 8)] + [256]: kept instances per (low 8 bits of the tile id, preprocess
-	                        //   workgroup), digit-major, row-scanned in place by k_rowscan_fixed; then the digit totals.
+	uint32_t* hist1;        // [256][8 * ceil(n_wg / 8)] + [256] + [256]: kept instances per (low 8 bits of the tile id, preprocess
+	                        //   workgroup), digit-major, row-scanned in place by k_scans; then the digit totals (k_scans) and
+	                        //   their exclusive prefix, the digit bases (k_emit_scatter).
 	                        //   First radix pass = k_emit_scatter: instances are written straight to their pass-1 place.
 	uint64_t* kept_mask;    // [P] see q3 above
 	ushort4* rect;      // [P] tile rect (xmin, ymin, xmax, ymax); zero area <=> culled

@@ -360,7 +360,7 @@ def decode_buffers(P, W, H, R, geom_t, bin_t, img_t):
     out.rec = geom[off:off + P * 64].view(np.float32).reshape(P, 16); off += _al(P * 64)
     out.inst_offset = geom[off:off + P * 4].view(np.uint32); off += _al(P * 4)
     off += 2 * _al(((P + 255) // 256) * 4)   # wg_kept, wg_area
-    off += _al((256 * (((P + 255) // 256 + 7) // 8 * 8) + 256) * 4)   # hist1 (pass-1 histogram) + digit totals
+    off += _al((256 * (((P + 255) // 256 + 7) // 8 * 8) + 512) * 4)   # hist1 (pass-1 histogram) + digit totals + digit bases
     out.kept_mask = geom[off:off + P * 8].view(np.uint64); off += _al(P * 8)
     out.rect = geom[off:off + P * 8].view(np.uint16).reshape(P, 4); off += _al(P * 8)
     out.clamped = geom[off:off + P].copy()
