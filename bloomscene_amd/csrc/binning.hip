@@ -35,20 +35,6 @@ namespace bsr {
 #define BSR_RADIX_BINS 256
 #define BSR_SORT_SMALL_N 1024   // tiles with more instances go to the wide sort classes (== BSR_SORT_SMALL below)
 
-// Inclusive sum over the 64 lanes on the vector ALU alone (the sequence LLVM's atomic optimiser emits for wave64 on
-// GFX9): four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3 and lane 31
-// into rows 2 - 3.  (__shfl_up is a ds_bpermute round trip per step.)
-__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
-{
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-	return x;
-}
-
 // Exclusive scan of n uint32 in place by ONE 1024-thread workgroup, 4 values per thread and step.
 // Returns the total to every thread.  s_wave: 32 words (two sets of 16 wave totals, used in turn).
 // One barrier per step: every thread adds up the sixteen wave totals itself (the carry lives in a register), and the
@@ -233,12 +219,7 @@ __global__ void __launch_bounds__(256) k_emit_scatter(int P, int gx, const int* 
 	const uint64_t mask = kept_mask[ld];
 	const uint32_t depth_bits = __float_as_uint(depth[ld]);
 	{   // digit base = exclusive scan of the 256 digit totals (thread d <-> digit d) + this workgroup's prefix
-		uint32_t incl = v;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += t;
-		}
+		const uint32_t incl = wave_inclusive_sum_dpp(v);   // (six __shfl_up steps are six ds_bpermute round trips)
 		if (lane == 63) s_scan[wave] = incl;
 		__syncthreads();
 		const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - v;
@@ -379,12 +360,7 @@ __device__ __forceinline__ BucketSlice bucket_slice(uint32_t my_total, int d1, i
                                                     uint32_t* s_base)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint32_t incl = my_total;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const uint32_t t = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += t;
-	}
+	const uint32_t incl = wave_inclusive_sum_dpp(my_total);
 	if (lane == 63) s_scan[wave] = incl;
 	__syncthreads();
 	const uint32_t base = (wave > 0 ? s_scan[0] : 0u) + (wave > 1 ? s_scan[1] : 0u) + (wave > 2 ? s_scan[2] : 0u) + incl - my_total;

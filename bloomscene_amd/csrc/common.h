@@ -216,6 +216,20 @@ __device__ __forceinline__ float bsr_expf(float x)
 // matters inside the tile walks.)
 __device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Inclusive sum over the 64 lanes on the vector ALU alone (the sequence LLVM's atomic optimiser emits for wave64 on
+// GFX9): four row_shr steps inside the 16-lane rows, then lane 15 of rows 0 / 2 broadcast into rows 1 / 3 and lane 31
+// into rows 2 - 3.  (__shfl_up is a ds_bpermute round trip per step.)
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t x)
+{
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+	return x;
+}
+
 // Branch-free bsr_expf for the tile walks, without the range checks (NaN flows through the fma chain):
 // there the result is only consumed on lanes whose argument passed `power <= 0` and
 // `power >= power_cut`, and power_cut = -ln(255 o) - 1e-3

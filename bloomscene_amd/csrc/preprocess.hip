@@ -307,15 +307,9 @@ __global__ void __launch_bounds__(256) k_preprocess(const PreArgs a)
 		const uint32_t n_inst = area_all ? kept_count(area_all, kept_mask) : 0u;
 		// inclusive wave scans of the kept-instance counts (-> instance blocks, relative to the
 		// workgroup) and wave sums of the rect areas (-> the reference's num_rendered)
-		uint32_t incl = n_inst;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += t;
-		}
-		uint32_t area_sum = area_all;
-#pragma unroll
-		for (int d = 32; d > 0; d >>= 1) area_sum += __shfl_xor(area_sum, d, 64);
+		// (on DPP row shifts: twelve __shfl steps are twelve dependent ds_bpermute round trips at the end of every wave)
+		const uint32_t incl = wave_inclusive_sum_dpp(n_inst);
+		const uint32_t area_sum = wave_inclusive_sum_dpp(area_all);   // (lane 63: the wave's total)
 		if (lane == 63) {
 			s_wave[wave] = incl;
 			s_area[wave] = area_sum;

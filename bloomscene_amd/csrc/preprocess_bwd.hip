@@ -215,12 +215,7 @@ __global__ void __launch_bounds__(256, (ROW_F4 == 12 ? 6 : 4)) k_preprocess_bwd(
 		const uint32_t area = (uint32_t)(rc.z - rc.x) * (uint32_t)(rc.w - rc.y);
 		const uint32_t n_inst = area ? kept_count(area, a.geom.kept_mask[idx]) : 0u;
 		const uint32_t off = n_inst ? a.geom.wg_kept[idx >> 8] + a.geom.inst_offset[idx] : 0u;
-		uint32_t incl = n_inst;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const uint32_t t = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += t;
-		}
+		const uint32_t incl = wave_inclusive_sum_dpp(n_inst);   // (DPP row shifts; six __shfl_up steps: six ds_bpermute round trips)
 		const uint32_t excl = incl - n_inst;
 		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		const uint64_t has = wave_ballot(n_inst != 0u);
