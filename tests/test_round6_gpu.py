@@ -88,7 +88,8 @@ def test_forward_during_capture_with_a_pending_overflow_check_fails_loudly():
 def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
     """libbsr_chain_only.so pins the tile-owned chain, libbsr_bucket_always.so k_bucket_sort with 512- / 1024-key areas,
     libbsr_bucket_big.so k_bucket_sort<2048, 1> (wherever they are eligible: up to 8192 tiles); the product library
-    chooses by size.  Every output and gradient of nine frames: three identical
+    chooses by size.  Every output and gradient of eleven frames (two of them with the depths piled on two or three
+    values, so that every form's compare-exchange network sorts them): identical
     digests.  (The order of the tile segments inside point_list differs between the forms; nothing visible may.)"""
     import json
     import os
@@ -107,7 +108,7 @@ def test_both_forms_of_the_second_binning_pass_give_the_same_bits():
         assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
         libs[name] = digest(["--lib", path])
     product = digest([])
-    assert len(product) == 9 and product.keys() == libs["chain_only"].keys() == libs["bucket_always"].keys() == libs["bucket_big"].keys()
+    assert len(product) == 11 and product.keys() == libs["chain_only"].keys() == libs["bucket_always"].keys() == libs["bucket_big"].keys()
     for case in product:
         assert libs["chain_only"][case] == libs["bucket_always"][case], case
         assert libs["chain_only"][case] == libs["bucket_big"][case], case

@@ -27,10 +27,21 @@ if "--plans" in sys.argv:
              "tiles_8160_k4": dict(P=200000, W=1920, H=1080, deg=0, seed=6, scale_mul=1.5),
              "all_long_lists": dict(P=30000, W=20, H=20, deg=0, seed=8, scale_mul=30.0),
              "mostly_culled": dict(P=3000, W=160, H=96, deg=1, seed=9, near_fraction=1.0),
-             "few_tiles": dict(P=500, W=40, H=24, deg=2, seed=10, scale_mul=3.0)}
+             "few_tiles": dict(P=500, W=40, H=24, deg=2, seed=10, scale_mul=3.0),
+             # every Gaussian on one of two depth values: the bucket-and-rank sort declines every segment of more than 64
+             # keys, so each form's NETWORK sorts them -- in k_bucket_sort's 512- / 1024- / 2048-key areas (one wave per
+             # tile), its long-tile path, and the chain's small / mid / wide classes
+             "piled_depths_1k_per_tile": dict(P=60000, W=320, H=192, deg=0, seed=11, scale_mul=3.0, z_levels=2),
+             "piled_depths_300_per_tile": dict(P=40000, W=480, H=270, deg=1, seed=12, scale_mul=1.5, z_levels=3)}
 out = {}
 for name, kw in CASES.items():
+    kw = dict(kw)
+    z_levels = kw.pop("z_levels", 0)
     c = Hh.make_case(**kw)
+    if z_levels:   # (scene A's camera looks down +z from the origin: view depth = z)
+        import torch
+        zm = float(c.means3D[:, 2].median())
+        c.means3D[:, 2] = torch.linspace(0.8 * zm, 1.2 * zm, z_levels)[torch.arange(c.P) % z_levels]
     for dg in ((False,) if "--plans" in sys.argv else (False, True)):
         r = Hh.run_hip(c, depth_gradient=dg)
         d = {"color": r.color, "depth": r.depth, "radii": r.radii}
