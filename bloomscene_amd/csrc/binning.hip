@@ -21,9 +21,12 @@
 //      loads/stores): per-workgroup digit histogram -> 256 parallel row scans -> stable scatter
 //      (wave ballots for the in-round rank, stamped per-wave counters across the 4 waves),
 //   4. k_tile_ranges finds each tile's segment by a 16-ary search (one DPP row of 16 lanes per tile),
-//   5. k_sort_tiles sorts each segment by its 64-bit key in LDS (bitonic network), which yields
+//   5. every segment is sorted by its 64-bit key in LDS (a bucket-and-rank sort where the depths spread, a bitonic
+//      network where they pile up: rank_sort and the sections above it), which yields
 //      exactly the reference's stable-sort order because ids are unique within a tile -- so the
-//      order in which step 2 drops equal-tile elements never reaches the output.
+//      order in which step 2 drops equal-tile elements never reaches the output,
+//   6. frames of up to 8192 tiles with at most 1400 kept instances per tile take steps 3-5 in ONE launch
+//      (k_bucket_sort: the tile segments laid out inside their pass-1 bucket).
 // The earlier version counted and appended instances with global integer atomics (~20 G/s when
 // lane-scattered on MI355X: 0.2 ms at C3, 1.4 ms at C5); this one is also fully deterministic.
 #include "common.h"
@@ -1373,7 +1376,7 @@ __global__ void __launch_bounds__(BSR_SORT_NT) __attribute__((amdgpu_waves_per_e
 //   parts are counted (one wave ballot per element, no LDS traffic), which is all the layout needs: the bucket's range
 //   holds part 0's tiles, then part 1's, ..., inside a part in order of L -- part j begins behind the elements of the
 //   parts before it, which every workgroup of the bucket counts alike, so the segments tile the range.
-//   Then the ranges are written and every wave sorts its TPW tiles in place (the wave-owned network of
+//   Then the ranges are written and every wave sorts its TPW tiles in place (rank_sort, or the wave-owned network of
 //   k_sort_tiles_small, from LDS instead of global memory; up to 64 keys: ranks by counting) and writes the ids.
 //   A tile of more than AREA instances (rare where this kernel is chosen) is staged as plain keys in global scratch
 //   by a second pass over the bucket and sorted by the whole workgroup with the long-tile routines above.
