@@ -111,6 +111,9 @@ struct SyncCache {
 	uint32_t last_kept = 0;      // kept instances of that call (the hint that picks the next call's binning plan)
 	bool pending = false;        // a BSR_FLAG_NO_READBACK forward's copy of the counters is in flight / unchecked
 	size_t pending_capacity = 0;
+	int pending_P = -1, pending_W = -1, pending_H = -1;   // shape of that forward, and (once its counters have been
+	int nr_P = -1, nr_W = -1, nr_H = -1;                  // checked) the shape and kept instances of the last checked one:
+	uint32_t nr_kept = 0;                                 // the plan hint of the next no-readback forward of the same shape
 };
 static SyncCache* sync_cache()
 {
@@ -166,6 +169,8 @@ static int check_deferred(SyncCache* sc)
 	if (hipEventSynchronize(sc->deferred) != hipSuccess)
 		return fail("waiting for the counters of the previous no-readback forward failed: %s", hipGetErrorString(hipGetLastError()));
 	const uint32_t kept = (uint32_t)sc->pinned[2];
+	sc->nr_P = sc->pending_P; sc->nr_W = sc->pending_W; sc->nr_H = sc->pending_H;
+	sc->nr_kept = kept;
 	if ((size_t)kept > sc->pending_capacity)
 		return fail("the previous BSR_FLAG_NO_READBACK forward of this thread kept %u tile instances but was given a capacity "
 		            "of %zu: that frame was not rendered (NaN outputs); its num_rendered was %u",
@@ -516,8 +521,12 @@ static int forward_impl(int V, bsr_alloc_fn geometryBuffer, void* geometry_user,
 			HIP_TRY(hipEventRecord(sc->deferred, s));   // (behind k_scans, which wrote the counters to the pinned buffer)
 			sc->pending = true;
 			sc->pending_capacity = (size_t)given_capacity;
+			sc->pending_P = V == 1 ? P : -1; sc->pending_W = width; sc->pending_H = height;
 		}
-		if (run_tail((size_t)given_capacity, false, 0)) return 1;
+		// the binning plan: from the kept instances of this thread's last CHECKED no-readback forward of the same shape (its
+		// counters were read when this call began), else from the capacity alone -- every plan is correct for every input
+		const bool same = V == 1 && sc->nr_P == P && sc->nr_W == width && sc->nr_H == height;
+		if (run_tail((size_t)given_capacity, false, same ? (long long)sc->nr_kept : 0)) return 1;
 		STAGE_CHECK("render_fwd", debug, s);
 		return 0;
 	}
