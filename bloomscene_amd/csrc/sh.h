@@ -66,9 +66,10 @@ __device__ __forceinline__ void sh_eval(const float* c, float x, float y, float 
 	}
 }
 
-// Degree 3 with M = 16 (the C3 shape), streamed: the 48 floats of a Gaussian come in as three groups of four
-// 16-byte loads and every group is consumed before the next one is requested, so 16 instead of 48 coefficient
-// registers are live (k_preprocess: 92 -> occupancy 5; this path aims at fewer).  The sums run in exactly the
+// Degree 3 with M = 16 (the C3 shape), streamed: the 48 floats of a Gaussian come in as two groups of six
+// 16-byte loads (three of four until the second half of round 6: sh_eval3_stream) and every group is consumed before
+// the next one is requested, so 24 instead of 48 coefficient registers are live (k_preprocess with all 48: 92 VGPRs ->
+// occupancy 5; this path: 62 -> 8).  The sums run in exactly the
 // order of sh_eval<3> (term k of channel ch is added k-th): bit-identical results.
 __device__ __forceinline__ float sh3_basis(int k, float x, float y, float z, float xx, float yy, float zz, float xy,
                                            float yz, float xz)
@@ -99,20 +100,30 @@ __device__ __forceinline__ void sh_eval3_stream(const float* __restrict__ sh, fl
 	const float xy = x * y, yz = y * z, xz = x * z;
 	const float4* s4 = reinterpret_cast<const float4*>(sh);
 	float r[3] = {0.f, 0.f, 0.f};
+	// Twelve 16-byte loads per row in groups, each group consumed before the next is requested (all twelve at once: 92
+	// VGPRs, 5 waves per SIMD instead of 8).  Two groups of six (62 VGPRs), measured on one box: 78.5 us against 83.9 for
+	// three groups of four (55 VGPRs), 93.6 for four of three, 99.0 for six of two; unequal pairs 8 + 4 / 7 + 5 / 4 + 8:
+	// 88.6 / 86.6 / 93.8; groups 0 and 1 of three in flight together: 96.3.  (The rows are 192 B, the cache lines 128: a
+	// line is asked for by more than one group, and a nontemporal load costs the kernel half its speed.)
+#ifndef BSR_SH_GROUP
+#define BSR_SH_GROUP 6
+#endif
+	constexpr int GS = BSR_SH_GROUP;
+	static_assert(12 % GS == 0, "twelve 16-byte loads");
 #pragma unroll
-	for (int g = 0; g < 3; g++) {
+	for (int g = 0; g < 12 / GS; g++) {
 		// the next group's address is made to depend on this point of the sums, or the compiler hoists all twelve
 		// loads to the top again
 		if (g > 0) asm volatile("" : "+v"(s4), "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
-		float v[16];
+		float v[4 * GS];
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-			const float4 q = s4[4 * g + i];
+		for (int i = 0; i < GS; i++) {
+			const float4 q = s4[GS * g + i];
 			v[4 * i + 0] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
 		}
 #pragma unroll
-		for (int j = 0; j < 16; j++) {
-			const int p = 16 * g + j, k = p / 3, ch = p % 3;
+		for (int j = 0; j < 4 * GS; j++) {
+			const int p = 4 * GS * g + j, k = p / 3, ch = p % 3;
 			const float b = sh3_basis(k, x, y, z, xx, yy, zz, xy, yz, xz);
 			if (k == 0) r[ch] = b * v[j];
 			else if (k == 1 || k == 3) r[ch] = r[ch] - b * v[j];
